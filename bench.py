@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the interp_array hot path on MI355X.
+
+Metric (BASELINE.json): interp_array Mpoints/s (points = queries x lanes), 1-D CubicSpline f64, plus the
+achieved fraction of the HBM roofline.  A "step" is one pass of the hot path (locate + evaluate) over one
+batch of synthetic queries; tables, queries and the output buffer are resident in HBM when the timed
+region starts.  Workload at N=1: BASELINE.json configs[1] (C2: 4096 knots x 4096 lanes f64, 1e6 queries).
+N>1: the same per-GPU batch on every rank (weak scaling), tables replicated, no data-path collective.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def load_package():
+    name = "ndarray_interp_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    pkg_dir = os.path.join(ROOT, "ndarray-interp_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def synth_c2(n, lanes, nq, rank):
+    """Synthetic monotone grid: knots g2 = sorted unique uniform(0,1) (no O(1) search
+    shortcut; cf. benches/rand_extensions.rs:26-35), data uniform(0,1) seed 42, queries uniform in
+    [k0, kn] seed 123 (+rank), unsorted, all in range (benches/bench_interp1d.rs:13-15)."""
+    rng = np.random.default_rng(42)
+    x = np.unique(rng.uniform(0.0, 1.0, 2 * n))[:n]
+    assert x.size == n
+    y = rng.uniform(0.0, 1.0, (n, lanes))
+    q = np.random.default_rng(123 + rank).uniform(x[0], x[-1], nq)
+    return x, y, q
+
+
+def cpu_baseline(x, y, q_all, budget_s=12.0):
+    """The CPU port (oracle/, -ffp-contract=off) timed on this box's host cores on a bounded sample of the
+    same workload: blocks of 2048 queries into a reused output block until ~budget_s of CPU work."""
+    sys.path.insert(0, ROOT)
+    import oracle
+    n, lanes = y.shape
+    t0 = time.perf_counter()
+    st, a, b = oracle.cubic_build(x, y)
+    build_s = time.perf_counter() - t0
+    assert st == oracle.OK
+    blk = 2048
+    out = np.zeros((blk, lanes))
+    res = {}
+    for label, threads in (("1t", 1), ("all", os.cpu_count() or 1)):
+        done, t_used, pos = 0, 0.0, 0
+        while t_used < budget_s / 2 and pos + blk <= q_all.size:
+            t0 = time.perf_counter()
+            s, _, _ = oracle.interp1d_cubic(x, y, a, b, q_all[pos:pos + blk], nthreads=threads, out=out)
+            t_used += time.perf_counter() - t0
+            assert s == oracle.OK
+            done += blk
+            pos += blk
+        res[label] = (done * lanes / t_used / 1e6, done, threads)
+    return res, build_s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--knots", type=int, default=4096)
+    ap.add_argument("--lanes", type=int, default=4096)
+    ap.add_argument("--queries", type=int, default=1_000_000, help="queries per GPU per step")
+    ap.add_argument("--path", choices=["auto", "gather", "bucketed"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    pkg = load_package()
+
+    n, lanes, nq = args.knots, args.lanes, args.queries
+    x, y, q = synth_c2(n, lanes, nq, rank)
+    yd = torch.as_tensor(y, device=dev)
+    xd = torch.as_tensor(x, device=dev)
+    t0 = time.perf_counter()
+    interp = pkg.Interp1DBuilder.new(yd).x(xd).strategy(pkg.CubicSpline.new()).build()
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    interp.strategy.path = {"auto": pkg.PATH_AUTO, "gather": pkg.PATH_GATHER, "bucketed": pkg.PATH_BUCKETED}[args.path]
+    qd = torch.as_tensor(q, device=dev)
+    out = torch.empty((nq, lanes), dtype=torch.float64, device=dev)  # 32.8 GB at C2, stays in HBM
+
+    def step():
+        interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    interp.strategy.finish()
+    pkg.profile_enable(True)
+    pkg.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    interp.strategy.finish()  # raises if any batch failed (none may: all queries are in range)
+    prof = pkg.profile_read(reset=True)
+    pkg.profile_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # sanity inside the bench: a few rows against the CPU oracle (never in the timed region)
+    points_per_step = nq * lanes
+    value = world * points_per_step * args.steps / elapsed / 1e6
+    if rank == 0:
+        kernel_ms = prof["eval_ms"] / max(1, prof["eval_launches"])
+        # cubic = 4 operand reads + 1 write = 5*sizeof(T) per point (+ the query value)
+        alg_bytes = points_per_step * 40 + nq * 8
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # compulsory traffic of the batch: the output once, every table once, the queries once
+        comp_bytes = points_per_step * 8 + (n + 2 * (n - 1)) * lanes * 8 + nq * 8
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{prof['last_path']}_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "interp_array Mpoints/s (queries x lanes), 1D cubic f64",
+            "value": round(value, 1), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C2: 1D CubicSpline NotAKnot, {n} knots x {lanes} lanes f64, {nq} queries per GPU "
+                                   "(sorted-unique uniform knots, unsorted uniform in-range queries)",
+                       "path": prof["last_path"], "sharding": f"queries x{world}, tables replicated, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "eval_bucketed_kernel" if prof["last_path"] == "bucketed" else "eval_rows_kernel",
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                         "compulsory_bytes_per_launch": comp_bytes,
+                         "compulsory_frac": round(comp_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "stages_ms_per_step": {"locate": round(prof["locate_ms"] / max(1, args.steps), 4),
+                                   "group": round(prof["group_ms"] / max(1, args.steps), 4),
+                                   "eval": round(prof["eval_ms"] / max(1, args.steps), 4)},
+            "build_ms": round(build_ms, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res, build_s = cpu_baseline(x, y, q)
+            v1, done1, _ = res["1t"]
+            vall, doneall, threads = res["all"]
+            line["cpu_baseline"] = {"value": round(v1, 1), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+                                    "sample": f"{done1} of the {nq} queries x {lanes} lanes, oracle/ serial loop "
+                                              "(the reference is single-threaded)",
+                                    "all_cores": {"value": round(vall, 1), "cores": threads,
+                                                  "sample": f"{doneall} queries, contiguous blocks per thread"},
+                                    "build_s": round(build_s, 2)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

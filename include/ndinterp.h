@@ -1,0 +1,234 @@
+/* include/ndinterp.h -- C ABI of libndinterp_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the batched `interp_array` hot path of the Rust crate
+ * ndarray-interp v0.6.0 (1D Linear, 1D CubicSpline, 2D Bilinear).  The reference
+ * has no FFI of its own: its boundary is the strategy trait pair plus the inherent
+ * methods of Interp1D / Interp2D.  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference tree).  A Rust
+ * `extern "C"` block binding exactly these symbols, and the strategy overrides that
+ * call them, are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; no exceptions, no panics cross the ABI; every call
+ *    returns an ndi_status (ndi_last_error_string() has the text for the calling
+ *    thread).
+ *  - element type T is selected per handle by ndi_dtype (f32 / f64 only: the GPU
+ *    path covers the float types; integer element types stay on the host's generic
+ *    per-query path).
+ *  - arrays are C-order and contiguous: data[n][lanes], data2d[nx][ny][lanes];
+ *    "lanes" = product of the trailing (non-interpolated) axes.
+ *  - every pointer argument carries a memory space (host or device).  Device
+ *    pointers must belong to the handle's device.
+ *  - the product has NO CPU fallback: without a usable HIP device every compute
+ *    entry point fails with NDI_HIP_ERROR.
+ */
+#ifndef NDINTERP_H
+#define NDINTERP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDI_VERSION_MAJOR 0
+#define NDI_VERSION_MINOR 1
+
+/* BuilderError / InterpolateError (src/lib.rs:127-146) + ABI-only codes. */
+typedef enum ndi_status {
+  NDI_OK = 0,
+  NDI_NOT_ENOUGH_DATA = 1, /* BuilderError::NotEnoughData                                  */
+  NDI_MONOTONIC = 2,       /* BuilderError::Monotonic                                      */
+  NDI_SHAPE = 3,           /* BuilderError::ShapeError                                     */
+  NDI_VALUE = 4,           /* BuilderError::ValueError (periodic y[0] != y[n-1])           */
+  NDI_OUT_OF_BOUNDS = 5,   /* InterpolateError::OutOfBounds                                */
+  NDI_NAN_QUERY = 6,       /* reference panics: vector_extensions.rs:83-84                 */
+  NDI_HIP_ERROR = 7,       /* no device / HIP runtime failure                              */
+  NDI_BAD_ARG = 8,
+  NDI_UNSUPPORTED = 9
+} ndi_status;
+
+typedef enum ndi_dtype { NDI_F32 = 0, NDI_F64 = 1 } ndi_dtype;
+typedef enum ndi_memspace { NDI_MEM_HOST = 0, NDI_MEM_DEVICE = 1 } ndi_memspace;
+
+/* 1D strategies: Linear (src/interp1d/strategies/linear.rs),
+ * CubicSpline (src/interp1d/strategies/cubic_spline.rs). */
+typedef enum ndi_strategy1d { NDI_LINEAR = 0, NDI_CUBIC_SPLINE = 1 } ndi_strategy1d;
+
+/* SingleBoundary (cubic_spline.rs:204-217).  Natural == SecondDeriv(0),
+ * Clamped == FirstDeriv(0) (:287-296). */
+typedef enum ndi_bc_kind {
+  NDI_BC_NOT_A_KNOT = 0,
+  NDI_BC_NATURAL = 1,
+  NDI_BC_CLAMPED = 2,
+  NDI_BC_FIRST_DERIV = 3,
+  NDI_BC_SECOND_DERIV = 4
+} ndi_bc_kind;
+
+typedef struct ndi_boundary {
+  int32_t kind; /* ndi_bc_kind */
+  double value; /* derivative value for FIRST_DERIV / SECOND_DERIV */
+} ndi_boundary;
+
+/* Monotonic (src/vector_extensions.rs:25-29). */
+typedef enum ndi_monotonic {
+  NDI_MONO_NOT = 0,
+  NDI_MONO_RISING_STRICT = 1,
+  NDI_MONO_RISING = 2,
+  NDI_MONO_FALLING_STRICT = 3,
+  NDI_MONO_FALLING = 4
+} ndi_monotonic;
+
+/* Evaluation formulation (results are identical):
+ *  GATHER   one coalesced row gather per query (4 operand rows in, 1 row out);
+ *  BUCKETED queries are grouped by interval on the device so each table row is
+ *           read once per group and the kernel becomes a pure output stream;
+ *  AUTO     BUCKETED when the batch has enough queries per interval to pay for
+ *           the grouping pass, else GATHER. */
+typedef enum ndi_path { NDI_PATH_AUTO = 0, NDI_PATH_GATHER = 1, NDI_PATH_BUCKETED = 2 } ndi_path;
+
+/* Replaces Interp1DBuilder::{new,x,strategy,build} (src/interp1d/mod.rs:399-476)
+ * + Interp1DStrategyBuilder::build (src/interp1d/strategies/mod.rs:12-40):
+ * Linear::build (linear.rs:54-63) / CubicSpline::build (cubic_spline.rs:754-771). */
+typedef struct ndi_interp1d_desc {
+  int32_t dtype;       /* ndi_dtype */
+  int32_t strategy;    /* ndi_strategy1d */
+  int32_t extrapolate; /* Linear::extrapolate / CubicSpline::extrapolate (bool) */
+  int32_t device;      /* HIP device ordinal */
+  uint64_t n;          /* data.shape()[0] */
+  uint64_t lanes;      /* product of data.shape()[1..] (1 for 1-D data) */
+  uint64_t x_len;      /* x.len(); checked against n exactly as build() does (:465-471) */
+  const void* x;       /* T[x_len] knots, or NULL for the default axis 0..n (:402-406) */
+  const void* data;    /* T[n * lanes] */
+  int32_t memspace;    /* ndi_memspace of x and data */
+  int32_t validate;    /* != 0: run Interp1DBuilder::build's checks (:449-471) here */
+  /* CubicSpline boundary (BoundaryCondition, cubic_spline.rs:153-168) */
+  int32_t periodic;    /* BoundaryCondition::Periodic */
+  ndi_boundary left;   /* applied to every lane unless lane_* are given */
+  ndi_boundary right;
+  /* BoundaryCondition::Individual (per trailing element, cubic_spline.rs:332-347):
+   * arrays of `lanes` entries, host memory; all four NULL for a global boundary. */
+  const int32_t* lane_left_kind;
+  const double* lane_left_value;
+  const int32_t* lane_right_kind;
+  const double* lane_right_value;
+} ndi_interp1d_desc;
+
+/* Replaces Interp2DBuilder::{new,x,y,strategy,build} (src/interp2d/mod.rs:382-519)
+ * + Bilinear::build (src/interp2d/strategies/bilinear.rs:45-52). */
+typedef struct ndi_interp2d_desc {
+  int32_t dtype;
+  int32_t extrapolate; /* Bilinear::extrapolate */
+  int32_t device;
+  int32_t memspace;    /* of x, y, data */
+  uint64_t nx, ny;     /* data.shape()[0], data.shape()[1] */
+  uint64_t lanes;      /* product of data.shape()[2..] */
+  uint64_t x_len, y_len;
+  const void* x;       /* T[x_len] or NULL for 0..nx (:389-393) */
+  const void* y;       /* T[y_len] or NULL for 0..ny (:394-398) */
+  const void* data;    /* T[nx * ny * lanes] */
+  int32_t validate;    /* != 0: run Interp2DBuilder::build's checks (:477-509) here */
+  int32_t reserved;
+} ndi_interp2d_desc;
+
+typedef struct ndi_interp1d ndi_interp1d; /* owns device copies of x, data (and a, b) */
+typedef struct ndi_interp2d ndi_interp2d;
+
+/* First failing query of a batch: the reference's query loop stops at the first Err
+ * (src/interp1d/mod.rs:334-342, src/interp2d/mod.rs:297-306).  `index` is the lowest
+ * flat query index that failed, `value` the offending coordinate and `axis` 0 for x,
+ * 1 for y (x is tested before y for the same query: bilinear.rs:71-80), so the host
+ * can format the reference's message ("x = {x:#?} is not in range"). */
+typedef struct ndi_oob_info {
+  uint64_t index;
+  double value;
+  int32_t axis;
+  int32_t status; /* NDI_OUT_OF_BOUNDS or NDI_NAN_QUERY */
+} ndi_oob_info;
+
+typedef struct ndi_eval_opts {
+  int32_t q_memspace;   /* ndi_memspace of the query array(s) */
+  int32_t out_memspace; /* ndi_memspace of the output buffer */
+  void* stream;         /* hipStream_t, or NULL for a library-owned per-thread stream */
+  int32_t path;         /* ndi_path */
+  int32_t async_launch; /* != 0 (device out only): enqueue and return; fetch the batch
+                           status later with ndi_interp{1,2}d_finish on the same stream */
+} ndi_eval_opts;
+
+/* ---- build ------------------------------------------------------------------ */
+ndi_status ndi_interp1d_create(const ndi_interp1d_desc* desc, ndi_interp1d** out);
+void ndi_interp1d_destroy(ndi_interp1d* h);
+ndi_status ndi_interp2d_create(const ndi_interp2d_desc* desc, ndi_interp2d** out);
+void ndi_interp2d_destroy(ndi_interp2d* h);
+
+/* CubicSplineStrategy{a, b} (cubic_spline.rs:94-102): copies the coefficient tables,
+ * each T[(n-1) * lanes], to `a_out` / `b_out` (either may be NULL). */
+ndi_status ndi_interp1d_coefficients(const ndi_interp1d* h, void* a_out, void* b_out,
+                                     int32_t memspace);
+
+/* ---- evaluate ----------------------------------------------------------------
+ * Replaces Interp1D::interp_array_into for a flattened query array
+ * (src/interp1d/mod.rs:272-343) with Linear::interp_into (linear.rs:73-98) or
+ * CubicSplineStrategy::interp_into (cubic_spline.rs:791-830) as the per-query body:
+ *   out[i * out_row_stride + l] = strategy(q[i])[l],  i < nq, l < lanes.
+ * out_row_stride is in elements (>= lanes).  On NDI_OUT_OF_BOUNDS / NDI_NAN_QUERY
+ * rows before info->index are written and later rows are untouched, as in the
+ * reference.  General-rank queries are a flatten on the caller's side. */
+ndi_status ndi_interp1d_eval(const ndi_interp1d* h, const void* q, uint64_t nq, void* out,
+                             uint64_t out_row_stride, const ndi_eval_opts* opts,
+                             ndi_oob_info* info);
+
+/* Replaces Interp2D::interp_array_into (src/interp2d/mod.rs:215-307) with
+ * Bilinear::interp_into (bilinear.rs:64-99) as the per-query body. */
+ndi_status ndi_interp2d_eval(const ndi_interp2d* h, const void* qx, const void* qy, uint64_t nq,
+                             void* out, uint64_t out_row_stride, const ndi_eval_opts* opts,
+                             ndi_oob_info* info);
+
+/* Completes async_launch evaluations on `stream`: synchronises it and reports the
+ * status of the last batch enqueued there. */
+ndi_status ndi_interp1d_finish(const ndi_interp1d* h, void* stream, ndi_oob_info* info);
+ndi_status ndi_interp2d_finish(const ndi_interp2d* h, void* stream, ndi_oob_info* info);
+
+/* ---- helpers on the path ------------------------------------------------------ */
+/* VectorExtensions::get_lower_index (src/vector_extensions.rs:55-111), batched:
+ * out_idx[i] = the unique j with knots[j] <= q[i] < knots[j+1], clamped to [0, n-2];
+ * -1 for a NaN query.  Device search (wavefront-cooperative, knots in LDS). */
+ndi_status ndi_get_lower_index_batch(int32_t dtype, int32_t device, const void* knots, uint64_t n,
+                                     const void* q, uint64_t nq, int64_t* out_idx,
+                                     int32_t memspace);
+
+/* VectorExtensions::monotonic_prop (src/vector_extensions.rs:40-53, 116-198).
+ * Host-side O(n) validation; returns an ndi_monotonic. */
+int32_t ndi_monotonic_prop(int32_t dtype, const void* host_v, uint64_t n);
+
+/* Interp1DBuilder::build / Interp2DBuilder::build checks alone (host). */
+ndi_status ndi_validate1d(int32_t dtype, const void* host_x, uint64_t x_len, uint64_t n,
+                          int32_t strategy);
+ndi_status ndi_validate2d(int32_t dtype, const void* host_x, uint64_t x_len, const void* host_y,
+                          uint64_t y_len, uint64_t nx, uint64_t ny);
+
+/* ---- runtime ------------------------------------------------------------------ */
+int32_t ndi_device_count(void);
+const char* ndi_last_error_string(void);
+uint32_t ndi_version(void); /* (major << 16) | minor */
+
+/* Per-kernel HIP-event timing of the evaluation stages, recorded on the stream the
+ * kernels run on.  Enable, run evaluations, then read (read synchronises the events). */
+typedef struct ndi_profile {
+  uint64_t eval_launches;   /* dominant kernel: gather / bucketed evaluation */
+  double eval_ms;           /* summed duration of those launches */
+  uint64_t locate_launches; /* per-query search kernel */
+  double locate_ms;
+  uint64_t group_launches;  /* bucketed path only: count + scan + scatter kernels */
+  double group_ms;
+  int32_t last_path;        /* ndi_path actually taken by the last evaluation */
+  int32_t reserved;
+} ndi_profile;
+void ndi_profile_enable(int32_t on);
+ndi_status ndi_profile_read(ndi_profile* out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDINTERP_H */

@@ -1,0 +1,664 @@
+// csrc/kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
+//
+// Everything here is HBM-bound gather/stream work (no dense contraction, so no MFMA):
+//   locate_kernel          per-query interval search, wavefront-cooperative 64-ary search
+//                          over a knot pyramid staged in LDS          (vector_extensions.rs:55-111)
+//   eval_rows_kernel       GATHER formulation, one row segment per workgroup pass, 16-byte
+//                          coalesced loads of the operand rows fused with the polynomial
+//                          (linear.rs:94-96, cubic_spline.rs:818-828)
+//   eval_flat_kernel       same arithmetic for short / unaligned rows and for Bilinear
+//                          (bilinear.rs:83-97): one 16-byte (or scalar) output vector per thread
+//   bucket_* + eval_bucketed_kernel
+//                          BUCKETED formulation: queries grouped by interval (counting sort),
+//                          operand rows held in registers across a group, output streamed
+//   spline_build_*         batched Thomas solve, one lane of the trailing axes per thread,
+//                          shared elimination factors (cubic_spline.rs:310-368, 409-721)
+//
+// Arithmetic is written in the reference's operation order and the translation unit is
+// compiled with -ffp-contract=off, so results are bit-identical to a non-fused CPU evaluation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ndi {
+
+constexpr unsigned long long NO_FAIL = ~0ull;
+constexpr int BLOCK = 256;
+
+enum ExtrapMode : int { EX_NO = 0, EX_YES = 1, EX_PERIODIC = 2 };
+enum Strat : int { ST_LINEAR = 0, ST_CUBIC = 1 };
+
+// Device-resident per-evaluation status (one per workspace).
+struct StatusBlock {
+  unsigned long long first_fail[2];  // lowest failing flat query index per axis (x, y)
+  unsigned long long n_valid;        // bucketed path: number of grouped queries
+  unsigned long long periodic_mismatch;  // build: lanes with y[0] != y[n-1]
+};
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef float flt4 __attribute__((ext_vector_type(4)));
+
+template <class T, int VEC>
+struct VecT;
+template <>
+struct VecT<double, 2> { using type = dbl2; };
+template <>
+struct VecT<float, 4> { using type = flt4; };
+template <>
+struct VecT<double, 1> { using type = double; };
+template <>
+struct VecT<float, 1> { using type = float; };
+
+template <class T>
+struct Wide;
+template <>
+struct Wide<double> { static constexpr int N = 2; };
+template <>
+struct Wide<float> { static constexpr int N = 4; };
+
+__device__ __forceinline__ float readlane_t(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double readlane_t(double v, int lane) {
+  unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Euclid::rem_euclid for floats: r = a % b; r < 0 ? r + |b| : r   (cubic_spline.rs:808)
+__device__ __forceinline__ float rem_euclid_t(float a, float b) {
+  float r = fmodf(a, b);
+  return (r < 0.0f) ? r + fabsf(b) : r;
+}
+__device__ __forceinline__ double rem_euclid_t(double a, double b) {
+  double r = fmod(a, b);
+  return (r < 0.0) ? r + fabs(b) : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// locate: knot pyramid  lv0 = knots[n], lv1[j] = knots[64 j], lv2[j] = knots[4096 j]
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Pyramid {
+  const T* lv0;
+  const T* lv1;
+  const T* lv2;
+  uint32_t n, n1, n2;
+  int levels;  // 1, 2 or 3
+};
+
+// Number of knots <= x for a wave-uniform x, found cooperatively: each level has the 64 lanes
+// probe 64 consecutive pyramid entries (conflict-free LDS reads), ballot, popcount.
+// NaN compares false everywhere -> 0.
+template <class T>
+__device__ __forceinline__ uint32_t wave_count_le(const Pyramid<T>& P, T x, uint32_t lane) {
+  uint32_t blk = 0;
+  if (P.levels >= 3) {
+    bool p = lane < P.n2 && P.lv2[lane] <= x;
+    uint32_t c = (uint32_t)__popcll(__ballot(p));
+    if (c == 0) return 0;
+    blk = c - 1;
+  }
+  if (P.levels >= 2) {
+    uint32_t pos = blk * 64u + lane;
+    bool p = pos < P.n1 && P.lv1[pos] <= x;
+    uint32_t c = (uint32_t)__popcll(__ballot(p));
+    if (c == 0) return 0;
+    blk = blk * 64u + c - 1;
+  }
+  uint32_t pos = blk * 64u + lane;
+  bool p = pos < P.n && P.lv0[pos] <= x;
+  uint32_t c = (uint32_t)__popcll(__ballot(p));
+  return blk * 64u + c;
+}
+
+template <class T>
+struct LocateArgs {
+  Pyramid<T> pyr;          // global-memory pyramid
+  const T* q;              // queries
+  uint64_t nq;
+  uint32_t* idx;           // out: interval index per query (nullable)
+  int64_t* idx64;          // out: ndi_get_lower_index_batch result, -1 for NaN (nullable)
+  T* t;                    // out (cubic): (x - x_l) / (x_r - x_l) (nullable)
+  unsigned long long* first_fail;  // atomicMin target
+  int mode;                // ExtrapMode
+  int stage_lds;           // copy the pyramid into LDS first
+};
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void locate_kernel(LocateArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Pyramid<T> P = A.pyr;
+  const uint32_t tid = threadIdx.x;
+  if (A.stage_lds) {
+    T* s0 = reinterpret_cast<T*>(smem_raw);
+    T* s1 = s0 + P.n;
+    T* s2 = s1 + P.n1;
+    for (uint32_t i = tid; i < P.n; i += BLOCK) s0[i] = A.pyr.lv0[i];
+    for (uint32_t i = tid; i < P.n1; i += BLOCK) s1[i] = A.pyr.lv1[i];
+    for (uint32_t i = tid; i < P.n2; i += BLOCK) s2[i] = A.pyr.lv2[i];
+    __syncthreads();
+    P.lv0 = s0;
+    P.lv1 = s1;
+    P.lv2 = s2;
+  }
+  const T k0 = P.lv0[0];
+  const T kn = P.lv0[P.n - 1];
+  const uint32_t lane = tid & 63u;
+  const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + (tid >> 6);
+  const uint64_t wave_stride = (uint64_t)gridDim.x * (BLOCK / 64);
+  for (uint64_t base = wave_global * 64u; base < A.nq; base += wave_stride * 64u) {
+    const uint64_t qi = base + lane;
+    const bool active = qi < A.nq;
+    const T x = active ? A.q[qi] : k0;
+    const bool inr = (k0 <= x) && (x <= kn);   // Interp1D::is_in_range, interp1d/mod.rs:384-386
+    T xs = x;
+    if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;
+    const int cnt = (A.nq - base < 64u) ? (int)(A.nq - base) : 64;
+    uint32_t ub = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const T xj = readlane_t(xs, j);
+      const uint32_t c = wave_count_le(P, xj, lane);
+      if (lane == (uint32_t)j) ub = c;
+    }
+    if (!active) continue;
+    // unique i with k[i] <= x < k[i+1], clamped to [0, n-2]  (vector_extensions.rs:61-66, 100-110)
+    uint32_t i = (ub == 0) ? 0u : ub - 1u;
+    if (i > P.n - 2u) i = P.n - 2u;
+    const bool isnan_q = !(xs == xs);
+    const bool bad = (A.mode == EX_NO) ? !inr : isnan_q;
+    if (bad && A.first_fail) atomicMin(A.first_fail, (unsigned long long)qi);
+    if (A.idx) A.idx[qi] = i;
+    if (A.idx64) A.idx64[qi] = isnan_q ? (int64_t)-1 : (int64_t)i;
+    if (A.t) {
+      const T xl = P.lv0[i], xr = P.lv0[i + 1];
+      A.t[qi] = (xs - xl) / (xr - xl);  // cubic_spline.rs:818
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1-D evaluation
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Eval1Args {
+  const T* knots;
+  const T* data;   // [n][lanes]
+  const T* ca;     // [n-1][lanes] (cubic)
+  const T* cb;
+  const T* q;      // raw queries (linear uses x itself)
+  const uint32_t* idx;
+  const T* t;      // cubic
+  T* out;
+  uint64_t lanes, out_stride, nq;
+  const StatusBlock* status;
+  // bucketed
+  const uint32_t* perm;
+};
+
+// Per-query scalars shared by all lanes of a row.
+template <class T, int STRAT>
+struct RowCoef {
+  T c0, c1, c2;  // cubic: (1-t), t, t(1-t)      linear: (x2-x1), (x-x1), unused
+};
+
+template <class T, int STRAT>
+__device__ __forceinline__ RowCoef<T, STRAT> row_coef(const T* knots, uint32_t i, T xq, T t) {
+  RowCoef<T, STRAT> c;
+  if (STRAT == ST_CUBIC) {
+    const T one = T(1);
+    c.c0 = one - t;
+    c.c1 = t;
+    c.c2 = t * (one - t);
+  } else {
+    const T x1 = knots[i], x2 = knots[i + 1];
+    c.c0 = x2 - x1;
+    c.c1 = xq - x1;
+    c.c2 = T(0);
+  }
+  return c;
+}
+
+// cubic_spline.rs:825-827:  (1-t)*yl + t*yr + t*(1-t)*(a*(1-t) + b*t)
+// linear.rs:33-35:          ((y2-y1)/(x2-x1)) * (x-x1) + y1
+template <class T, int STRAT, class V>
+__device__ __forceinline__ V row_point(const RowCoef<T, STRAT>& c, V yl, V yr, V a, V b) {
+  if (STRAT == ST_CUBIC) {
+    return c.c0 * yl + c.c1 * yr + c.c2 * (a * c.c0 + b * c.c1);
+  } else {
+    V m = (yr - yl) / c.c0;
+    return m * c.c1 + yl;
+  }
+}
+
+template <class V>
+__device__ __forceinline__ void store_stream(V* p, V v) {
+  __builtin_nontemporal_store(v, p);
+}
+
+// GATHER, long rows: grid.x strides over queries, grid.y over 256*U-vector segments of a row.
+template <class T, int STRAT, int U>
+__global__ __launch_bounds__(BLOCK) void eval_rows_kernel(Eval1Args<T> A) {
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  const uint64_t LV = A.lanes / VN;
+  const uint32_t seg_vecs = BLOCK * U;
+  const uint32_t segs = (uint32_t)((LV + seg_vecs - 1) / seg_vecs);
+  unsigned long long limit = A.status->first_fail[0];
+  if (limit > A.nq) limit = A.nq;
+  for (uint64_t qi = blockIdx.x; qi < limit; qi += gridDim.x) {
+    const uint32_t i = A.idx[qi];
+    const RowCoef<T, STRAT> c =
+        row_coef<T, STRAT>(A.knots, i, STRAT == ST_LINEAR ? A.q[qi] : T(0),
+                           STRAT == ST_CUBIC ? A.t[qi] : T(0));
+    const V* yl = reinterpret_cast<const V*>(A.data + (uint64_t)i * A.lanes);
+    const V* yr = yl + LV;
+    const V* pa = reinterpret_cast<const V*>(A.ca + (uint64_t)i * A.lanes);
+    const V* pb = reinterpret_cast<const V*>(A.cb + (uint64_t)i * A.lanes);
+    V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
+    for (uint32_t seg = blockIdx.y; seg < segs; seg += gridDim.y) {
+      const uint64_t v0 = (uint64_t)seg * seg_vecs + threadIdx.x;
+      V ryl[U], ryr[U], ra[U], rb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t v = v0 + (uint64_t)u * BLOCK;
+        if (v < LV) {
+          ryl[u] = yl[v];
+          ryr[u] = yr[v];
+          if (STRAT == ST_CUBIC) {
+            ra[u] = pa[v];
+            rb[u] = pb[v];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t v = v0 + (uint64_t)u * BLOCK;
+        if (v < LV) store_stream(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
+      }
+    }
+  }
+}
+
+// GATHER, short / unaligned rows: one VEC-wide output vector per thread, several queries per
+// workgroup tile.  tile_q queries x LV vectors <= 2^31 items per tile.
+template <class T, int STRAT, int VEC>
+__global__ __launch_bounds__(BLOCK) void eval_flat_kernel(Eval1Args<T> A, uint32_t tile_q) {
+  using V = typename VecT<T, VEC>::type;
+  const uint32_t LV = (uint32_t)(A.lanes / VEC);
+  unsigned long long limit = A.status->first_fail[0];
+  if (limit > A.nq) limit = A.nq;
+  const uint64_t ntiles = (limit + tile_q - 1) / tile_q;
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t q0 = tile * tile_q;
+    const uint32_t nq_here = (limit - q0 < tile_q) ? (uint32_t)(limit - q0) : tile_q;
+    const uint32_t items = nq_here * LV;
+    for (uint32_t it = threadIdx.x; it < items; it += BLOCK) {
+      const uint32_t ql = it / LV;
+      const uint32_t v = it - ql * LV;
+      const uint64_t qi = q0 + ql;
+      const uint32_t i = A.idx[qi];
+      const RowCoef<T, STRAT> c =
+          row_coef<T, STRAT>(A.knots, i, STRAT == ST_LINEAR ? A.q[qi] : T(0),
+                             STRAT == ST_CUBIC ? A.t[qi] : T(0));
+      const V* yl = reinterpret_cast<const V*>(A.data + (uint64_t)i * A.lanes);
+      const V* yr = reinterpret_cast<const V*>(A.data + (uint64_t)(i + 1) * A.lanes);
+      V a = V(0), b = V(0);
+      if (STRAT == ST_CUBIC) {
+        a = reinterpret_cast<const V*>(A.ca + (uint64_t)i * A.lanes)[v];
+        b = reinterpret_cast<const V*>(A.cb + (uint64_t)i * A.lanes)[v];
+      }
+      V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
+      o[v] = row_point<T, STRAT, V>(c, yl[v], yr[v], a, b);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BUCKETED: counting sort of the valid queries by interval, then a streaming evaluation
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void bucket_count_kernel(const uint32_t* idx, uint64_t nq,
+                                                             const StatusBlock* status,
+                                                             uint32_t* counts) {
+  unsigned long long limit = status->first_fail[0];
+  if (limit > nq) limit = nq;
+  for (uint64_t qi = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; qi < limit;
+       qi += (uint64_t)gridDim.x * BLOCK)
+    atomicAdd(&counts[idx[qi]], 1u);
+}
+
+// Single-workgroup exclusive scan of nb counters -> cursor[] (start offsets); n_valid = total.
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* counts, uint32_t nb,
+                                                           uint32_t* cursor, StatusBlock* status) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (nb + 1023u) / 1024u;
+  const uint32_t b0 = tid * per;
+  uint32_t s = 0;
+  for (uint32_t k = 0; k < per; ++k)
+    if (b0 + k < nb) s += counts[b0 + k];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024u; off <<= 1) {  // Hillis-Steele inclusive scan
+    uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = (tid == 0) ? 0u : part[tid - 1];
+  for (uint32_t k = 0; k < per; ++k)
+    if (b0 + k < nb) {
+      cursor[b0 + k] = run;
+      run += counts[b0 + k];
+    }
+  if (tid == 1023u) status->n_valid = part[1023];
+}
+
+__global__ __launch_bounds__(BLOCK) void bucket_scatter_kernel(const uint32_t* idx, uint64_t nq,
+                                                               const StatusBlock* status,
+                                                               uint32_t* cursor, uint32_t* perm) {
+  unsigned long long limit = status->first_fail[0];
+  if (limit > nq) limit = nq;
+  for (uint64_t qi = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; qi < limit;
+       qi += (uint64_t)gridDim.x * BLOCK) {
+    const uint32_t pos = atomicAdd(&cursor[idx[qi]], 1u);
+    perm[pos] = (uint32_t)qi;
+  }
+}
+
+// One workgroup streams CQ grouped queries x one 256*U-vector row segment.  The four operand
+// row segments stay in registers while the interval does not change, so table traffic is
+// ~ (1/CQ + 1/queries-per-interval) of the gather formulation and the kernel is an output stream.
+template <class T, int STRAT, int U, int CQ>
+__global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  __shared__ uint32_t s_q[CQ];
+  __shared__ uint32_t s_i[CQ];
+  __shared__ T s_s[CQ];  // cubic: t          linear: raw x
+  const uint64_t LV = A.lanes / VN;
+  const uint32_t seg_vecs = BLOCK * U;
+  const uint32_t segs = (uint32_t)((LV + seg_vecs - 1) / seg_vecs);
+  const unsigned long long n_valid = A.status->n_valid;
+  const uint64_t nchunks = (n_valid + CQ - 1) / CQ;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t p0 = chunk * CQ;
+    const uint32_t cnt = (n_valid - p0 < (uint64_t)CQ) ? (uint32_t)(n_valid - p0) : (uint32_t)CQ;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) {
+      const uint32_t qi = A.perm[p0 + j];
+      s_q[j] = qi;
+      s_i[j] = A.idx[qi];
+      s_s[j] = (STRAT == ST_CUBIC) ? A.t[qi] : A.q[qi];
+    }
+    __syncthreads();
+    for (uint32_t seg = blockIdx.y; seg < segs; seg += gridDim.y) {
+      const uint64_t v0 = (uint64_t)seg * seg_vecs + threadIdx.x;
+      V ryl[U], ryr[U], ra[U], rb[U];
+      uint32_t cur = 0xffffffffu;
+      for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_i[j]);
+        const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_q[j]);
+        const T sj = s_s[j];
+        if (i != cur) {
+          cur = i;
+          const V* yl = reinterpret_cast<const V*>(A.data + (uint64_t)i * A.lanes);
+          const V* yr = yl + LV;
+          const V* pa = reinterpret_cast<const V*>(A.ca + (uint64_t)i * A.lanes);
+          const V* pb = reinterpret_cast<const V*>(A.cb + (uint64_t)i * A.lanes);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint64_t v = v0 + (uint64_t)u * BLOCK;
+            if (v < LV) {
+              ryl[u] = yl[v];
+              ryr[u] = yr[v];
+              if (STRAT == ST_CUBIC) {
+                ra[u] = pa[v];
+                rb[u] = pb[v];
+              }
+            }
+          }
+        }
+        const RowCoef<T, STRAT> c = row_coef<T, STRAT>(A.knots, i, sj, sj);
+        V* o = reinterpret_cast<V*>(A.out + (uint64_t)qi * A.out_stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint64_t v = v0 + (uint64_t)u * BLOCK;
+          if (v < LV) store_stream(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2-D bilinear (bilinear.rs:83-97): z = frac(y; frac(x; z11,z21), frac(x; z12,z22))
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Eval2Args {
+  const T* xk;
+  const T* yk;
+  const T* data;  // [nx][ny][lanes]
+  const T* qx;
+  const T* qy;
+  const uint32_t* xi;
+  const uint32_t* yi;
+  T* out;
+  uint64_t ny, lanes, out_stride, nq;
+  const StatusBlock* status;
+};
+
+template <class T, class V>
+__device__ __forceinline__ V frac_v(T x1, V y1, T x2, V y2, T x) {
+  V m = (y2 - y1) / (x2 - x1);  // Linear::calc_frac, linear.rs:33-35
+  return m * (x - x1) + y1;
+}
+
+template <class T, int VEC>
+__global__ __launch_bounds__(BLOCK) void eval_bilinear_kernel(Eval2Args<T> A, uint32_t tile_q) {
+  using V = typename VecT<T, VEC>::type;
+  const uint32_t LV = (uint32_t)(A.lanes / VEC);
+  unsigned long long limit = A.status->first_fail[0];
+  if (A.status->first_fail[1] < limit) limit = A.status->first_fail[1];
+  if (limit > A.nq) limit = A.nq;
+  const uint64_t ntiles = (limit + tile_q - 1) / tile_q;
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t q0 = tile * tile_q;
+    const uint32_t nq_here = (limit - q0 < tile_q) ? (uint32_t)(limit - q0) : tile_q;
+    const uint32_t items = nq_here * LV;
+    for (uint32_t it = threadIdx.x; it < items; it += BLOCK) {
+      const uint32_t ql = it / LV;
+      const uint32_t v = it - ql * LV;
+      const uint64_t qi = q0 + ql;
+      const uint32_t xi = A.xi[qi], yi = A.yi[qi];
+      const T x = A.qx[qi], y = A.qy[qi];
+      const T x1 = A.xk[xi], x2 = A.xk[xi + 1];
+      const T y1 = A.yk[yi], y2 = A.yk[yi + 1];
+      const V* z11 = reinterpret_cast<const V*>(A.data + ((uint64_t)xi * A.ny + yi) * A.lanes);
+      const V* z12 = z11 + LV;                                    // (xi,   yi+1)
+      const V* z21 = reinterpret_cast<const V*>(A.data + ((uint64_t)(xi + 1) * A.ny + yi) * A.lanes);
+      const V* z22 = z21 + LV;                                    // (xi+1, yi+1)
+      const V a11 = z11[v], a12 = z12[v], a21 = z21[v], a22 = z22[v];
+      const V z1 = frac_v<T, V>(x1, a11, x2, a21, x);
+      const V z2 = frac_v<T, V>(x1, a12, x2, a22, x);
+      V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
+      o[v] = frac_v<T, V>(y1, z1, y2, z2, y);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// spline build: batched Thomas, one lane per thread
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct BuildArgs {
+  const T* data;  // [n][lanes]
+  T* ca;          // [n-1][lanes]  (rows double as scratch for the eliminated rhs)
+  T* cb;          // [n-1][lanes]  (periodic: scratch for k1)
+  const T* dx;    // [n-1]
+  const T* up;    // [m]
+  const T* w;     // [m]
+  const T* midp;  // [m]
+  const T* k2;    // [m] periodic
+  uint64_t n, lanes;
+  int left_kind, right_kind;  // EndKind
+  T left_val, right_val;
+  T nkL_tmp1, nkL_d, nkR_tmp1, nkR_d, dx0_sq, dxl_sq;
+  T per_den;
+  StatusBlock* status;
+};
+
+// SPLINE_GENERAL: rows 0 and n-1 from the boundary kinds (cubic_spline.rs:597-670), interior
+// rows :456-471, thomas :678-721, then a/b :354-365 fused into the back substitution.
+template <class T>
+__global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A) {
+  const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= A.lanes) return;
+  const uint64_t n = A.n, L = A.lanes;
+  const T two = T(2), three = T(3);
+  const T* y = A.data + l;
+  T* sa = A.ca + l;
+  T* sb = A.cb + l;
+  T ym = y[0], yc = y[L], yp = y[2 * L];
+  const T dx0 = A.dx[0], dx1 = A.dx[1];
+  T r_prev;
+  if (A.left_kind == 0) {
+    r_prev = (A.nkL_tmp1 * (yc - ym) / dx0 + A.dx0_sq * (yp - yc) / dx1) / A.nkL_d;
+  } else if (A.left_kind == 1) {
+    r_prev = A.left_val;
+  } else {
+    r_prev = three * (yc - ym) - A.left_val * A.dx0_sq / two;
+  }
+  sa[0] = r_prev;
+  for (uint64_t i = 1; i + 1 < n; ++i) {
+    const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
+    const T rhs = three * (dxn * (yc - ym) / dxn_1 + dxn_1 * (yp - yc) / dxn);
+    const T r = rhs - A.w[i] * r_prev;
+    sa[i * L] = r;
+    r_prev = r;
+    if (i + 2 < n) {
+      ym = yc;
+      yc = yp;
+      yp = y[(i + 2) * L];
+    }
+  }
+  // window is now (y[n-3], y[n-2], y[n-1])
+  const T dxl = A.dx[n - 2], dxl2 = A.dx[n - 3];
+  T rhs_last;
+  if (A.right_kind == 0) {
+    rhs_last = (A.dxl_sq * (yc - ym) / dxl2 + A.nkR_tmp1 * (yp - yc) / dxl) / A.nkR_d;
+  } else if (A.right_kind == 1) {
+    rhs_last = A.right_val;
+  } else {
+    rhs_last = three * (yp - yc) + A.right_val * A.dxl_sq / two;
+  }
+  const T r_last = rhs_last - A.w[n - 1] * r_prev;
+  T k_next = r_last / A.midp[n - 1];
+  T y_hi = yp;
+  for (uint64_t i = n - 1; i-- > 0;) {
+    const T ri = sa[i * L];
+    const T y_lo = y[i * L];
+    const T k = (ri - A.up[i] * k_next) / A.midp[i];
+    const T dy = y_hi - y_lo;
+    const T dxi = A.dx[i];
+    sa[i * L] = k * dxi - dy;
+    sb[i * L] = dy - k_next * dxi;
+    k_next = k;
+    y_hi = y_lo;
+  }
+}
+
+// n == 3 closed forms: parabola (:569-596) and periodic (:480-496).
+template <class T>
+__global__ __launch_bounds__(64) void spline_build_n3_kernel(BuildArgs<T> A, int periodic) {
+  const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= A.lanes) return;
+  const uint64_t L = A.lanes;
+  const T one = T(1), two = T(2), three = T(3);
+  const T y0 = A.data[l], y1 = A.data[L + l], y2 = A.data[2 * L + l];
+  const T dx0 = A.dx[0], dx1 = A.dx[1];
+  const T slope0 = (y1 - y0) / dx0;
+  const T slope1 = (y2 - y1) / dx1;
+  T k0, k1, k2;
+  if (periodic) {
+    if (y0 != y2) atomicAdd(&A.status->periodic_mismatch, 1ull);
+    const T v = (slope0 / dx0 + slope1 / dx1) / (one / dx0 + one / dx1);
+    k0 = v; k1 = v; k2 = v;
+  } else {
+    const T r0 = slope0 * two;
+    const T r1 = (slope1 * dx0 + slope0 * dx1) * three - A.w[1] * r0;
+    const T r2 = slope1 * two - A.w[2] * r1;
+    k2 = r2 / A.midp[2];
+    k1 = (r1 - A.up[1] * k2) / A.midp[1];
+    k0 = (r0 - A.up[0] * k1) / A.midp[0];
+  }
+  A.ca[l] = k0 * dx0 - (y1 - y0);
+  A.cb[l] = (y1 - y0) - k1 * dx0;
+  A.ca[L + l] = k1 * dx1 - (y2 - y1);
+  A.cb[L + l] = (y2 - y1) - k2 * dx1;
+}
+
+// SPLINE_PERIODIC, n >= 4 (:498-565): condensed (n-2) system, k = k1 + k_{n-2} * k2.
+template <class T>
+__global__ __launch_bounds__(64) void spline_build_periodic_kernel(BuildArgs<T> A) {
+  const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= A.lanes) return;
+  const uint64_t n = A.n, L = A.lanes, m = n - 2;
+  const T three = T(3);
+  const T* y = A.data + l;
+  T* sa = A.ca + l;
+  T* sb = A.cb + l;
+  const T dx0 = A.dx[0], dxl = A.dx[n - 2], dxl2 = A.dx[n - 3];
+  const T y0 = y[0], y1 = y[L];
+  const T yn1 = y[(n - 1) * L], yn2 = y[(n - 2) * L], yn3 = y[(n - 3) * L];
+  if (y0 != yn1) atomicAdd(&A.status->periodic_mismatch, 1ull);
+  const T slope0 = (y1 - y0) / dx0;
+  const T slope_1 = (yn1 - yn2) / dxl;
+  const T slope_2 = (yn2 - yn3) / dxl2;
+  const T rhs_first = (slope_1 * dx0 + slope0 * dxl) * three;
+  const T rhs_last = (slope_2 * dxl + slope_1 * dxl2) * three;  // row n-2 of the sliced rhs
+  // forward sweep over rows 0..m-1 (row 0 special, rows 1..m-1 interior formula)
+  T r_prev = rhs_first;
+  sa[0] = r_prev;
+  T ym = y0, yc = y1, yp = y[2 * L];
+  for (uint64_t i = 1; i < m; ++i) {
+    const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
+    const T rhs = three * (dxn * (yc - ym) / dxn_1 + dxn_1 * (yp - yc) / dxn);
+    const T r = rhs - A.w[i] * r_prev;
+    sa[i * L] = r;
+    r_prev = r;
+    ym = yc;
+    yc = yp;
+    yp = y[(i + 2) * L];
+  }
+  // back substitution -> k1 rows 0..m-1 parked in cb
+  T k_next = r_prev / A.midp[m - 1];
+  sb[(m - 1) * L] = k_next;
+  for (uint64_t i = m - 1; i-- > 0;) {
+    const T k = (sa[i * L] - A.up[i] * k_next) / A.midp[i];
+    sb[i * L] = k;
+    k_next = k;
+  }
+  const T k1_first = sb[0], k1_last = sb[(m - 1) * L];
+  const T k_m1 = (rhs_last - k1_first * dxl2 - k1_last * dxl) / A.per_den;
+  const T k_0 = k1_first + k_m1 * A.k2[0];
+  // k[i] = k1[i] + k_m1*k2[i] (i < m), k[m] = k_m1, k[n-1] = k[0]; a/b :354-365
+  T k_i = k_0;
+  T y_lo = y0;
+  for (uint64_t i = 0; i + 1 < n; ++i) {
+    T k_r;
+    if (i + 1 < m) k_r = sb[(i + 1) * L] + k_m1 * A.k2[i + 1];
+    else if (i + 1 == m) k_r = k_m1;
+    else k_r = k_0;
+    const T y_hi = y[(i + 1) * L];
+    const T dy = y_hi - y_lo;
+    const T dxi = A.dx[i];
+    sa[i * L] = k_i * dxi - dy;
+    sb[i * L] = dy - k_r * dxi;
+    k_i = k_r;
+    y_lo = y_hi;
+  }
+}
+
+}  // namespace ndi

@@ -1,0 +1,955 @@
+// csrc/ndinterp_api.hip -- the extern "C" surface of libndinterp_hip.so (include/ndinterp.h).
+//
+// Host side of the drop-in boundary: owns the device copies of knots / data / spline tables,
+// validates like the reference's builders, sequences the kernels of kernels.hpp on a HIP stream
+// and translates the device status word into the reference's error values.
+// There is deliberately NO CPU evaluation path in this library.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+#include "host_logic.hpp"
+#include "kernels.hpp"
+
+#define NDI_API extern "C" __attribute__((visibility("default")))
+
+namespace ndi {
+
+// ---------------------------------------------------------------------------------------------
+// small RAII helpers
+// ---------------------------------------------------------------------------------------------
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    NDI_HIP(hipGetDevice(&prev));
+    if (prev != dev) NDI_HIP(hipSetDevice(dev));
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void reserve(size_t need) {
+    if (need <= bytes) return;
+    release();
+    NDI_HIP(hipMalloc(&p, need));
+    bytes = need;
+  }
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+static hipStream_t thread_stream(int device) {
+  static thread_local std::map<int, hipStream_t> streams;
+  auto it = streams.find(device);
+  if (it != streams.end()) return it->second;
+  hipStream_t s;
+  NDI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  streams[device] = s;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-kernel event profiling (ndi_profile_*)
+// ---------------------------------------------------------------------------------------------
+enum ProfCat : int { PC_EVAL = 0, PC_LOCATE = 1, PC_GROUP = 2 };
+struct ProfRec { hipEvent_t a, b; int cat; };
+static std::atomic<int> g_prof_on{0};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof_recs;
+static ndi_profile g_prof_acc{};
+static std::atomic<int> g_last_path{0};
+
+struct ProfScope {
+  hipStream_t s;
+  ProfRec r{};
+  bool on;
+  ProfScope(hipStream_t stream, int cat) : s(stream), on(g_prof_on.load() != 0) {
+    if (!on) return;
+    r.cat = cat;
+    NDI_HIP(hipEventCreate(&r.a));
+    NDI_HIP(hipEventCreate(&r.b));
+    NDI_HIP(hipEventRecord(r.a, s));
+  }
+  void done() {
+    if (!on) return;
+    NDI_HIP(hipEventRecord(r.b, s));
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    g_prof_recs.push_back(r);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// knot pyramid on the device
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct DevicePyramid {
+  DevBuf buf;
+  Pyramid<T> view{};
+  std::vector<T> host_knots;
+  size_t lds_bytes = 0;
+
+  void upload(const T* knots, uint64_t n) {
+    host_knots.assign(knots, knots + n);
+    const uint32_t n1 = (uint32_t)((n + 63) / 64);
+    const uint32_t n2 = (uint32_t)((n1 + 63) / 64);
+    std::vector<T> all(n + n1 + n2);
+    std::copy(knots, knots + n, all.begin());
+    for (uint32_t j = 0; j < n1; ++j) all[n + j] = knots[(uint64_t)j * 64];
+    for (uint32_t j = 0; j < n2; ++j) all[n + n1 + j] = knots[(uint64_t)j * 4096];
+    buf.reserve(all.size() * sizeof(T));
+    NDI_HIP(hipMemcpy(buf.p, all.data(), all.size() * sizeof(T), hipMemcpyHostToDevice));
+    view.lv0 = buf.as<T>();
+    view.lv1 = view.lv0 + n;
+    view.lv2 = view.lv1 + n1;
+    view.n = (uint32_t)n;
+    view.n1 = n1;
+    view.n2 = n2;
+    view.levels = (n <= 64) ? 1 : (n <= 4096 ? 2 : 3);
+    lds_bytes = all.size() * sizeof(T);
+  }
+};
+
+constexpr uint64_t MAX_KNOTS = 64ull * 64ull * 64ull;   // three pyramid levels
+constexpr size_t LDS_STAGE_LIMIT = 150 * 1024;          // of the CU's 160 KiB
+
+// ---------------------------------------------------------------------------------------------
+// workspace: per (handle, stream) scratch, reused across stream-ordered evaluations
+// ---------------------------------------------------------------------------------------------
+struct Workspace {
+  DevBuf idx, idx2, t, perm, counts, cursor, status, qdev, qdev2, stage[2];
+  StatusBlock* host_status = nullptr;  // pinned
+  // record of the last batch (for finish())
+  uint64_t last_nq = 0;
+  const void* last_q = nullptr;
+  const void* last_q2 = nullptr;
+  int last_q_space = NDI_MEM_DEVICE;
+  bool pending = false;
+  ~Workspace() {
+    if (host_status) (void)hipHostFree(host_status);
+  }
+  void ensure_status() {
+    status.reserve(sizeof(StatusBlock));
+    if (!host_status) NDI_HIP(hipHostMalloc((void**)&host_status, sizeof(StatusBlock), hipHostMallocDefault));
+  }
+};
+
+template <class T, class K, class A>
+static void launch1(hipStream_t s, int cat, dim3 grid, dim3 block, size_t shmem, K kernel, const A& args) {
+  ProfScope ps(s, cat);
+  hipLaunchKernelGGL(kernel, grid, block, shmem, s, args);
+  NDI_HIP(hipGetLastError());
+  ps.done();
+}
+
+static void reset_status(Workspace& ws, hipStream_t s) {
+  ws.ensure_status();
+  // first_fail[0..1] = NO_FAIL (all ones), the rest zero
+  NDI_HIP(hipMemsetAsync(ws.status.p, 0xFF, 2 * sizeof(unsigned long long), s));
+  NDI_HIP(hipMemsetAsync((char*)ws.status.p + 2 * sizeof(unsigned long long), 0,
+                         sizeof(StatusBlock) - 2 * sizeof(unsigned long long), s));
+}
+
+template <class T>
+static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, uint64_t nq,
+                       uint32_t* idx, int64_t* idx64, T* t, unsigned long long* first_fail, int mode) {
+  LocateArgs<T> A{};
+  A.pyr = pyr.view;
+  A.q = q;
+  A.nq = nq;
+  A.idx = idx;
+  A.idx64 = idx64;
+  A.t = t;
+  A.first_fail = first_fail;
+  A.mode = mode;
+  A.stage_lds = pyr.lds_bytes <= LDS_STAGE_LIMIT ? 1 : 0;
+  const size_t shmem = A.stage_lds ? pyr.lds_bytes : 0;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+  });
+  const uint64_t blocks_needed = (nq + BLOCK - 1) / BLOCK;
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(blocks_needed, 1024));
+  launch1<T>(s, PC_LOCATE, dim3(grid), dim3(BLOCK), shmem, locate_kernel<T>, A);
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// Interp1D
+// ---------------------------------------------------------------------------------------------
+struct Interp1DBase {
+  virtual ~Interp1DBase() = default;
+  int dtype = 0, device = 0;
+  virtual ndi_status eval(const void* q, uint64_t nq, void* out, uint64_t out_stride,
+                          const ndi_eval_opts* opts, ndi_oob_info* info) = 0;
+  virtual ndi_status finish(void* stream, ndi_oob_info* info) = 0;
+  virtual ndi_status coefficients(void* a_out, void* b_out, int memspace) = 0;
+};
+
+template <class T>
+struct Interp1DImpl final : Interp1DBase {
+  int strategy = NDI_LINEAR;
+  int mode = EX_NO;
+  uint64_t n = 0, lanes = 0;
+  DevicePyramid<T> pyr;
+  DevBuf data, ca, cb;
+  std::mutex mu;
+  std::map<hipStream_t, std::unique_ptr<Workspace>> spaces;
+
+  Workspace& workspace(hipStream_t s) {
+    std::lock_guard<std::mutex> g(mu);
+    auto& slot = spaces[s];
+    if (!slot) slot.reset(new Workspace());
+    return *slot;
+  }
+
+  // ---- build (CubicSpline::build, cubic_spline.rs:754-771) --------------------------------
+  ndi_status build_spline(const ndi_interp1d_desc& d) {
+    if (d.lane_left_kind || d.lane_left_value || d.lane_right_kind || d.lane_right_value)
+      return fail(NDI_UNSUPPORTED,
+                  "BoundaryCondition::Individual (per-lane boundaries) is not on the device path yet");
+    const bool periodic = d.periodic != 0;
+    if (periodic && n == 3) { /* closed form */ }
+    SplinePlan<T> P = make_spline_plan<T>(pyr.host_knots.data(), n, periodic, d.left.kind,
+                                          d.left.value, d.right.kind, d.right.value);
+    const size_t tab = (size_t)(n - 1) * lanes * sizeof(T);
+    ca.reserve(tab);
+    cb.reserve(tab);
+    // scalars of the plan, packed into one upload: dx | up | w | midp | k2
+    const size_t m = P.m;
+    std::vector<T> pack;
+    pack.insert(pack.end(), P.dx.begin(), P.dx.end());
+    const size_t o_up = pack.size();
+    pack.insert(pack.end(), P.up.begin(), P.up.end());
+    const size_t o_w = pack.size();
+    pack.insert(pack.end(), P.w.begin(), P.w.end());
+    const size_t o_mid = pack.size();
+    pack.insert(pack.end(), P.midp.begin(), P.midp.end());
+    const size_t o_k2 = pack.size();
+    pack.insert(pack.end(), P.k2.begin(), P.k2.end());
+    (void)m;
+    DevBuf plan;
+    plan.reserve(std::max<size_t>(pack.size(), 1) * sizeof(T));
+    NDI_HIP(hipMemcpy(plan.p, pack.data(), pack.size() * sizeof(T), hipMemcpyHostToDevice));
+    DevBuf status;
+    status.reserve(sizeof(StatusBlock));
+    NDI_HIP(hipMemset(status.p, 0, sizeof(StatusBlock)));
+
+    BuildArgs<T> A{};
+    A.data = data.as<T>();
+    A.ca = ca.as<T>();
+    A.cb = cb.as<T>();
+    A.dx = plan.as<T>();
+    A.up = plan.as<T>() + o_up;
+    A.w = plan.as<T>() + o_w;
+    A.midp = plan.as<T>() + o_mid;
+    A.k2 = plan.as<T>() + o_k2;
+    A.n = n;
+    A.lanes = lanes;
+    A.left_kind = P.left_kind;
+    A.right_kind = P.right_kind;
+    A.left_val = P.left_val;
+    A.right_val = P.right_val;
+    A.nkL_tmp1 = P.nkL_tmp1; A.nkL_d = P.nkL_d;
+    A.nkR_tmp1 = P.nkR_tmp1; A.nkR_d = P.nkR_d;
+    A.dx0_sq = P.dx0_sq; A.dxl_sq = P.dxl_sq;
+    A.per_den = P.per_den;
+    A.status = status.as<StatusBlock>();
+    const unsigned grid = (unsigned)((lanes + 63) / 64);
+    hipStream_t s = nullptr;
+    switch (P.mode) {
+      case SPLINE_GENERAL:
+        hipLaunchKernelGGL(spline_build_general_kernel<T>, dim3(grid), dim3(64), 0, s, A);
+        break;
+      case SPLINE_PARABOLA3:
+        hipLaunchKernelGGL(spline_build_n3_kernel<T>, dim3(grid), dim3(64), 0, s, A, 0);
+        break;
+      case SPLINE_PERIODIC3:
+        hipLaunchKernelGGL(spline_build_n3_kernel<T>, dim3(grid), dim3(64), 0, s, A, 1);
+        break;
+      case SPLINE_PERIODIC:
+        hipLaunchKernelGGL(spline_build_periodic_kernel<T>, dim3(grid), dim3(64), 0, s, A);
+        break;
+    }
+    NDI_HIP(hipGetLastError());
+    StatusBlock hs{};
+    NDI_HIP(hipMemcpy(&hs, status.p, sizeof(hs), hipMemcpyDeviceToHost));  // synchronises
+    if (hs.periodic_mismatch != 0)
+      return fail(NDI_VALUE,
+                  "for periodic boundary condition the first and last value must be equal "
+                  "(%llu lane(s) differ)", hs.periodic_mismatch);
+    // Extrapolate::{No,Yes,Periodic}, cubic_spline.rs:763-769
+    if (mode != EX_NO && periodic) mode = EX_PERIODIC;
+    return NDI_OK;
+  }
+
+  // ---- evaluation core on device pointers --------------------------------------------------
+  void enqueue(hipStream_t s, Workspace& ws, const T* q, uint64_t nq, T* out, uint64_t out_stride,
+               int path) {
+    ws.idx.reserve(nq * sizeof(uint32_t));
+    if (strategy == NDI_CUBIC_SPLINE) ws.t.reserve(nq * sizeof(T));
+    reset_status(ws, s);
+    StatusBlock* st = ws.status.as<StatusBlock>();
+    run_locate<T>(s, pyr, q, nq, ws.idx.as<uint32_t>(), nullptr,
+                  strategy == NDI_CUBIC_SPLINE ? ws.t.as<T>() : nullptr, &st->first_fail[0], mode);
+
+    Eval1Args<T> A{};
+    A.knots = pyr.view.lv0;
+    A.data = data.as<T>();
+    A.ca = ca.as<T>();
+    A.cb = cb.as<T>();
+    A.q = q;
+    A.idx = ws.idx.as<uint32_t>();
+    A.t = ws.t.as<T>();
+    A.out = out;
+    A.lanes = lanes;
+    A.out_stride = out_stride;
+    A.nq = nq;
+    A.status = st;
+
+    constexpr int VN = Wide<T>::N;
+    const bool vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
+    const uint64_t LV = vec_ok ? lanes / VN : lanes;
+    const bool rows_ok = vec_ok && LV >= (uint64_t)BLOCK;
+    bool bucketed = false;
+    if (path == NDI_PATH_BUCKETED) bucketed = rows_ok && nq < 0xffffffffull;
+    else if (path == NDI_PATH_AUTO) bucketed = rows_ok && nq < 0xffffffffull && nq >= 8 * (n - 1);
+    g_last_path.store(bucketed ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
+
+    const int U = LV >= 1024 ? 4 : (LV >= 512 ? 2 : 1);
+    const uint64_t segs = rows_ok ? (LV + (uint64_t)BLOCK * U - 1) / ((uint64_t)BLOCK * U) : 1;
+    const unsigned gy = (unsigned)std::min<uint64_t>(segs, 16);
+
+    if (bucketed) {
+      const uint32_t nb = (uint32_t)(n - 1);
+      ws.counts.reserve((size_t)nb * sizeof(uint32_t));
+      ws.cursor.reserve((size_t)nb * sizeof(uint32_t));
+      ws.perm.reserve(nq * sizeof(uint32_t));
+      A.perm = ws.perm.as<uint32_t>();
+      {
+        ProfScope ps(s, PC_GROUP);
+        NDI_HIP(hipMemsetAsync(ws.counts.p, 0, (size_t)nb * sizeof(uint32_t), s));
+        const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 2048));
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(BLOCK), 0, s, A.idx, nq, st,
+                           ws.counts.as<uint32_t>());
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
+                           ws.cursor.as<uint32_t>(), st);
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(BLOCK), 0, s, A.idx, nq, st,
+                           ws.cursor.as<uint32_t>(), ws.perm.as<uint32_t>());
+        NDI_HIP(hipGetLastError());
+        ps.done();
+      }
+      constexpr int CQ = 128;
+      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + CQ - 1) / CQ, 8192));
+      dim3 grid(gx, gy);
+#define NDI_BK(ST, UU) launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_bucketed_kernel<T, ST, UU, CQ>, A)
+      if (strategy == NDI_CUBIC_SPLINE) {
+        if (U == 4) NDI_BK(ST_CUBIC, 4); else if (U == 2) NDI_BK(ST_CUBIC, 2); else NDI_BK(ST_CUBIC, 1);
+      } else {
+        if (U == 4) NDI_BK(ST_LINEAR, 4); else if (U == 2) NDI_BK(ST_LINEAR, 2); else NDI_BK(ST_LINEAR, 1);
+      }
+#undef NDI_BK
+      return;
+    }
+    if (rows_ok) {
+      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nq, 16384));
+      dim3 grid(gx, gy);
+#define NDI_RW(ST, UU) launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_rows_kernel<T, ST, UU>, A)
+      if (strategy == NDI_CUBIC_SPLINE) {
+        if (U == 4) NDI_RW(ST_CUBIC, 4); else if (U == 2) NDI_RW(ST_CUBIC, 2); else NDI_RW(ST_CUBIC, 1);
+      } else {
+        if (U == 4) NDI_RW(ST_LINEAR, 4); else if (U == 2) NDI_RW(ST_LINEAR, 2); else NDI_RW(ST_LINEAR, 1);
+      }
+#undef NDI_RW
+      return;
+    }
+    // flat
+    const uint32_t tile_q = (uint32_t)std::max<uint64_t>(1, 1024 / std::max<uint64_t>(LV, 1));
+    const uint64_t ntiles = (nq + tile_q - 1) / tile_q;
+    const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 16384));
+    ProfScope ps(s, PC_EVAL);
+    if (strategy == NDI_CUBIC_SPLINE) {
+      if (vec_ok) hipLaunchKernelGGL((eval_flat_kernel<T, ST_CUBIC, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+      else hipLaunchKernelGGL((eval_flat_kernel<T, ST_CUBIC, 1>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+    } else {
+      if (vec_ok) hipLaunchKernelGGL((eval_flat_kernel<T, ST_LINEAR, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+      else hipLaunchKernelGGL((eval_flat_kernel<T, ST_LINEAR, 1>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+    }
+    NDI_HIP(hipGetLastError());
+    ps.done();
+  }
+
+  // Reads the status block back (stream must be idle) and converts it to the reference's error.
+  ndi_status collect(hipStream_t s, Workspace& ws, uint64_t index_offset, ndi_oob_info* info) {
+    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    NDI_HIP(hipStreamSynchronize(s));
+    ws.pending = false;
+    const unsigned long long ff = ws.host_status->first_fail[0];
+    if (ff == NO_FAIL) return NDI_OK;
+    T v;
+    if (ws.last_q_space == NDI_MEM_DEVICE)
+      NDI_HIP(hipMemcpy(&v, (const T*)ws.last_q + ff, sizeof(T), hipMemcpyDeviceToHost));
+    else
+      v = ((const T*)ws.last_q)[ff];
+    const bool is_nan = !(v == v);
+    const ndi_status st = (mode != EX_NO && is_nan) ? NDI_NAN_QUERY : NDI_OUT_OF_BOUNDS;
+    if (info) {
+      info->index = index_offset + ff;
+      info->value = (double)v;
+      info->axis = 0;
+      info->status = st;
+    }
+    if (st == NDI_NAN_QUERY) return fail(st, "failed to convert NaN to usize (query %llu)", index_offset + ff);
+    return fail(st, "x = %.17g is not in range", (double)v);
+  }
+
+  ndi_status eval(const void* q_, uint64_t nq, void* out_, uint64_t out_stride,
+                  const ndi_eval_opts* opts, ndi_oob_info* info) override {
+    DeviceGuard dg(device);
+    ndi_eval_opts o{};
+    if (opts) o = *opts;
+    hipStream_t s = o.stream ? (hipStream_t)o.stream : thread_stream(device);
+    if (out_stride < lanes) return fail(NDI_BAD_ARG, "out_row_stride (%llu) < lanes (%llu)",
+                                        (unsigned long long)out_stride, (unsigned long long)lanes);
+    if (nq == 0) return NDI_OK;
+    if (!q_ || !out_) return fail(NDI_BAD_ARG, "null query / output pointer");
+    Workspace& ws = workspace(s);
+    const T* q = (const T*)q_;
+    if (o.q_memspace == NDI_MEM_HOST) {
+      ws.qdev.reserve(nq * sizeof(T));
+      NDI_HIP(hipMemcpyAsync(ws.qdev.p, q_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+      q = ws.qdev.as<T>();
+    }
+    ws.last_q = q_;
+    ws.last_q_space = o.q_memspace;
+    ws.last_nq = nq;
+    if (o.out_memspace == NDI_MEM_DEVICE) {
+      enqueue(s, ws, q, nq, (T*)out_, out_stride, o.path);
+      ws.pending = true;
+      if (o.async_launch) return NDI_OK;
+      return collect(s, ws, 0, info);
+    }
+    // host output: stream the batch through a device staging buffer in query chunks
+    const uint64_t row_bytes = lanes * sizeof(T);
+    const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / row_bytes));
+    ws.stage[0].reserve(chunk_q * row_bytes);
+    for (uint64_t off = 0; off < nq; off += chunk_q) {
+      const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
+      enqueue(s, ws, q + off, cq, ws.stage[0].as<T>(), lanes, o.path);
+      ws.last_q = (const T*)q_ + off;
+      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipStreamSynchronize(s));
+      unsigned long long ff = ws.host_status->first_fail[0];
+      const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
+      if (good)
+        NDI_HIP(hipMemcpy2D((T*)out_ + off * out_stride, out_stride * sizeof(T), ws.stage[0].p, row_bytes,
+                            row_bytes, good, hipMemcpyDeviceToHost));
+      if (ff != NO_FAIL) return collect(s, ws, off, info);
+    }
+    return NDI_OK;
+  }
+
+  ndi_status finish(void* stream, ndi_oob_info* info) override {
+    DeviceGuard dg(device);
+    hipStream_t s = stream ? (hipStream_t)stream : thread_stream(device);
+    Workspace& ws = workspace(s);
+    if (!ws.pending) {
+      NDI_HIP(hipStreamSynchronize(s));
+      return NDI_OK;
+    }
+    return collect(s, ws, 0, info);
+  }
+
+  ndi_status coefficients(void* a_out, void* b_out, int memspace) override {
+    DeviceGuard dg(device);
+    if (strategy != NDI_CUBIC_SPLINE) return fail(NDI_BAD_ARG, "Linear has no coefficient tables");
+    const size_t tab = (size_t)(n - 1) * lanes * sizeof(T);
+    const hipMemcpyKind k = memspace == NDI_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (a_out) NDI_HIP(hipMemcpy(a_out, ca.p, tab, k));
+    if (b_out) NDI_HIP(hipMemcpy(b_out, cb.p, tab, k));
+    return NDI_OK;
+  }
+};
+
+template <class T>
+static std::vector<T> default_axis(uint64_t n) {
+  std::vector<T> v(n);
+  for (uint64_t i = 0; i < n; ++i) v[i] = (T)i;  // interp1d/mod.rs:402-406
+  return v;
+}
+
+template <class T>
+static std::vector<T> fetch_axis(const void* p, uint64_t len, int memspace) {
+  std::vector<T> v(len);
+  if (len == 0) return v;
+  if (memspace == NDI_MEM_DEVICE)
+    NDI_HIP(hipMemcpy(v.data(), p, len * sizeof(T), hipMemcpyDeviceToHost));
+  else
+    std::memcpy(v.data(), p, len * sizeof(T));
+  return v;
+}
+
+template <class T>
+static ndi_status create1d(const ndi_interp1d_desc& d, Interp1DBase** out) {
+  DeviceGuard dg(d.device);
+  std::unique_ptr<Interp1DImpl<T>> h(new Interp1DImpl<T>());
+  h->dtype = d.dtype;
+  h->device = d.device;
+  h->strategy = d.strategy;
+  h->mode = d.extrapolate ? EX_YES : EX_NO;
+  h->n = d.n;
+  h->lanes = d.lanes;
+  std::vector<T> x = d.x ? fetch_axis<T>(d.x, d.x_len, d.memspace) : default_axis<T>(d.n);
+  const uint64_t x_len = d.x ? d.x_len : d.n;
+  if (d.validate) {
+    ndi_status st = check_axis_1d<T>(x.data(), x_len, d.n, d.strategy);
+    if (st != NDI_OK) return st;
+  } else if (x_len != d.n || d.n < min_len_1d(d.strategy)) {
+    return fail(NDI_BAD_ARG, "unvalidated create with inconsistent sizes (x_len %llu, n %llu)",
+                (unsigned long long)x_len, (unsigned long long)d.n);
+  }
+  if (d.lanes == 0) return fail(NDI_BAD_ARG, "lanes must be >= 1");
+  if (d.n > MAX_KNOTS) return fail(NDI_UNSUPPORTED, "more than %llu knots", (unsigned long long)MAX_KNOTS);
+  if (!d.data) return fail(NDI_BAD_ARG, "null data pointer");
+  h->pyr.upload(x.data(), d.n);
+  const size_t bytes = (size_t)d.n * d.lanes * sizeof(T);
+  h->data.reserve(bytes);
+  NDI_HIP(hipMemcpy(h->data.p, d.data, bytes,
+                    d.memspace == NDI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  if (d.strategy == NDI_CUBIC_SPLINE) {
+    ndi_status st = h->build_spline(d);
+    if (st != NDI_OK) return st;
+  }
+  *out = h.release();
+  return NDI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Interp2D (Bilinear)
+// ---------------------------------------------------------------------------------------------
+struct Interp2DBase {
+  virtual ~Interp2DBase() = default;
+  int dtype = 0, device = 0;
+  virtual ndi_status eval(const void* qx, const void* qy, uint64_t nq, void* out, uint64_t out_stride,
+                          const ndi_eval_opts* opts, ndi_oob_info* info) = 0;
+  virtual ndi_status finish(void* stream, ndi_oob_info* info) = 0;
+};
+
+template <class T>
+struct Interp2DImpl final : Interp2DBase {
+  int mode = EX_NO;
+  uint64_t nx = 0, ny = 0, lanes = 0;
+  DevicePyramid<T> px, py;
+  DevBuf data;
+  std::mutex mu;
+  std::map<hipStream_t, std::unique_ptr<Workspace>> spaces;
+
+  Workspace& workspace(hipStream_t s) {
+    std::lock_guard<std::mutex> g(mu);
+    auto& slot = spaces[s];
+    if (!slot) slot.reset(new Workspace());
+    return *slot;
+  }
+
+  void enqueue(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t nq, T* out,
+               uint64_t out_stride) {
+    ws.idx.reserve(nq * sizeof(uint32_t));
+    ws.idx2.reserve(nq * sizeof(uint32_t));
+    reset_status(ws, s);
+    StatusBlock* st = ws.status.as<StatusBlock>();
+    run_locate<T>(s, px, qx, nq, ws.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
+    run_locate<T>(s, py, qy, nq, ws.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);
+    Eval2Args<T> A{};
+    A.xk = px.view.lv0;
+    A.yk = py.view.lv0;
+    A.data = data.as<T>();
+    A.qx = qx;
+    A.qy = qy;
+    A.xi = ws.idx.as<uint32_t>();
+    A.yi = ws.idx2.as<uint32_t>();
+    A.out = out;
+    A.ny = ny;
+    A.lanes = lanes;
+    A.out_stride = out_stride;
+    A.nq = nq;
+    A.status = st;
+    g_last_path.store(NDI_PATH_GATHER);
+    constexpr int VN = Wide<T>::N;
+    const bool vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
+    const uint64_t LV = vec_ok ? lanes / VN : lanes;
+    const uint32_t tile_q = (uint32_t)std::max<uint64_t>(1, 1024 / std::max<uint64_t>(LV, 1));
+    const uint64_t ntiles = (nq + tile_q - 1) / tile_q;
+    const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 32768));
+    ProfScope ps(s, PC_EVAL);
+    if (vec_ok) hipLaunchKernelGGL((eval_bilinear_kernel<T, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+    else hipLaunchKernelGGL((eval_bilinear_kernel<T, 1>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+    NDI_HIP(hipGetLastError());
+    ps.done();
+  }
+
+  ndi_status collect(hipStream_t s, Workspace& ws, uint64_t index_offset, ndi_oob_info* info) {
+    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    NDI_HIP(hipStreamSynchronize(s));
+    ws.pending = false;
+    const unsigned long long fx = ws.host_status->first_fail[0], fy = ws.host_status->first_fail[1];
+    if (fx == NO_FAIL && fy == NO_FAIL) return NDI_OK;
+    // x is tested before y for the same query (bilinear.rs:71-80)
+    const int axis = (fx <= fy) ? 0 : 1;
+    const unsigned long long ff = axis == 0 ? fx : fy;
+    const void* src = axis == 0 ? ws.last_q : ws.last_q2;
+    T v;
+    if (ws.last_q_space == NDI_MEM_DEVICE)
+      NDI_HIP(hipMemcpy(&v, (const T*)src + ff, sizeof(T), hipMemcpyDeviceToHost));
+    else
+      v = ((const T*)src)[ff];
+    const bool is_nan = !(v == v);
+    const ndi_status st = (mode != EX_NO && is_nan) ? NDI_NAN_QUERY : NDI_OUT_OF_BOUNDS;
+    if (info) {
+      info->index = index_offset + ff;
+      info->value = (double)v;
+      info->axis = axis;
+      info->status = st;
+    }
+    if (st == NDI_NAN_QUERY) return fail(st, "failed to convert NaN to usize (query %llu)", index_offset + ff);
+    return fail(st, "%s = %.17g is not in range", axis == 0 ? "x" : "y", (double)v);
+  }
+
+  ndi_status eval(const void* qx_, const void* qy_, uint64_t nq, void* out_, uint64_t out_stride,
+                  const ndi_eval_opts* opts, ndi_oob_info* info) override {
+    DeviceGuard dg(device);
+    ndi_eval_opts o{};
+    if (opts) o = *opts;
+    hipStream_t s = o.stream ? (hipStream_t)o.stream : thread_stream(device);
+    if (out_stride < lanes) return fail(NDI_BAD_ARG, "out_row_stride (%llu) < lanes (%llu)",
+                                        (unsigned long long)out_stride, (unsigned long long)lanes);
+    if (nq == 0) return NDI_OK;
+    if (!qx_ || !qy_ || !out_) return fail(NDI_BAD_ARG, "null query / output pointer");
+    Workspace& ws = workspace(s);
+    const T* qx = (const T*)qx_;
+    const T* qy = (const T*)qy_;
+    if (o.q_memspace == NDI_MEM_HOST) {
+      ws.qdev.reserve(nq * sizeof(T));
+      ws.qdev2.reserve(nq * sizeof(T));
+      NDI_HIP(hipMemcpyAsync(ws.qdev.p, qx_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+      NDI_HIP(hipMemcpyAsync(ws.qdev2.p, qy_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+      qx = ws.qdev.as<T>();
+      qy = ws.qdev2.as<T>();
+    }
+    ws.last_q = qx_;
+    ws.last_q2 = qy_;
+    ws.last_q_space = o.q_memspace;
+    ws.last_nq = nq;
+    if (o.out_memspace == NDI_MEM_DEVICE) {
+      enqueue(s, ws, qx, qy, nq, (T*)out_, out_stride);
+      ws.pending = true;
+      if (o.async_launch) return NDI_OK;
+      return collect(s, ws, 0, info);
+    }
+    const uint64_t row_bytes = lanes * sizeof(T);
+    const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / row_bytes));
+    ws.stage[0].reserve(chunk_q * row_bytes);
+    for (uint64_t off = 0; off < nq; off += chunk_q) {
+      const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
+      enqueue(s, ws, qx + off, qy + off, cq, ws.stage[0].as<T>(), lanes);
+      ws.last_q = (const T*)qx_ + off;
+      ws.last_q2 = (const T*)qy_ + off;
+      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipStreamSynchronize(s));
+      const unsigned long long ff = std::min(ws.host_status->first_fail[0], ws.host_status->first_fail[1]);
+      const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
+      if (good)
+        NDI_HIP(hipMemcpy2D((T*)out_ + off * out_stride, out_stride * sizeof(T), ws.stage[0].p, row_bytes,
+                            row_bytes, good, hipMemcpyDeviceToHost));
+      if (ff != NO_FAIL) return collect(s, ws, off, info);
+    }
+    return NDI_OK;
+  }
+
+  ndi_status finish(void* stream, ndi_oob_info* info) override {
+    DeviceGuard dg(device);
+    hipStream_t s = stream ? (hipStream_t)stream : thread_stream(device);
+    Workspace& ws = workspace(s);
+    if (!ws.pending) {
+      NDI_HIP(hipStreamSynchronize(s));
+      return NDI_OK;
+    }
+    return collect(s, ws, 0, info);
+  }
+};
+
+template <class T>
+static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
+  DeviceGuard dg(d.device);
+  std::unique_ptr<Interp2DImpl<T>> h(new Interp2DImpl<T>());
+  h->dtype = d.dtype;
+  h->device = d.device;
+  h->mode = d.extrapolate ? EX_YES : EX_NO;
+  h->nx = d.nx;
+  h->ny = d.ny;
+  h->lanes = d.lanes;
+  std::vector<T> x = d.x ? fetch_axis<T>(d.x, d.x_len, d.memspace) : default_axis<T>(d.nx);
+  std::vector<T> y = d.y ? fetch_axis<T>(d.y, d.y_len, d.memspace) : default_axis<T>(d.ny);
+  const uint64_t x_len = d.x ? d.x_len : d.nx, y_len = d.y ? d.y_len : d.ny;
+  if (d.validate) {
+    ndi_status st = check_axes_2d<T>(x.data(), x_len, y.data(), y_len, d.nx, d.ny);
+    if (st != NDI_OK) return st;
+  } else if (x_len != d.nx || y_len != d.ny || d.nx < 2 || d.ny < 2) {
+    return fail(NDI_BAD_ARG, "unvalidated create with inconsistent sizes");
+  }
+  if (d.lanes == 0) return fail(NDI_BAD_ARG, "lanes must be >= 1");
+  if (d.nx > MAX_KNOTS || d.ny > MAX_KNOTS) return fail(NDI_UNSUPPORTED, "too many knots");
+  if (!d.data) return fail(NDI_BAD_ARG, "null data pointer");
+  h->px.upload(x.data(), d.nx);
+  h->py.upload(y.data(), d.ny);
+  const size_t bytes = (size_t)d.nx * d.ny * d.lanes * sizeof(T);
+  h->data.reserve(bytes);
+  NDI_HIP(hipMemcpy(h->data.p, d.data, bytes,
+                    d.memspace == NDI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  *out = h.release();
+  return NDI_OK;
+}
+
+template <class T>
+static ndi_status lower_index_batch(int device, const void* knots, uint64_t n, const void* q, uint64_t nq,
+                                    int64_t* out_idx, int memspace) {
+  DeviceGuard dg(device);
+  if (n < 2) return fail(NDI_BAD_ARG, "get_lower_index needs at least 2 knots");
+  if (n > MAX_KNOTS) return fail(NDI_UNSUPPORTED, "too many knots");
+  if (nq == 0) return NDI_OK;
+  std::vector<T> x = fetch_axis<T>(knots, n, memspace);
+  DevicePyramid<T> pyr;
+  pyr.upload(x.data(), n);
+  hipStream_t s = thread_stream(device);
+  DevBuf qd, od;
+  const T* qdev = (const T*)q;
+  int64_t* odev = out_idx;
+  if (memspace == NDI_MEM_HOST) {
+    qd.reserve(nq * sizeof(T));
+    od.reserve(nq * sizeof(int64_t));
+    NDI_HIP(hipMemcpyAsync(qd.p, q, nq * sizeof(T), hipMemcpyHostToDevice, s));
+    qdev = qd.as<T>();
+    odev = od.as<int64_t>();
+  }
+  run_locate<T>(s, pyr, qdev, nq, nullptr, odev, nullptr, nullptr, EX_YES);
+  if (memspace == NDI_MEM_HOST)
+    NDI_HIP(hipMemcpyAsync(out_idx, od.p, nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  NDI_HIP(hipStreamSynchronize(s));
+  return NDI_OK;
+}
+
+}  // namespace ndi
+
+// =============================================================================================
+// extern "C"
+// =============================================================================================
+struct ndi_interp1d { ndi::Interp1DBase* impl; };
+struct ndi_interp2d { ndi::Interp2DBase* impl; };
+
+#define NDI_TRY try {
+#define NDI_CATCH                                                                  \
+  }                                                                                \
+  catch (const ndi::HipFailure& f) { return ndi::from_hip(f); }                    \
+  catch (const std::bad_alloc&) { return ndi::fail(NDI_HIP_ERROR, "host out of memory"); } \
+  catch (...) { return ndi::fail(NDI_HIP_ERROR, "unexpected C++ exception"); }
+
+static ndi_status need_device(int device) {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0)
+    return ndi::fail(NDI_HIP_ERROR, "no HIP device available (%s); this library has no CPU fallback",
+                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= cnt)
+    return ndi::fail(NDI_BAD_ARG, "device ordinal %d out of range [0, %d)", device, cnt);
+  return NDI_OK;
+}
+
+NDI_API ndi_status ndi_interp1d_create(const ndi_interp1d_desc* desc, ndi_interp1d** out) {
+  if (!desc || !out) return ndi::fail(NDI_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (desc->dtype != NDI_F32 && desc->dtype != NDI_F64) return ndi::fail(NDI_BAD_ARG, "unknown dtype");
+  if (desc->strategy != NDI_LINEAR && desc->strategy != NDI_CUBIC_SPLINE)
+    return ndi::fail(NDI_BAD_ARG, "unknown strategy");
+  // Builder checks that need no device come first, so they behave the same everywhere.
+  if (desc->validate && desc->memspace == NDI_MEM_HOST && desc->x) {
+    ndi_status st = ndi_validate1d(desc->dtype, desc->x, desc->x_len, desc->n, desc->strategy);
+    if (st != NDI_OK) return st;
+  } else if (desc->validate && !desc->x && desc->n < ndi::min_len_1d(desc->strategy)) {
+    return ndi::fail(NDI_NOT_ENOUGH_DATA, "The chosen Interpolation strategy needs at least %llu data points",
+                     (unsigned long long)ndi::min_len_1d(desc->strategy));
+  }
+  ndi_status ds = need_device(desc->device);
+  if (ds != NDI_OK) return ds;
+  NDI_TRY
+  ndi::Interp1DBase* impl = nullptr;
+  ndi_status st = desc->dtype == NDI_F32 ? ndi::create1d<float>(*desc, &impl)
+                                         : ndi::create1d<double>(*desc, &impl);
+  if (st != NDI_OK) return st;
+  *out = new ndi_interp1d{impl};
+  return NDI_OK;
+  NDI_CATCH
+}
+
+NDI_API void ndi_interp1d_destroy(ndi_interp1d* h) {
+  if (!h) return;
+  try {
+    ndi::DeviceGuard dg(h->impl->device);
+    delete h->impl;
+  } catch (...) {
+  }
+  delete h;
+}
+
+NDI_API ndi_status ndi_interp2d_create(const ndi_interp2d_desc* desc, ndi_interp2d** out) {
+  if (!desc || !out) return ndi::fail(NDI_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (desc->dtype != NDI_F32 && desc->dtype != NDI_F64) return ndi::fail(NDI_BAD_ARG, "unknown dtype");
+  if (desc->validate && desc->memspace == NDI_MEM_HOST && desc->x && desc->y) {
+    ndi_status st = ndi_validate2d(desc->dtype, desc->x, desc->x_len, desc->y, desc->y_len, desc->nx, desc->ny);
+    if (st != NDI_OK) return st;
+  }
+  ndi_status ds = need_device(desc->device);
+  if (ds != NDI_OK) return ds;
+  NDI_TRY
+  ndi::Interp2DBase* impl = nullptr;
+  ndi_status st = desc->dtype == NDI_F32 ? ndi::create2d<float>(*desc, &impl)
+                                         : ndi::create2d<double>(*desc, &impl);
+  if (st != NDI_OK) return st;
+  *out = new ndi_interp2d{impl};
+  return NDI_OK;
+  NDI_CATCH
+}
+
+NDI_API void ndi_interp2d_destroy(ndi_interp2d* h) {
+  if (!h) return;
+  try {
+    ndi::DeviceGuard dg(h->impl->device);
+    delete h->impl;
+  } catch (...) {
+  }
+  delete h;
+}
+
+NDI_API ndi_status ndi_interp1d_coefficients(const ndi_interp1d* h, void* a_out, void* b_out, int32_t memspace) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->coefficients(a_out, b_out, memspace);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp1d_eval(const ndi_interp1d* h, const void* q, uint64_t nq, void* out,
+                                     uint64_t out_row_stride, const ndi_eval_opts* opts, ndi_oob_info* info) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->eval(q, nq, out, out_row_stride, opts, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp2d_eval(const ndi_interp2d* h, const void* qx, const void* qy, uint64_t nq,
+                                     void* out, uint64_t out_row_stride, const ndi_eval_opts* opts,
+                                     ndi_oob_info* info) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->eval(qx, qy, nq, out, out_row_stride, opts, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp1d_finish(const ndi_interp1d* h, void* stream, ndi_oob_info* info) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->finish(stream, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp2d_finish(const ndi_interp2d* h, void* stream, ndi_oob_info* info) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->finish(stream, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_get_lower_index_batch(int32_t dtype, int32_t device, const void* knots, uint64_t n,
+                                             const void* q, uint64_t nq, int64_t* out_idx, int32_t memspace) {
+  if (!knots || (!q && nq) || (!out_idx && nq)) return ndi::fail(NDI_BAD_ARG, "null argument");
+  ndi_status ds = need_device(device);
+  if (ds != NDI_OK) return ds;
+  NDI_TRY
+  if (dtype == NDI_F32) return ndi::lower_index_batch<float>(device, knots, n, q, nq, out_idx, memspace);
+  if (dtype == NDI_F64) return ndi::lower_index_batch<double>(device, knots, n, q, nq, out_idx, memspace);
+  return ndi::fail(NDI_BAD_ARG, "unknown dtype");
+  NDI_CATCH
+}
+
+NDI_API int32_t ndi_monotonic_prop(int32_t dtype, const void* host_v, uint64_t n) {
+  if (dtype == NDI_F32) return ndi::monotonic_scan<float>((const float*)host_v, n);
+  return ndi::monotonic_scan<double>((const double*)host_v, n);
+}
+
+NDI_API ndi_status ndi_validate1d(int32_t dtype, const void* host_x, uint64_t x_len, uint64_t n, int32_t strategy) {
+  if (dtype == NDI_F32) return ndi::check_axis_1d<float>((const float*)host_x, x_len, n, strategy);
+  if (dtype == NDI_F64) return ndi::check_axis_1d<double>((const double*)host_x, x_len, n, strategy);
+  return ndi::fail(NDI_BAD_ARG, "unknown dtype");
+}
+
+NDI_API ndi_status ndi_validate2d(int32_t dtype, const void* host_x, uint64_t x_len, const void* host_y,
+                                  uint64_t y_len, uint64_t nx, uint64_t ny) {
+  if (dtype == NDI_F32)
+    return ndi::check_axes_2d<float>((const float*)host_x, x_len, (const float*)host_y, y_len, nx, ny);
+  if (dtype == NDI_F64)
+    return ndi::check_axes_2d<double>((const double*)host_x, x_len, (const double*)host_y, y_len, nx, ny);
+  return ndi::fail(NDI_BAD_ARG, "unknown dtype");
+}
+
+NDI_API int32_t ndi_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+
+NDI_API const char* ndi_last_error_string(void) { return ndi::tls_error().c_str(); }
+
+NDI_API uint32_t ndi_version(void) { return (NDI_VERSION_MAJOR << 16) | NDI_VERSION_MINOR; }
+
+NDI_API void ndi_profile_enable(int32_t on) { ndi::g_prof_on.store(on ? 1 : 0); }
+
+NDI_API ndi_status ndi_profile_read(ndi_profile* out, int32_t reset) {
+  if (!out) return ndi::fail(NDI_BAD_ARG, "null argument");
+  NDI_TRY
+  std::lock_guard<std::mutex> g(ndi::g_prof_mu);
+  for (auto& r : ndi::g_prof_recs) {
+    NDI_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    NDI_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    if (r.cat == ndi::PC_EVAL) { ndi::g_prof_acc.eval_launches++; ndi::g_prof_acc.eval_ms += ms; }
+    else if (r.cat == ndi::PC_LOCATE) { ndi::g_prof_acc.locate_launches++; ndi::g_prof_acc.locate_ms += ms; }
+    else { ndi::g_prof_acc.group_launches++; ndi::g_prof_acc.group_ms += ms; }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  ndi::g_prof_recs.clear();
+  ndi::g_prof_acc.last_path = ndi::g_last_path.load();
+  *out = ndi::g_prof_acc;
+  if (reset) ndi::g_prof_acc = ndi_profile{};
+  return NDI_OK;
+  NDI_CATCH
+}

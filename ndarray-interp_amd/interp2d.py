@@ -1,0 +1,300 @@
+"""Host-side mirror of the reference's 2-D surface (src/interp2d/mod.rs + strategies/):
+`Interp2DBuilder`, `Interp2D`, the strategy trait pair and the built-in `Bilinear`."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._arrays import Buf, current_stream_ptr, dtype_id, is_torch, np_dtype_of
+from .errors import BuilderError, Panic, raise_builder, raise_eval
+from .interp1d import _default_device, _host, _to_device
+from .vector_extensions import Monotonic, get_lower_index, monotonic_prop
+
+
+class Interp2DStrategyBuilder:
+    """Trait `Interp2DStrategyBuilder` (src/interp2d/strategies/mod.rs:14-44)."""
+
+    MINIMUM_DATA_LENGHT = 2
+
+    def build(self, x, y, data) -> "Interp2DStrategy":
+        raise NotImplementedError
+
+
+class Interp2DStrategy:
+    """Trait `Interp2DStrategy` (src/interp2d/strategies/mod.rs:46-73): per-query
+    `interp_into(interpolator, target, x, y)`; `interp_array_into` is the defaulted batched hook whose
+    default body is the reference's serial loop (interp2d/mod.rs:287-307)."""
+
+    def interp_into(self, interpolator, target, x, y) -> None:
+        raise NotImplementedError
+
+    def interp_array_into(self, interpolator, xs_flat, ys_flat, out2d) -> None:
+        shape = tuple(interpolator.data.shape[2:])
+        for i in range(len(xs_flat)):
+            self.interp_into(interpolator, out2d[i].reshape(shape), xs_flat[i], ys_flat[i])
+
+    def release(self) -> None:
+        pass
+
+
+class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
+    """Bilinear strategy (src/interp2d/strategies/bilinear.rs); builder and finished strategy in one,
+    as in the reference (`type FinishedStrat = Self`, :43)."""
+
+    MINIMUM_DATA_LENGHT = 2  # bilinear.rs:41
+
+    def __init__(self):
+        self._extrapolate = False
+        self._h = None
+        self._device = 0
+        self._np_dtype = None
+        self._lanes = 1
+
+    @staticmethod
+    def new() -> "Bilinear":
+        return Bilinear()
+
+    def extrapolate(self, yes: bool) -> "Bilinear":
+        self._extrapolate = bool(yes)
+        return self
+
+    def build(self, x, y, data, device=None):
+        dt = np_dtype_of(data)
+        tid = dtype_id(dt)
+        db = Buf(data)
+
+        def axis(a):
+            if a is None:
+                return None
+            if db.memspace == _capi.MEM_HOST:
+                return Buf(_host(a), dt)
+            return Buf(_to_device(a, db.keep.device), dt)
+
+        xb, yb = axis(x), axis(y)
+        if device is None:
+            device = db.device if db.memspace == _capi.MEM_DEVICE else _default_device()
+        nx, ny = db.shape[0], db.shape[1]
+        lanes = int(np.prod(db.shape[2:], dtype=np.int64)) if len(db.shape) > 2 else 1
+        d = _capi.Interp2DDesc()
+        d.dtype, d.extrapolate, d.device, d.memspace = tid, int(self._extrapolate), device, db.memspace
+        d.nx, d.ny, d.lanes = nx, ny, lanes
+        d.x_len = xb.size if xb is not None else nx
+        d.y_len = yb.size if yb is not None else ny
+        d.x = xb.ptr if xb is not None else None
+        d.y = yb.ptr if yb is not None else None
+        d.data = db.ptr
+        d.validate = 0  # Interp2DBuilder.build() validated already (interp2d/mod.rs:477-511)
+        h = C.c_void_p()
+        st = _capi.lib().ndi_interp2d_create(C.byref(d), C.byref(h))
+        if st != _capi.OK:
+            raise_builder(st)
+        self._h, self._device, self._np_dtype, self._lanes = h, device, dt, lanes
+        return self
+
+    def release(self):
+        if self._h is not None:
+            _capi.lib().ndi_interp2d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def interp_array_into(self, interpolator, xs_flat, ys_flat, out2d, *, async_launch=False):
+        """Replaces the reference's query loop (interp2d/mod.rs:287-307) by one C-ABI call."""
+        qx = Buf(xs_flat, self._np_dtype)
+        qy = Buf(ys_flat, self._np_dtype)
+        if qx.memspace != qy.memspace:
+            raise TypeError("xs and ys must live in the same memory space")
+        opts = _capi.EvalOpts()
+        opts.q_memspace = qx.memspace
+        opts.async_launch = int(bool(async_launch))
+        if is_torch(out2d):
+            if not out2d.is_cuda:
+                raise TypeError("torch output buffers must live on the device; use numpy for host buffers")
+            opts.out_memspace = _capi.MEM_DEVICE
+            optr = out2d.data_ptr()
+            stride = out2d.stride(0) if out2d.dim() > 1 and out2d.shape[0] > 1 else self._lanes
+            opts.stream = current_stream_ptr(self._device)
+        else:
+            opts.out_memspace = _capi.MEM_HOST
+            optr = out2d.ctypes.data
+            stride = out2d.strides[0] // out2d.itemsize if out2d.ndim > 1 and out2d.shape[0] > 1 else self._lanes
+            if qx.memspace == _capi.MEM_DEVICE:
+                opts.stream = current_stream_ptr(self._device)
+        info = _capi.OobInfo()
+        st = _capi.lib().ndi_interp2d_eval(self._h, qx.ptr, qy.ptr, qx.size, optr, max(stride, self._lanes),
+                                           C.byref(opts), C.byref(info))
+        if st != _capi.OK:
+            raise_eval(st, info)
+
+    def finish(self):
+        info = _capi.OobInfo()
+        st = _capi.lib().ndi_interp2d_finish(self._h, current_stream_ptr(self._device), C.byref(info))
+        if st != _capi.OK:
+            raise_eval(st, info)
+
+    def interp_into(self, interpolator, target, x, y):
+        out = np.empty((1, self._lanes), dtype=self._np_dtype)
+        self.interp_array_into(interpolator, np.array([x], dtype=self._np_dtype),
+                               np.array([y], dtype=self._np_dtype), out)
+        target[...] = out.reshape(target.shape)
+
+
+class Interp2D:
+    """Two dimensional interpolator (interp2d/mod.rs:36-48)."""
+
+    def __init__(self, x, y, data, strategy):
+        self.x, self.y, self.data, self.strategy = x, y, data, strategy
+        self._x_host, self._y_host = _host(x), _host(y)
+
+    @staticmethod
+    def builder(data) -> "Interp2DBuilder":
+        return Interp2DBuilder.new(data)
+
+    @staticmethod
+    def new_unchecked(x, y, data, strategy) -> "Interp2D":
+        return Interp2D(x, y, data, strategy)
+
+    def index_point(self, x_idx: int, y_idx: int):
+        return self._x_host[x_idx], self._y_host[y_idx], self.data[x_idx, y_idx]
+
+    def get_index_left_of(self, x, y):
+        def one(k, v):
+            if k.dtype in (np.float32, np.float64):
+                r = int(get_lower_index(np.ascontiguousarray(k), np.array([v], dtype=k.dtype))[0])
+                if r < 0:
+                    raise Panic("not implemented: failed to convert NaN to usize")
+                return r
+            return int(np.clip(np.searchsorted(k, v, side="right") - 1, 0, k.size - 2))
+        return one(self._x_host, x), one(self._y_host, y)
+
+    def is_in_x_range(self, x) -> bool:
+        return bool(self._x_host[0] <= x <= self._x_host[-1])
+
+    def is_in_y_range(self, y) -> bool:
+        return bool(self._y_host[0] <= y <= self._y_host[-1])
+
+    def _lanes_shape(self):
+        return tuple(self.data.shape[2:])
+
+    def interp_scalar(self, x, y):
+        """interp2d/mod.rs:107-113 (data must be 2-D)."""
+        if len(self.data.shape) != 2:
+            raise TypeError("interp_scalar needs 2-D data; use interp()")
+        buf = np.zeros((), dtype=np_dtype_of(self.data))
+        self.strategy.interp_into(self, buf, x, y)
+        return buf[()]
+
+    def interp(self, x, y):
+        target = np.zeros(self._lanes_shape(), dtype=np_dtype_of(self.data))
+        self.strategy.interp_into(self, target, x, y)
+        return target
+
+    def interp_into(self, x, y, buffer):
+        if tuple(buffer.shape) != self._lanes_shape():
+            raise Panic(f"ShapeError/IncompatibleShape: incompatible shapes expected: "
+                        f"{list(self._lanes_shape())}, got: {list(buffer.shape)}")
+        self.strategy.interp_into(self, buffer, x, y)
+
+    def get_buffer_shape(self, q_shape):
+        """interp2d/mod.rs:310-321."""
+        return tuple(q_shape) + self._lanes_shape()
+
+    def interp_array(self, xs, ys):
+        """interp2d/mod.rs:175-196; panics when `xs.shape != ys.shape`."""
+        if tuple(xs.shape) != tuple(ys.shape):
+            raise Panic("`xs.shape()` and `ys.shape()` do not match")
+        shape = self.get_buffer_shape(tuple(xs.shape))
+        if is_torch(xs) and xs.is_cuda:
+            import torch
+            zs = torch.empty(shape, dtype=xs.dtype, device=xs.device)
+        else:
+            zs = np.zeros(shape, dtype=np_dtype_of(self.data))
+        self.interp_array_into(xs, ys, zs)
+        return zs
+
+    def interp_array_into(self, xs, ys, buffer, **kw):
+        """interp2d/mod.rs:215-285."""
+        if tuple(xs.shape) != tuple(ys.shape):
+            raise Panic("`xs.shape()` and `ys.shape()` do not match")
+        expect = self.get_buffer_shape(tuple(xs.shape))
+        if tuple(buffer.shape) != expect:
+            raise Panic(f"ShapeError/IncompatibleShape: incompatible shapes expected: {list(expect)}, "
+                        f"got: {list(buffer.shape)}")
+        nq = int(np.prod(xs.shape, dtype=np.int64))
+        lanes = int(np.prod(self._lanes_shape(), dtype=np.int64))
+        xf, yf = xs.reshape(-1), ys.reshape(-1)
+        if is_torch(buffer):
+            if not buffer.is_contiguous():
+                raise TypeError("device output buffers must be contiguous")
+            self.strategy.interp_array_into(self, xf, yf, buffer.view(nq, lanes), **kw)
+            return
+        if not is_torch(xs):
+            xf, yf = _host(xf), _host(yf)
+        if buffer.flags.c_contiguous:
+            self.strategy.interp_array_into(self, xf, yf, buffer.reshape(nq, lanes), **kw)
+            return
+        tmp = np.zeros((nq, lanes), dtype=buffer.dtype)
+        try:
+            self.strategy.interp_array_into(self, xf, yf, tmp, **kw)
+        finally:
+            buffer[...] = tmp.reshape(buffer.shape)
+
+
+class Interp2DBuilder:
+    """Create and configure a `Interp2D` interpolator (interp2d/mod.rs:52-64, 382-519)."""
+
+    def __init__(self, data, x=None, y=None, strategy=None):
+        self._data, self._x, self._y = data, x, y
+        self._strategy = strategy if strategy is not None else Bilinear.new()  # :403
+
+    @staticmethod
+    def new(data) -> "Interp2DBuilder":
+        return Interp2DBuilder(data)
+
+    def strategy(self, strategy) -> "Interp2DBuilder":
+        return Interp2DBuilder(self._data, self._x, self._y, strategy)
+
+    def x(self, x) -> "Interp2DBuilder":
+        return Interp2DBuilder(self._data, x, self._y, self._strategy)
+
+    def y(self, y) -> "Interp2DBuilder":
+        return Interp2DBuilder(self._data, self._x, y, self._strategy)
+
+    def build(self) -> Interp2D:
+        """Validate the input and create the configured `Interp2D` (interp2d/mod.rs:468-518)."""
+        data, strategy = self._data, self._strategy
+        shape = tuple(data.shape)
+        if len(shape) < 2:
+            raise BuilderError.ShapeError("data dimension needs to be at least 2")
+        need = type(strategy).MINIMUM_DATA_LENGHT
+        if shape[0] < need:
+            raise BuilderError.NotEnoughData(
+                "The 0-dimension has not enough data for the chosen interpolation strategy. "
+                f"Provided: {shape[0]}, Reqired: {need}")
+        if shape[1] < need:
+            raise BuilderError.NotEnoughData(
+                "The 1-dimension has not enough data for the chosen interpolation strategy. "
+                f"Provided: {shape[1]}, Reqired: {need}")
+        dt = np_dtype_of(data)
+        x = np.arange(shape[0]).astype(dt) if self._x is None else self._x
+        y = np.arange(shape[1]).astype(dt) if self._y is None else self._y
+        x_len = int(np.prod(x.shape, dtype=np.int64))
+        y_len = int(np.prod(y.shape, dtype=np.int64))
+        if x_len != shape[0]:
+            raise BuilderError.ShapeError(
+                f"Lenghts of x-axis and data-0-axis need to match. Got x: {x_len}, data-0: {shape[0]}")
+        if y_len != shape[1]:
+            raise BuilderError.ShapeError(
+                f"Lenghts of y-axis and data-1-axis need to match. Got y: {y_len}, data-1: {shape[1]}")
+        if monotonic_prop(x) != Monotonic.Rising(True):
+            raise BuilderError.Monotonic("The x-axis needs to be strictly monotonic rising")
+        if monotonic_prop(y) != Monotonic.Rising(True):
+            raise BuilderError.Monotonic("The y-axis needs to be strictly monotonic rising")
+        finished = strategy.build(x, y, data)
+        return Interp2D(x, y, data, finished)

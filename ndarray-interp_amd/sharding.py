@@ -1,0 +1,43 @@
+"""Query sharding over the GPUs of one node.
+
+Each query's result depends on read-only tables only (the reference's loop carries no state,
+interp1d/mod.rs:334-342), so a batch shards embarrassingly: rank r of W evaluates the contiguous block
+`shard_bounds(Q, r, W)` of the flattened query array on its own device, with knots / data / spline
+tables replicated per device.  There is NO collective on the data path; the only cross-rank step is
+reproducing the reference's *first-error* result: every rank reports its lowest failing global index
+and the minimum over ranks wins (MIN all-reduce of one int64 -- RCCL on the GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from .errors import InterpolateError
+
+NO_FAIL = (1 << 62)
+
+
+def shard_bounds(nq: int, rank: int, world: int):
+    """Contiguous block [lo, hi) of rank `rank`; block sizes differ by at most one."""
+    base, rem = divmod(nq, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def eval_shard(evaluate, nq: int, rank: int, world: int):
+    """Runs `evaluate(lo, hi)` for this rank's block and converts a local first-error into its global
+    index.  Returns (global_fail_index or NO_FAIL, exception or None)."""
+    lo, hi = shard_bounds(nq, rank, world)
+    try:
+        evaluate(lo, hi)
+    except InterpolateError.OutOfBounds as e:  # local index -> global index
+        return lo + (e.index if e.index is not None else 0), e
+    return NO_FAIL, None
+
+
+def first_error_across_ranks(local_fail: int, group=None, device=None) -> int:
+    """MIN all-reduce of the per-rank first failing global index (NO_FAIL when a rank had none)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_fail
+    t = torch.tensor([local_fail], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())

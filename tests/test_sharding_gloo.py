@@ -1,0 +1,86 @@
+"""CPU, world_size 2, gloo: the N>1 path.  Queries shard into contiguous blocks per rank with the tables
+replicated and no data-path collective; the only cross-rank step is the MIN all-reduce that reproduces
+the reference's first-error result.  The per-shard evaluator injected here is the CPU
+oracle (tests may use it); on the GPUs the same helper wraps the device evaluation (bench.py)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["NDI_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NDI_ROOT"], "tests"))
+import oracle
+from conftest import load_product_package
+pkg = load_product_package()
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(1)            # same inputs on every rank: tables are replicated
+n, L, Q = 64, 9, 10007
+x = np.sort(rng.uniform(0, 1, n)); y = rng.uniform(0, 1, (n, L)); q = rng.uniform(x[0], x[-1], Q)
+mode = os.environ["NDI_CASE"]
+if mode == "err":
+    q[7001] = 5.0; q[9000] = -3.0; q[200 + 5003] = 9.0      # failures in both shards; lowest is 5203
+st, a, b = oracle.cubic_build(x, y)
+out = np.full((Q, L), -1.0)
+def evaluate(lo, hi):
+    s, fail, _ = oracle.interp1d_cubic(x, y, a, b, q[lo:hi], out=out[lo:hi])
+    if s == oracle.OUT_OF_BOUNDS:
+        raise pkg.InterpolateError.OutOfBounds("x = ? is not in range", index=fail, value=float(q[lo + fail]))
+local, exc = pkg.sharding.eval_shard(evaluate, Q, rank, world)
+first = pkg.sharding.first_error_across_ranks(local)
+lo, hi = pkg.sharding.shard_bounds(Q, rank, world)
+np.save(os.path.join(os.environ["NDI_OUT"], f"out{rank}.npy"), out[lo:hi])
+with open(os.path.join(os.environ["NDI_OUT"], f"first{rank}.txt"), "w") as f:
+    f.write(f"{first} {lo} {hi}")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run(case):
+    import oracle
+    with tempfile.TemporaryDirectory() as tmp:
+        script = os.path.join(tmp, "worker.py")
+        open(script, "w").write(WORKER)
+        env = dict(os.environ, NDI_ROOT=ROOT, NDI_OUT=tmp, NDI_CASE=case, MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(29500 + (os.getpid() % 2000)), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+                 for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+        firsts, parts = [], []
+        for r in range(2):
+            first, lo, hi = map(int, open(os.path.join(tmp, f"first{r}.txt")).read().split())
+            firsts.append(first)
+            parts.append((lo, hi, np.load(os.path.join(tmp, f"out{r}.npy"))))
+        return firsts, parts
+
+
+def _inputs():
+    rng = np.random.default_rng(1)
+    n, L, Q = 64, 9, 10007
+    x = np.sort(rng.uniform(0, 1, n)); y = rng.uniform(0, 1, (n, L)); q = rng.uniform(x[0], x[-1], Q)
+    return x, y, q
+
+
+def test_two_rank_shards_equal_single_process(pkg):
+    import oracle
+    firsts, parts = _run("ok")
+    assert firsts == [pkg.sharding.NO_FAIL] * 2
+    x, y, q = _inputs()
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == q.size
+    assert np.array_equal(np.concatenate([p[2] for p in parts]), ref)
+
+
+def test_two_rank_first_error_is_global_minimum(pkg):
+    firsts, parts = _run("err")
+    assert firsts == [5203, 5203]          # both ranks learn the reference's first failing index

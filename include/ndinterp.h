@@ -150,7 +150,8 @@ typedef struct ndi_oob_info {
 typedef struct ndi_eval_opts {
   int32_t q_memspace;   /* ndi_memspace of the query array(s) */
   int32_t out_memspace; /* ndi_memspace of the output buffer */
-  void* stream;         /* hipStream_t, or NULL for a library-owned per-thread stream */
+  void* stream;         /* hipStream_t the kernels are enqueued on; NULL = the HIP default stream
+                           (hipStreamPerThread is accepted like any other handle) */
   int32_t path;         /* ndi_path */
   int32_t async_launch; /* != 0 (device out only): enqueue and return; fetch the batch
                            status later with ndi_interp{1,2}d_finish on the same stream */

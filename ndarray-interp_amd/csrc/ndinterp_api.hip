@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -58,15 +59,16 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-static hipStream_t thread_stream(int device) {
-  static thread_local std::map<int, hipStream_t> streams;
-  auto it = streams.find(device);
-  if (it != streams.end()) return it->second;
-  hipStream_t s;
-  NDI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  streams[device] = s;
-  return s;
-}
+// Workspaces are keyed by (stream, calling thread): work enqueued on one stream is ordered, so a
+// thread may reuse its scratch across stream-ordered evaluations, and two host threads that share a
+// stream (e.g. the default stream) still get private scratch -- `eval` on one handle is re-entrant.
+struct SpaceKey {
+  hipStream_t stream;
+  std::thread::id tid;
+  bool operator<(const SpaceKey& o) const {
+    return stream != o.stream ? std::less<hipStream_t>()(stream, o.stream) : tid < o.tid;
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
 // per-kernel event profiling (ndi_profile_*)
@@ -215,11 +217,11 @@ struct Interp1DImpl final : Interp1DBase {
   DevicePyramid<T> pyr;
   DevBuf data, ca, cb;
   std::mutex mu;
-  std::map<hipStream_t, std::unique_ptr<Workspace>> spaces;
+  std::map<SpaceKey, std::unique_ptr<Workspace>> spaces;
 
   Workspace& workspace(hipStream_t s) {
     std::lock_guard<std::mutex> g(mu);
-    auto& slot = spaces[s];
+    auto& slot = spaces[SpaceKey{s, std::this_thread::get_id()}];
     if (!slot) slot.reset(new Workspace());
     return *slot;
   }
@@ -429,7 +431,7 @@ struct Interp1DImpl final : Interp1DBase {
     DeviceGuard dg(device);
     ndi_eval_opts o{};
     if (opts) o = *opts;
-    hipStream_t s = o.stream ? (hipStream_t)o.stream : thread_stream(device);
+    hipStream_t s = (hipStream_t)o.stream;  // NULL = the HIP default stream
     if (out_stride < lanes) return fail(NDI_BAD_ARG, "out_row_stride (%llu) < lanes (%llu)",
                                         (unsigned long long)out_stride, (unsigned long long)lanes);
     if (nq == 0) return NDI_OK;
@@ -472,7 +474,7 @@ struct Interp1DImpl final : Interp1DBase {
 
   ndi_status finish(void* stream, ndi_oob_info* info) override {
     DeviceGuard dg(device);
-    hipStream_t s = stream ? (hipStream_t)stream : thread_stream(device);
+    hipStream_t s = (hipStream_t)stream;
     Workspace& ws = workspace(s);
     if (!ws.pending) {
       NDI_HIP(hipStreamSynchronize(s));
@@ -563,11 +565,11 @@ struct Interp2DImpl final : Interp2DBase {
   DevicePyramid<T> px, py;
   DevBuf data;
   std::mutex mu;
-  std::map<hipStream_t, std::unique_ptr<Workspace>> spaces;
+  std::map<SpaceKey, std::unique_ptr<Workspace>> spaces;
 
   Workspace& workspace(hipStream_t s) {
     std::lock_guard<std::mutex> g(mu);
-    auto& slot = spaces[s];
+    auto& slot = spaces[SpaceKey{s, std::this_thread::get_id()}];
     if (!slot) slot.reset(new Workspace());
     return *slot;
   }
@@ -640,7 +642,7 @@ struct Interp2DImpl final : Interp2DBase {
     DeviceGuard dg(device);
     ndi_eval_opts o{};
     if (opts) o = *opts;
-    hipStream_t s = o.stream ? (hipStream_t)o.stream : thread_stream(device);
+    hipStream_t s = (hipStream_t)o.stream;  // NULL = the HIP default stream
     if (out_stride < lanes) return fail(NDI_BAD_ARG, "out_row_stride (%llu) < lanes (%llu)",
                                         (unsigned long long)out_stride, (unsigned long long)lanes);
     if (nq == 0) return NDI_OK;
@@ -688,7 +690,7 @@ struct Interp2DImpl final : Interp2DBase {
 
   ndi_status finish(void* stream, ndi_oob_info* info) override {
     DeviceGuard dg(device);
-    hipStream_t s = stream ? (hipStream_t)stream : thread_stream(device);
+    hipStream_t s = (hipStream_t)stream;
     Workspace& ws = workspace(s);
     if (!ws.pending) {
       NDI_HIP(hipStreamSynchronize(s));
@@ -740,7 +742,7 @@ static ndi_status lower_index_batch(int device, const void* knots, uint64_t n, c
   std::vector<T> x = fetch_axis<T>(knots, n, memspace);
   DevicePyramid<T> pyr;
   pyr.upload(x.data(), n);
-  hipStream_t s = thread_stream(device);
+  hipStream_t s = nullptr;
   DevBuf qd, od;
   const T* qdev = (const T*)q;
   int64_t* odev = out_idx;

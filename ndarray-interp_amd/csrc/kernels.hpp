@@ -79,38 +79,59 @@ __device__ __forceinline__ double rem_euclid_t(double a, double b) {
 // ---------------------------------------------------------------------------------------------
 // locate: knot pyramid  lv0 = knots[n], lv1[j] = knots[64 j], lv2[j] = knots[4096 j]
 // ---------------------------------------------------------------------------------------------
-template <class T>
-struct Pyramid {
-  const T* lv0;
-  const T* lv1;
-  const T* lv2;
+template <class T, class PTR>
+struct PyramidT {
+  PTR lv0;
+  PTR lv1;
+  PTR lv2;
   uint32_t n, n1, n2;
   int levels;  // 1, 2 or 3
 };
-
-// Number of knots <= x for a wave-uniform x, found cooperatively: each level has the 64 lanes
-// probe 64 consecutive pyramid entries (conflict-free LDS reads), ballot, popcount.
-// NaN compares false everywhere -> 0.
 template <class T>
-__device__ __forceinline__ uint32_t wave_count_le(const Pyramid<T>& P, T x, uint32_t lane) {
-  uint32_t blk = 0;
-  if (P.levels >= 3) {
-    bool p = lane < P.n2 && P.lv2[lane] <= x;
-    uint32_t c = (uint32_t)__popcll(__ballot(p));
-    if (c == 0) return 0;
-    blk = c - 1;
+using Pyramid = PyramidT<T, const T*>;                      // global memory
+template <class T>
+using lds_ptr = const __attribute__((address_space(3))) T*;  // explicit LDS pointers: ds_read, not flat_load
+template <class T>
+using PyramidLds = PyramidT<T, lds_ptr<T>>;
+
+// Number of knots <= x, one query per lane, wavefront-cooperative:
+//  * top pyramid level (<= 64 entries): every lane holds one entry in a register; the entries are
+//    broadcast one after the other (v_readlane) and each lane counts against its own query --
+//    64 queries are ranked against the whole level with no memory access at all;
+//  * each lower level: the 64-entry block selected by the level above is searched by the lane itself
+//    with a 6-step branch-free bisection in LDS (the block's first entry is known to be <= x).
+// NaN compares false everywhere -> 0.
+template <class T, class PTR>
+__device__ __forceinline__ uint32_t block_last_le(PTR blk, uint32_t len, T x) {
+  uint32_t lo = 0;  // invariant: blk[lo] <= x
+  const uint32_t last = len - 1u;
+#pragma unroll
+  for (uint32_t step = 32; step >= 1; step >>= 1) {
+    const uint32_t probe = lo + step;
+    const T v = blk[probe < last ? probe : last];  // unconditional (clamped) read: no divergent branch
+    lo = (probe <= last && v <= x) ? probe : lo;
   }
-  if (P.levels >= 2) {
-    uint32_t pos = blk * 64u + lane;
-    bool p = pos < P.n1 && P.lv1[pos] <= x;
-    uint32_t c = (uint32_t)__popcll(__ballot(p));
-    if (c == 0) return 0;
-    blk = blk * 64u + c - 1;
+  return lo;
+}
+
+template <class T, class PTR>
+__device__ __forceinline__ uint32_t wave_count_le(const PyramidT<T, PTR>& P, T x, uint32_t lane) {
+  const PTR top = P.levels == 3 ? P.lv2 : (P.levels == 2 ? P.lv1 : P.lv0);
+  const uint32_t ntop = P.levels == 3 ? P.n2 : (P.levels == 2 ? P.n1 : P.n);
+  const T mine = top[lane < ntop ? lane : ntop - 1];
+  uint32_t c = 0;
+#pragma unroll 8
+  for (uint32_t j = 0; j < ntop; ++j) c += (readlane_t(mine, (int)j) <= x) ? 1u : 0u;
+  if (P.levels == 1 || c == 0) return c;
+  uint32_t i = c - 1;  // index (within the level just searched) of the last entry <= x
+  if (P.levels == 3) {
+    const uint32_t base = i * 64u;
+    const uint32_t len = (P.n1 - base < 64u) ? P.n1 - base : 64u;
+    i = base + block_last_le<T, PTR>(P.lv1 + base, len, x);
   }
-  uint32_t pos = blk * 64u + lane;
-  bool p = pos < P.n && P.lv0[pos] <= x;
-  uint32_t c = (uint32_t)__popcll(__ballot(p));
-  return blk * 64u + c;
+  const uint32_t base = i * 64u;
+  const uint32_t len = (P.n - base < 64u) ? P.n - base : 64u;
+  return base + block_last_le<T, PTR>(P.lv0 + base, len, x) + 1u;
 }
 
 template <class T>
@@ -124,44 +145,31 @@ struct LocateArgs {
   unsigned long long* first_fail;  // atomicMin target
   int mode;                // ExtrapMode
   int stage_lds;           // copy the pyramid into LDS first
+  // grouping support (BUCKETED formulation): workgroup b handles the contiguous query slice
+  // [b*slice, (b+1)*slice) and, if hist != nullptr, leaves its interval histogram in hist[b][nb]
+  uint64_t slice;
+  uint32_t* hist;
+  uint32_t nb;
 };
 
-template <class T>
-__global__ __launch_bounds__(BLOCK) void locate_kernel(LocateArgs<T> A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Pyramid<T> P = A.pyr;
+// Body of locate_kernel for one pyramid address space.
+template <class T, class PTR>
+__device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const PyramidT<T, PTR>& P, uint32_t* s_hist) {
   const uint32_t tid = threadIdx.x;
-  if (A.stage_lds) {
-    T* s0 = reinterpret_cast<T*>(smem_raw);
-    T* s1 = s0 + P.n;
-    T* s2 = s1 + P.n1;
-    for (uint32_t i = tid; i < P.n; i += BLOCK) s0[i] = A.pyr.lv0[i];
-    for (uint32_t i = tid; i < P.n1; i += BLOCK) s1[i] = A.pyr.lv1[i];
-    for (uint32_t i = tid; i < P.n2; i += BLOCK) s2[i] = A.pyr.lv2[i];
-    __syncthreads();
-    P.lv0 = s0;
-    P.lv1 = s1;
-    P.lv2 = s2;
-  }
   const T k0 = P.lv0[0];
   const T kn = P.lv0[P.n - 1];
   const uint32_t lane = tid & 63u;
-  const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + (tid >> 6);
-  const uint64_t wave_stride = (uint64_t)gridDim.x * (BLOCK / 64);
-  for (uint64_t base = wave_global * 64u; base < A.nq; base += wave_stride * 64u) {
+  const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
+  uint64_t q_end = q_begin + A.slice;
+  if (q_end > A.nq) q_end = A.nq;
+  for (uint64_t base = q_begin + (uint64_t)(tid >> 6) * 64u; base < q_end; base += BLOCK) {
     const uint64_t qi = base + lane;
-    const bool active = qi < A.nq;
+    const bool active = qi < q_end;
     const T x = active ? A.q[qi] : k0;
     const bool inr = (k0 <= x) && (x <= kn);   // Interp1D::is_in_range, interp1d/mod.rs:384-386
     T xs = x;
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;
-    const int cnt = (A.nq - base < 64u) ? (int)(A.nq - base) : 64;
-    uint32_t ub = 0;
-    for (int j = 0; j < cnt; ++j) {
-      const T xj = readlane_t(xs, j);
-      const uint32_t c = wave_count_le(P, xj, lane);
-      if (lane == (uint32_t)j) ub = c;
-    }
+    const uint32_t ub = wave_count_le<T, PTR>(P, xs, lane);   // all 64 lanes take part (readlane broadcast)
     if (!active) continue;
     // unique i with k[i] <= x < k[i+1], clamped to [0, n-2]  (vector_extensions.rs:61-66, 100-110)
     uint32_t i = (ub == 0) ? 0u : ub - 1u;
@@ -175,6 +183,47 @@ __global__ __launch_bounds__(BLOCK) void locate_kernel(LocateArgs<T> A) {
       const T xl = P.lv0[i], xr = P.lv0[i + 1];
       A.t[qi] = (xs - xl) / (xr - xl);  // cubic_spline.rs:818
     }
+    if (s_hist) atomicAdd(&s_hist[i], 1u);
+  }
+}
+
+// One workgroup per contiguous slice of queries.  LDS: [pyramid | histogram].
+// STAGE: the pyramid is copied into LDS first (compile-time, so the search reads are ds_read).
+template <class T, bool STAGE>
+__global__ __launch_bounds__(BLOCK) void locate_kernel(LocateArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t tid = threadIdx.x;
+  uint32_t* s_hist = nullptr;
+  size_t hist_off = 0;
+  const uint32_t n = A.pyr.n, n1 = A.pyr.n1, n2 = A.pyr.n2;
+  if (STAGE) {
+    T* s0 = reinterpret_cast<T*>(smem_raw);
+    T* s1 = s0 + n;
+    T* s2 = s1 + n1;
+    for (uint32_t i = tid; i < n; i += BLOCK) s0[i] = A.pyr.lv0[i];
+    for (uint32_t i = tid; i < n1; i += BLOCK) s1[i] = A.pyr.lv1[i];
+    for (uint32_t i = tid; i < n2; i += BLOCK) s2[i] = A.pyr.lv2[i];
+    hist_off = ((size_t)(n + n1 + n2) * sizeof(T) + 15u) & ~(size_t)15u;
+  }
+  if (A.hist) {
+    s_hist = reinterpret_cast<uint32_t*>(smem_raw + hist_off);
+    for (uint32_t i = tid; i < A.nb; i += BLOCK) s_hist[i] = 0u;
+  }
+  __syncthreads();
+  if (STAGE) {
+    PyramidLds<T> P;
+    P.lv0 = (lds_ptr<T>)(smem_raw);
+    P.lv1 = P.lv0 + n;
+    P.lv2 = P.lv1 + n1;
+    P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels;
+    locate_slice<T, lds_ptr<T>>(A, P, s_hist);
+  } else {
+    locate_slice<T, const T*>(A, A.pyr, s_hist);
+  }
+  if (A.hist) {
+    __syncthreads();
+    uint32_t* dst = A.hist + (uint64_t)blockIdx.x * A.nb;
+    for (uint32_t i = tid; i < A.nb; i += BLOCK) dst[i] = s_hist[i];
   }
 }
 
@@ -232,13 +281,15 @@ __device__ __forceinline__ V row_point(const RowCoef<T, STRAT>& c, V yl, V yr, V
   }
 }
 
-template <class V>
+// Output rows are written once and never re-read by the kernel: non-temporal by default.
+template <bool NT, class V>
 __device__ __forceinline__ void store_stream(V* p, V v) {
-  __builtin_nontemporal_store(v, p);
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
 
 // GATHER, long rows: grid.x strides over queries, grid.y over 256*U-vector segments of a row.
-template <class T, int STRAT, int U>
+template <class T, int STRAT, int U, bool NT = true>
 __global__ __launch_bounds__(BLOCK) void eval_rows_kernel(Eval1Args<T> A) {
   constexpr int VN = Wide<T>::N;
   using V = typename VecT<T, VN>::type;
@@ -275,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void eval_rows_kernel(Eval1Args<T> A) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint64_t v = v0 + (uint64_t)u * BLOCK;
-        if (v < LV) store_stream(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
+        if (v < LV) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
       }
     }
   }
@@ -321,8 +372,7 @@ __global__ __launch_bounds__(BLOCK) void eval_flat_kernel(Eval1Args<T> A, uint32
 __global__ __launch_bounds__(BLOCK) void bucket_count_kernel(const uint32_t* idx, uint64_t nq,
                                                              const StatusBlock* status,
                                                              uint32_t* counts) {
-  unsigned long long limit = status->first_fail[0];
-  if (limit > nq) limit = nq;
+  const uint64_t limit = nq;  // every query is grouped; the evaluation skips qi >= first_fail
   for (uint64_t qi = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; qi < limit;
        qi += (uint64_t)gridDim.x * BLOCK)
     atomicAdd(&counts[idx[qi]], 1u);
@@ -358,8 +408,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* count
 __global__ __launch_bounds__(BLOCK) void bucket_scatter_kernel(const uint32_t* idx, uint64_t nq,
                                                                const StatusBlock* status,
                                                                uint32_t* cursor, uint32_t* perm) {
-  unsigned long long limit = status->first_fail[0];
-  if (limit > nq) limit = nq;
+  const uint64_t limit = nq;
   for (uint64_t qi = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; qi < limit;
        qi += (uint64_t)gridDim.x * BLOCK) {
     const uint32_t pos = atomicAdd(&cursor[idx[qi]], 1u);
@@ -367,10 +416,56 @@ __global__ __launch_bounds__(BLOCK) void bucket_scatter_kernel(const uint32_t* i
   }
 }
 
+// Block-local counting sort (used when the interval histogram fits LDS): locate_kernel leaves one
+// histogram per query slice in hist[B][nb]; group_offsets_kernel turns column b-prefixes into per-slice
+// start offsets (one thread per interval, coalesced over intervals) and the interval totals;
+// bucket_scan_kernel scans the totals; group_scatter_kernel re-reads each slice and places its queries
+// with LDS atomics only.  No global atomics, deterministic output order within a bucket per slice.
+__global__ __launch_bounds__(BLOCK) void group_offsets_kernel(uint32_t* hist, uint32_t nblocks, uint32_t nb,
+                                                              uint32_t* totals) {
+  const uint32_t bin = blockIdx.x * BLOCK + threadIdx.x;
+  if (bin >= nb) return;
+  uint32_t run = 0;
+  uint32_t b = 0;
+  for (; b + 8 <= nblocks; b += 8) {
+    uint32_t h[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) h[u] = hist[(uint64_t)(b + u) * nb + bin];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      hist[(uint64_t)(b + u) * nb + bin] = run;
+      run += h[u];
+    }
+  }
+  for (; b < nblocks; ++b) {
+    const uint32_t h = hist[(uint64_t)b * nb + bin];
+    hist[(uint64_t)b * nb + bin] = run;
+    run += h;
+  }
+  totals[bin] = run;
+}
+
+__global__ __launch_bounds__(BLOCK) void group_scatter_kernel(const uint32_t* idx, uint64_t nq, uint64_t slice,
+                                                              const uint32_t* slice_off, const uint32_t* base,
+                                                              uint32_t nb, uint32_t* perm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem_raw);
+  const uint32_t* off = slice_off + (uint64_t)blockIdx.x * nb;
+  for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) cur[i] = off[i] + base[i];
+  __syncthreads();
+  const uint64_t q_begin = (uint64_t)blockIdx.x * slice;
+  uint64_t q_end = q_begin + slice;
+  if (q_end > nq) q_end = nq;
+  for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += BLOCK) {
+    const uint32_t pos = atomicAdd(&cur[idx[qi]], 1u);
+    perm[pos] = (uint32_t)qi;
+  }
+}
+
 // One workgroup streams CQ grouped queries x one 256*U-vector row segment.  The four operand
 // row segments stay in registers while the interval does not change, so table traffic is
 // ~ (1/CQ + 1/queries-per-interval) of the gather formulation and the kernel is an output stream.
-template <class T, int STRAT, int U, int CQ>
+template <class T, int STRAT, int U, int CQ, bool NT = true>
 __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
   constexpr int VN = Wide<T>::N;
   using V = typename VecT<T, VN>::type;
@@ -380,7 +475,9 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
   const uint64_t LV = A.lanes / VN;
   const uint32_t seg_vecs = BLOCK * U;
   const uint32_t segs = (uint32_t)((LV + seg_vecs - 1) / seg_vecs);
-  const unsigned long long n_valid = A.status->n_valid;
+  const unsigned long long n_valid = A.nq;  // every query is grouped ...
+  unsigned long long limit = A.status->first_fail[0];  // ... and rows at or after the first failure are skipped
+  if (limit > A.nq) limit = A.nq;
   const uint64_t nchunks = (n_valid + CQ - 1) / CQ;
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint64_t p0 = chunk * CQ;
@@ -400,6 +497,7 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
       for (uint32_t j = 0; j < cnt; ++j) {
         const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_i[j]);
         const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_q[j]);
+        if (qi >= limit) continue;
         const T sj = s_s[j];
         if (i != cur) {
           cur = i;
@@ -425,7 +523,7 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint64_t v = v0 + (uint64_t)u * BLOCK;
-          if (v < LV) store_stream(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
+          if (v < LV) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
         }
       }
     }

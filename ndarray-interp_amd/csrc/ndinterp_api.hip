@@ -138,7 +138,7 @@ constexpr size_t LDS_STAGE_LIMIT = 150 * 1024;          // of the CU's 160 KiB
 // workspace: per (handle, stream) scratch, reused across stream-ordered evaluations
 // ---------------------------------------------------------------------------------------------
 struct Workspace {
-  DevBuf idx, idx2, t, perm, counts, cursor, status, qdev, qdev2, stage[2];
+  DevBuf idx, idx2, t, perm, counts, cursor, hist, status, qdev, qdev2, stage[2];
   StatusBlock* host_status = nullptr;  // pinned
   // record of the last batch (for finish())
   uint64_t last_nq = 0;
@@ -171,9 +171,22 @@ static void reset_status(Workspace& ws, hipStream_t s) {
                          sizeof(StatusBlock) - 2 * sizeof(unsigned long long), s));
 }
 
+constexpr uint32_t GROUP_MAX_BLOCKS = 256;   // query slices of the block-local counting sort
+constexpr uint32_t GROUP_MAX_BINS = 16384;   // histogram must fit LDS next to the pyramid
+
+template <class T>
+static bool lds_sort_fits(const DevicePyramid<T>& pyr, uint64_t nb) {
+  const size_t stage = pyr.lds_bytes <= LDS_STAGE_LIMIT ? ((pyr.lds_bytes + 15) & ~(size_t)15) : 0;
+  return nb <= GROUP_MAX_BINS && stage + nb * 4 <= LDS_STAGE_LIMIT;
+}
+
+// Launches locate_kernel.  With `hist` the grid is one workgroup per contiguous query slice and each
+// leaves its interval histogram in hist[b][nb]; *slice_out / *blocks_out describe the slicing.
 template <class T>
 static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, uint64_t nq,
-                       uint32_t* idx, int64_t* idx64, T* t, unsigned long long* first_fail, int mode) {
+                       uint32_t* idx, int64_t* idx64, T* t, unsigned long long* first_fail, int mode,
+                       uint32_t* hist = nullptr, uint32_t nb = 0, uint64_t* slice_out = nullptr,
+                       uint32_t* blocks_out = nullptr) {
   LocateArgs<T> A{};
   A.pyr = pyr.view;
   A.q = q;
@@ -184,15 +197,28 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
   A.first_fail = first_fail;
   A.mode = mode;
   A.stage_lds = pyr.lds_bytes <= LDS_STAGE_LIMIT ? 1 : 0;
-  const size_t shmem = A.stage_lds ? pyr.lds_bytes : 0;
+  size_t shmem = A.stage_lds ? ((pyr.lds_bytes + 15) & ~(size_t)15) : 0;
+  uint64_t blocks = hist ? std::min<uint64_t>((nq + 2047) / 2048, GROUP_MAX_BLOCKS)
+                         : std::min<uint64_t>((nq + 1023) / 1024, 2048);
+  blocks = std::max<uint64_t>(blocks, 1);
+  uint64_t slice = (nq + blocks - 1) / blocks;
+  slice = (slice + BLOCK - 1) / BLOCK * BLOCK;   // whole 64-query batches per wave
+  blocks = (nq + slice - 1) / slice;
+  A.slice = slice;
+  A.hist = hist;
+  A.nb = nb;
+  if (hist) shmem += (size_t)nb * 4;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate_kernel<T>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate_kernel<T, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate_kernel<T, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
   });
-  const uint64_t blocks_needed = (nq + BLOCK - 1) / BLOCK;
-  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(blocks_needed, 1024));
-  launch1<T>(s, PC_LOCATE, dim3(grid), dim3(BLOCK), shmem, locate_kernel<T>, A);
+  if (slice_out) *slice_out = slice;
+  if (blocks_out) *blocks_out = (uint32_t)blocks;
+  if (A.stage_lds) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(BLOCK), shmem, locate_kernel<T, true>, A);
+  else launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(BLOCK), shmem, locate_kernel<T, false>, A);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -313,8 +339,6 @@ struct Interp1DImpl final : Interp1DBase {
     if (strategy == NDI_CUBIC_SPLINE) ws.t.reserve(nq * sizeof(T));
     reset_status(ws, s);
     StatusBlock* st = ws.status.as<StatusBlock>();
-    run_locate<T>(s, pyr, q, nq, ws.idx.as<uint32_t>(), nullptr,
-                  strategy == NDI_CUBIC_SPLINE ? ws.t.as<T>() : nullptr, &st->first_fail[0], mode);
 
     Eval1Args<T> A{};
     A.knots = pyr.view.lv0;
@@ -338,10 +362,7 @@ struct Interp1DImpl final : Interp1DBase {
     if (path == NDI_PATH_BUCKETED) bucketed = rows_ok && nq < 0xffffffffull;
     else if (path == NDI_PATH_AUTO) bucketed = rows_ok && nq < 0xffffffffull && nq >= 8 * (n - 1);
     g_last_path.store(bucketed ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
-
-    const int U = LV >= 1024 ? 4 : (LV >= 512 ? 2 : 1);
-    const uint64_t segs = rows_ok ? (LV + (uint64_t)BLOCK * U - 1) / ((uint64_t)BLOCK * U) : 1;
-    const unsigned gy = (unsigned)std::min<uint64_t>(segs, 16);
+    T* t_out = strategy == NDI_CUBIC_SPLINE ? ws.t.as<T>() : nullptr;
 
     if (bucketed) {
       const uint32_t nb = (uint32_t)(n - 1);
@@ -349,7 +370,32 @@ struct Interp1DImpl final : Interp1DBase {
       ws.cursor.reserve((size_t)nb * sizeof(uint32_t));
       ws.perm.reserve(nq * sizeof(uint32_t));
       A.perm = ws.perm.as<uint32_t>();
-      {
+      if (lds_sort_fits(pyr, nb)) {
+        // block-local counting sort: histogram per query slice in LDS, no global atomics
+        ws.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
+        uint64_t slice = 0;
+        uint32_t blocks = 0;
+        run_locate<T>(s, pyr, q, nq, ws.idx.as<uint32_t>(), nullptr, t_out,
+                      &st->first_fail[0], mode, ws.hist.as<uint32_t>(), nb, &slice, &blocks);
+        ProfScope ps(s, PC_GROUP);
+        hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
+                           ws.hist.as<uint32_t>(), blocks, nb, ws.counts.as<uint32_t>());
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
+                           ws.cursor.as<uint32_t>(), st);
+        static std::once_flag once;
+        std::call_once(once, [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&group_scatter_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GROUP_MAX_BINS * 4));
+        });
+        hipLaunchKernelGGL(group_scatter_kernel, dim3(blocks), dim3(BLOCK), (size_t)nb * 4, s,
+                           (const uint32_t*)ws.idx.as<uint32_t>(), nq, slice,
+                           (const uint32_t*)ws.hist.as<uint32_t>(), (const uint32_t*)ws.cursor.as<uint32_t>(),
+                           nb, ws.perm.as<uint32_t>());
+        NDI_HIP(hipGetLastError());
+        ps.done();
+      } else {
+        // many intervals: histogram and placement with global atomics
+        run_locate<T>(s, pyr, q, nq, ws.idx.as<uint32_t>(), nullptr, t_out, &st->first_fail[0], mode);
         ProfScope ps(s, PC_GROUP);
         NDI_HIP(hipMemsetAsync(ws.counts.p, 0, (size_t)nb * sizeof(uint32_t), s));
         const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 2048));
@@ -363,27 +409,29 @@ struct Interp1DImpl final : Interp1DBase {
         ps.done();
       }
       constexpr int CQ = 128;
-      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + CQ - 1) / CQ, 8192));
-      dim3 grid(gx, gy);
+      const int U = LV >= 2048 ? 8 : (LV >= 1024 ? 4 : (LV >= 512 ? 2 : 1));
+      const uint64_t segs = (LV + (uint64_t)BLOCK * U - 1) / ((uint64_t)BLOCK * U);
+      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + CQ - 1) / CQ, 65535));
+      dim3 grid(gx, (unsigned)std::min<uint64_t>(segs, 64));
 #define NDI_BK(ST, UU) launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_bucketed_kernel<T, ST, UU, CQ>, A)
       if (strategy == NDI_CUBIC_SPLINE) {
-        if (U == 4) NDI_BK(ST_CUBIC, 4); else if (U == 2) NDI_BK(ST_CUBIC, 2); else NDI_BK(ST_CUBIC, 1);
+        if (U == 8) NDI_BK(ST_CUBIC, 8); else if (U == 4) NDI_BK(ST_CUBIC, 4);
+        else if (U == 2) NDI_BK(ST_CUBIC, 2); else NDI_BK(ST_CUBIC, 1);
       } else {
-        if (U == 4) NDI_BK(ST_LINEAR, 4); else if (U == 2) NDI_BK(ST_LINEAR, 2); else NDI_BK(ST_LINEAR, 1);
+        if (U == 8) NDI_BK(ST_LINEAR, 8); else if (U == 4) NDI_BK(ST_LINEAR, 4);
+        else if (U == 2) NDI_BK(ST_LINEAR, 2); else NDI_BK(ST_LINEAR, 1);
       }
 #undef NDI_BK
       return;
     }
+    run_locate<T>(s, pyr, q, nq, ws.idx.as<uint32_t>(), nullptr, t_out, &st->first_fail[0], mode);
     if (rows_ok) {
-      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nq, 16384));
-      dim3 grid(gx, gy);
-#define NDI_RW(ST, UU) launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_rows_kernel<T, ST, UU>, A)
-      if (strategy == NDI_CUBIC_SPLINE) {
-        if (U == 4) NDI_RW(ST_CUBIC, 4); else if (U == 2) NDI_RW(ST_CUBIC, 2); else NDI_RW(ST_CUBIC, 1);
-      } else {
-        if (U == 4) NDI_RW(ST_LINEAR, 4); else if (U == 2) NDI_RW(ST_LINEAR, 2); else NDI_RW(ST_LINEAR, 1);
-      }
-#undef NDI_RW
+      // one 256-vector segment per workgroup pass and many workgroups: measured best on MI355X
+      const uint64_t segs = (LV + BLOCK - 1) / BLOCK;
+      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nq, 65536));
+      dim3 grid(gx, (unsigned)std::min<uint64_t>(segs, 64));
+      if (strategy == NDI_CUBIC_SPLINE) launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_rows_kernel<T, ST_CUBIC, 1>, A);
+      else launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_rows_kernel<T, ST_LINEAR, 1>, A);
       return;
     }
     // flat

@@ -1,0 +1,486 @@
+// host/ndarray_interp.hpp -- C++17 host-side mirror of the reference's builder / strategy surface
+// above the C ABI (include/ndinterp.h).
+//
+// The reference is Rust (no toolchain in this image), so the compiled host side is written in C++:
+// same names, argument meaning and error behaviour as src/interp1d/mod.rs, src/interp2d/mod.rs and the
+// strategy modules, so a test written against it reads like the reference's own tests
+// (tests/cpp/test_host_mirror.cpp).  Header-only; link with -lndinterp_hip.
+//
+//   auto interp = Interp1DBuilder<double>::new_(data).x(x).strategy(CubicSpline<double>::new_()).build();
+//   Array<double> ys = interp.interp_array(xs);          // one ndi_interp1d_eval call
+//
+// Rust traits -> abstract classes.  `Interp1DStrategy::interp_into` is the reference's per-query hook
+// (strategies/mod.rs:59-64); `interp_array_into` is the defaulted batched hook whose default body is the
+// reference's serial loop (interp1d/mod.rs:326-343), overridden by the built-in strategies.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ndinterp.h"
+
+namespace ndarray_interp {
+
+// ---- errors (src/lib.rs:127-146) ---------------------------------------------------------------
+struct BuilderError : std::runtime_error {
+  enum Kind { NotEnoughData, Monotonic, ShapeError, ValueError } kind;
+  BuilderError(Kind k, const std::string& m) : std::runtime_error(m), kind(k) {}
+};
+struct InterpolateError : std::runtime_error {
+  enum Kind { OutOfBounds } kind = OutOfBounds;
+  uint64_t index;  // lowest failing flat query index
+  double value;
+  int axis;
+  InterpolateError(const std::string& m, uint64_t i, double v, int a)
+      : std::runtime_error(m), index(i), value(v), axis(a) {}
+};
+struct Panic : std::logic_error {  // conditions on which the reference panics
+  using std::logic_error::logic_error;
+};
+struct DeviceError : std::runtime_error {  // HIP failure / no device / unsupported: no CPU fallback
+  using std::runtime_error::runtime_error;
+};
+
+namespace detail {
+template <class T> struct DType;
+template <> struct DType<float> { static constexpr int id = NDI_F32; };
+template <> struct DType<double> { static constexpr int id = NDI_F64; };
+
+inline std::string rust_float(double v) {  // `{x:#?}` of a float
+  if (v != v) return "NaN";
+  if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+  char buf[64];
+  for (int prec = 1; prec <= 17; ++prec) {
+    snprintf(buf, sizeof buf, "%.*g", prec, v);
+    if (std::strtod(buf, nullptr) == v) break;
+  }
+  std::string s(buf);
+  if (s.find_first_of(".en") == std::string::npos) s += ".0";
+  return s;
+}
+[[noreturn]] inline void throw_builder(int st) {
+  const std::string m = ndi_last_error_string();
+  switch (st) {
+    case NDI_NOT_ENOUGH_DATA: throw BuilderError(BuilderError::NotEnoughData, m);
+    case NDI_MONOTONIC: throw BuilderError(BuilderError::Monotonic, m);
+    case NDI_SHAPE: throw BuilderError(BuilderError::ShapeError, m);
+    case NDI_VALUE: throw BuilderError(BuilderError::ValueError, m);
+    default: throw DeviceError("ndinterp_hip status " + std::to_string(st) + ": " + m);
+  }
+}
+[[noreturn]] inline void throw_eval(int st, const ndi_oob_info& info) {
+  if (st == NDI_OUT_OF_BOUNDS)  // linear.rs:81-83, cubic_spline.rs:799-801, bilinear.rs:72-79
+    throw InterpolateError(std::string(info.axis == 0 ? "x" : "y") + " = " + rust_float(info.value) +
+                               " is not in range", info.index, info.value, info.axis);
+  if (st == NDI_NAN_QUERY) throw Panic("not implemented: failed to convert NaN to usize");
+  throw DeviceError("ndinterp_hip status " + std::to_string(st) + ": " + ndi_last_error_string());
+}
+inline size_t prod(const std::vector<size_t>& s, size_t from = 0) {
+  size_t p = 1;
+  for (size_t i = from; i < s.size(); ++i) p *= s[i];
+  return p;
+}
+inline std::string shape_str(const std::vector<size_t>& s) {
+  std::string r = "[";
+  for (size_t i = 0; i < s.size(); ++i) r += (i ? ", " : "") + std::to_string(s[i]);
+  return r + "]";
+}
+}  // namespace detail
+
+// ---- a minimal owned C-order n-d array (the host "ndarray") --------------------------------------
+template <class T>
+struct Array {
+  std::vector<size_t> shape;
+  std::vector<T> data;
+  Array() = default;
+  Array(std::vector<size_t> s, T fill = T(0)) : shape(std::move(s)), data(detail::prod(shape), fill) {}
+  Array(std::vector<size_t> s, std::vector<T> d) : shape(std::move(s)), data(std::move(d)) {
+    if (data.size() != detail::prod(shape)) throw Panic("Array: data length does not match shape");
+  }
+  static Array from_vec(std::vector<T> v) { size_t n = v.size(); return Array({n}, std::move(v)); }
+  static Array linspace(T a, T b, size_t n) {
+    std::vector<T> v(n);
+    const T step = n > 1 ? (b - a) / T(n - 1) : T(0);
+    for (size_t i = 0; i < n; ++i) v[i] = a + step * T(i);
+    if (n > 1) v[n - 1] = b;
+    return from_vec(std::move(v));
+  }
+  size_t ndim() const { return shape.size(); }
+  size_t len() const { return data.size(); }
+  T& operator[](size_t i) { return data[i]; }
+  const T& operator[](size_t i) const { return data[i]; }
+};
+
+// ---- VectorExtensions (src/vector_extensions.rs) -----------------------------------------------------
+enum class Monotonic { NotMonotonic, RisingStrict, Rising, FallingStrict, Falling };
+template <class T>
+Monotonic monotonic_prop(const std::vector<T>& v) {
+  switch (ndi_monotonic_prop(detail::DType<T>::id, v.data(), v.size())) {
+    case NDI_MONO_RISING_STRICT: return Monotonic::RisingStrict;
+    case NDI_MONO_RISING: return Monotonic::Rising;
+    case NDI_MONO_FALLING_STRICT: return Monotonic::FallingStrict;
+    case NDI_MONO_FALLING: return Monotonic::Falling;
+    default: return Monotonic::NotMonotonic;
+  }
+}
+template <class T>
+std::vector<int64_t> get_lower_index(const std::vector<T>& knots, const std::vector<T>& xs, int device = 0) {
+  std::vector<int64_t> out(xs.size());
+  int st = ndi_get_lower_index_batch(detail::DType<T>::id, device, knots.data(), knots.size(), xs.data(),
+                                     xs.size(), out.data(), NDI_MEM_HOST);
+  if (st != NDI_OK) throw DeviceError(ndi_last_error_string());
+  return out;
+}
+
+// =================================================================================================
+// 1-D
+// =================================================================================================
+template <class T> class Interp1D;
+
+template <class T>
+struct Interp1DStrategy {  // trait Interp1DStrategy, strategies/mod.rs:42-65
+  virtual ~Interp1DStrategy() = default;
+  virtual void interp_into(const Interp1D<T>& interpolator, T* target, T x) const = 0;
+  // defaulted batched hook: the reference's loop, stops at the first error
+  virtual void interp_array_into(const Interp1D<T>& interpolator, const T* xs, size_t nq, T* out,
+                                 size_t row_stride) const {
+    for (size_t i = 0; i < nq; ++i) {
+      try {
+        interp_into(interpolator, out + i * row_stride, xs[i]);
+      } catch (InterpolateError& e) {
+        e.index = i;
+        throw;
+      }
+    }
+  }
+};
+
+template <class T>
+struct Interp1DStrategyBuilder {  // trait Interp1DStrategyBuilder, strategies/mod.rs:12-40
+  virtual ~Interp1DStrategyBuilder() = default;
+  virtual size_t MINIMUM_DATA_LENGHT() const = 0;  // sic
+  virtual std::shared_ptr<Interp1DStrategy<T>> build(const std::vector<T>& x, const Array<T>& data) = 0;
+};
+
+namespace detail {
+template <class T>
+struct Device1D : Interp1DStrategy<T> {  // owns an ndi_interp1d*
+  ndi_interp1d* h = nullptr;
+  size_t lanes = 1;
+  int path = NDI_PATH_AUTO;
+  ~Device1D() override { ndi_interp1d_destroy(h); }
+  void create(const std::vector<T>& x, const Array<T>& data, int strategy, bool extrapolate, bool periodic,
+              ndi_boundary left, ndi_boundary right, int device) {
+    ndi_interp1d_desc d{};
+    d.dtype = DType<T>::id; d.strategy = strategy; d.extrapolate = extrapolate; d.device = device;
+    d.n = data.shape[0]; d.lanes = lanes = prod(data.shape, 1); d.x_len = x.size();
+    d.x = x.data(); d.data = data.data.data(); d.memspace = NDI_MEM_HOST;
+    d.validate = 0;  // Interp1DBuilder::build validated already (interp1d/mod.rs:449-473)
+    d.periodic = periodic; d.left = left; d.right = right;
+    int st = ndi_interp1d_create(&d, &h);
+    if (st != NDI_OK) throw_builder(st);
+  }
+  void interp_array_into(const Interp1D<T>&, const T* xs, size_t nq, T* out, size_t row_stride) const override {
+    ndi_eval_opts o{};
+    o.q_memspace = NDI_MEM_HOST; o.out_memspace = NDI_MEM_HOST; o.path = path;
+    ndi_oob_info info{};
+    int st = ndi_interp1d_eval(h, xs, nq, out, row_stride, &o, &info);
+    if (st != NDI_OK) throw_eval(st, info);
+  }
+  void interp_into(const Interp1D<T>& i, T* target, T x) const override { interp_array_into(i, &x, 1, target, lanes); }
+};
+}  // namespace detail
+
+// Linear (src/interp1d/strategies/linear.rs): builder and finished strategy in one, as in the reference
+template <class T>
+class Linear : public Interp1DStrategyBuilder<T> {
+  bool extrapolate_ = false;
+ public:
+  static Linear new_() { return Linear(); }
+  Linear extrapolate(bool e) && { extrapolate_ = e; return std::move(*this); }
+  Linear& extrapolate(bool e) & { extrapolate_ = e; return *this; }
+  size_t MINIMUM_DATA_LENGHT() const override { return 2; }  // linear.rs:52
+  std::shared_ptr<Interp1DStrategy<T>> build(const std::vector<T>& x, const Array<T>& data) override {
+    auto s = std::make_shared<detail::Device1D<T>>();
+    s->create(x, data, NDI_LINEAR, extrapolate_, false, {0, 0.0}, {0, 0.0}, 0);
+    return s;
+  }
+};
+
+// boundary conditions (cubic_spline.rs:153-217)
+struct SingleBoundary {
+  int kind = NDI_BC_NOT_A_KNOT;
+  double value = 0.0;
+  static SingleBoundary NotAKnot() { return {NDI_BC_NOT_A_KNOT, 0.0}; }
+  static SingleBoundary Natural() { return {NDI_BC_NATURAL, 0.0}; }
+  static SingleBoundary Clamped() { return {NDI_BC_CLAMPED, 0.0}; }
+  static SingleBoundary FirstDeriv(double v) { return {NDI_BC_FIRST_DERIV, v}; }
+  static SingleBoundary SecondDeriv(double v) { return {NDI_BC_SECOND_DERIV, v}; }
+};
+struct BoundaryCondition {
+  bool periodic = false;
+  SingleBoundary left, right;
+  static BoundaryCondition NotAKnot() { return {false, SingleBoundary::NotAKnot(), SingleBoundary::NotAKnot()}; }
+  static BoundaryCondition Natural() { return {false, SingleBoundary::Natural(), SingleBoundary::Natural()}; }
+  static BoundaryCondition Clamped() { return {false, SingleBoundary::Clamped(), SingleBoundary::Clamped()}; }
+  static BoundaryCondition Periodic() { return {true, {}, {}}; }
+  // RowBoundary::Mixed applied to the whole dataset
+  static BoundaryCondition Mixed(SingleBoundary l, SingleBoundary r) { return {false, l, r}; }
+};
+
+template <class T>
+class CubicSpline : public Interp1DStrategyBuilder<T> {  // cubic_spline.rs:85-88, 723-771
+  bool extrapolate_ = false;
+  BoundaryCondition boundary_ = BoundaryCondition::NotAKnot();  // default :724-729
+ public:
+  static CubicSpline new_() { return CubicSpline(); }
+  CubicSpline extrapolate(bool e) && { extrapolate_ = e; return std::move(*this); }
+  CubicSpline boundary(BoundaryCondition b) && { boundary_ = b; return std::move(*this); }
+  size_t MINIMUM_DATA_LENGHT() const override { return 3; }  // cubic_spline.rs:751
+  std::shared_ptr<Interp1DStrategy<T>> build(const std::vector<T>& x, const Array<T>& data) override {
+    auto s = std::make_shared<detail::Device1D<T>>();
+    s->create(x, data, NDI_CUBIC_SPLINE, extrapolate_, boundary_.periodic,
+              {boundary_.left.kind, boundary_.left.value}, {boundary_.right.kind, boundary_.right.value}, 0);
+    return s;
+  }
+};
+
+template <class T>
+class Interp1D {  // interp1d/mod.rs:39-51
+ public:
+  std::vector<T> x;
+  Array<T> data;
+  std::shared_ptr<Interp1DStrategy<T>> strategy;
+
+  static Interp1D new_unchecked(std::vector<T> x, Array<T> data, std::shared_ptr<Interp1DStrategy<T>> s) {
+    Interp1D i; i.x = std::move(x); i.data = std::move(data); i.strategy = std::move(s); return i;
+  }
+  size_t lanes() const { return detail::prod(data.shape, 1); }
+  std::vector<size_t> lanes_shape() const { return {data.shape.begin() + 1, data.shape.end()}; }
+
+  std::pair<T, const T*> index_point(size_t index) const { return {x.at(index), data.data.data() + index * lanes()}; }
+  size_t get_index_left_of(T v) const {
+    auto r = get_lower_index<T>(x, {v});
+    if (r[0] < 0) throw Panic("not implemented: failed to convert NaN to usize");
+    return (size_t)r[0];
+  }
+  bool is_in_range(T v) const { return x.front() <= v && v <= x.back(); }
+
+  T interp_scalar(T v) const {  // :108-114
+    if (data.ndim() != 1) throw Panic("interp_scalar needs 1-D data");
+    T out = T(0);
+    strategy->interp_into(*this, &out, v);
+    return out;
+  }
+  Array<T> interp(T v) const {  // :150-156
+    Array<T> target(lanes_shape());
+    strategy->interp_into(*this, target.data.data(), v);
+    return target;
+  }
+  void interp_into(T v, Array<T>& buffer) const {  // :169-175
+    if (buffer.shape != lanes_shape())
+      throw Panic("incompatible shapes expected: " + detail::shape_str(lanes_shape()) + ", got: " +
+                  detail::shape_str(buffer.shape));
+    strategy->interp_into(*this, buffer.data.data(), v);
+  }
+  std::vector<size_t> get_buffer_shape(const std::vector<size_t>& dq) const {  // :346-354
+    std::vector<size_t> s = dq;
+    s.insert(s.end(), data.shape.begin() + 1, data.shape.end());
+    return s;
+  }
+  Array<T> interp_array(const Array<T>& xs) const {  // :197-211
+    Array<T> ys(get_buffer_shape(xs.shape));
+    interp_array_into(xs, ys);
+    return ys;
+  }
+  void interp_array_into(const Array<T>& xs, Array<T>& buffer) const {  // :272-324, any query rank
+    const auto expect = get_buffer_shape(xs.shape);
+    if (buffer.shape != expect)
+      throw Panic("incompatible shapes expected: " + detail::shape_str(expect) + ", got: " +
+                  detail::shape_str(buffer.shape));
+    strategy->interp_array_into(*this, xs.data.data(), xs.len(), buffer.data.data(), lanes());
+  }
+};
+
+template <class T>
+class Interp1DBuilder {  // interp1d/mod.rs:60-70, 389-477
+  Array<T> data_;
+  std::vector<T> x_;
+  bool has_x_ = false;
+  std::shared_ptr<Interp1DStrategyBuilder<T>> strategy_;
+ public:
+  static Interp1DBuilder new_(Array<T> data) {
+    Interp1DBuilder b; b.data_ = std::move(data); b.strategy_ = std::make_shared<Linear<T>>(); return b;  // :408
+  }
+  Interp1DBuilder x(std::vector<T> x) && { x_ = std::move(x); has_x_ = true; return std::move(*this); }
+  template <class S> Interp1DBuilder strategy(S s) && { strategy_ = std::make_shared<S>(std::move(s)); return std::move(*this); }
+
+  Interp1D<T> build() && {  // :443-476, check order preserved
+    if (data_.ndim() < 1) throw BuilderError(BuilderError::ShapeError, "data dimension is 0, needs to be at least 1");
+    const size_t n = data_.shape[0];
+    if (!has_x_) { x_.resize(n); for (size_t i = 0; i < n; ++i) x_[i] = T(i); }  // :402-406
+    const size_t need = strategy_->MINIMUM_DATA_LENGHT();
+    if (n < need)
+      throw BuilderError(BuilderError::NotEnoughData,
+                         "The chosen Interpolation strategy needs at least " + std::to_string(need) + " data points");
+    if (monotonic_prop(x_) != Monotonic::RisingStrict)
+      throw BuilderError(BuilderError::Monotonic, "Values in the x axis need to be strictly monotonic rising");
+    if (x_.size() != n)
+      throw BuilderError(BuilderError::ShapeError, "Lengths of x and data axis need to match. Got x: " +
+                                                       std::to_string(x_.size()) + ", data: " + std::to_string(n));
+    auto finished = strategy_->build(x_, data_);
+    return Interp1D<T>::new_unchecked(std::move(x_), std::move(data_), std::move(finished));
+  }
+};
+
+// =================================================================================================
+// 2-D
+// =================================================================================================
+template <class T> class Interp2D;
+
+template <class T>
+struct Interp2DStrategy {  // src/interp2d/strategies/mod.rs:46-73
+  virtual ~Interp2DStrategy() = default;
+  virtual void interp_into(const Interp2D<T>&, T* target, T x, T y) const = 0;
+  virtual void interp_array_into(const Interp2D<T>& ip, const T* xs, const T* ys, size_t nq, T* out,
+                                 size_t row_stride) const {
+    for (size_t i = 0; i < nq; ++i) {
+      try {
+        interp_into(ip, out + i * row_stride, xs[i], ys[i]);
+      } catch (InterpolateError& e) {
+        e.index = i;
+        throw;
+      }
+    }
+  }
+};
+template <class T>
+struct Interp2DStrategyBuilder {  // src/interp2d/strategies/mod.rs:14-44
+  virtual ~Interp2DStrategyBuilder() = default;
+  virtual size_t MINIMUM_DATA_LENGHT() const = 0;
+  virtual std::shared_ptr<Interp2DStrategy<T>> build(const std::vector<T>& x, const std::vector<T>& y,
+                                                     const Array<T>& data) = 0;
+};
+
+namespace detail {
+template <class T>
+struct Device2D : Interp2DStrategy<T> {
+  ndi_interp2d* h = nullptr;
+  size_t lanes = 1;
+  ~Device2D() override { ndi_interp2d_destroy(h); }
+  void interp_array_into(const Interp2D<T>&, const T* xs, const T* ys, size_t nq, T* out,
+                         size_t row_stride) const override {
+    ndi_eval_opts o{};
+    o.q_memspace = NDI_MEM_HOST; o.out_memspace = NDI_MEM_HOST;
+    ndi_oob_info info{};
+    int st = ndi_interp2d_eval(h, xs, ys, nq, out, row_stride, &o, &info);
+    if (st != NDI_OK) throw_eval(st, info);
+  }
+  void interp_into(const Interp2D<T>& i, T* target, T x, T y) const override {
+    interp_array_into(i, &x, &y, 1, target, lanes);
+  }
+};
+}  // namespace detail
+
+template <class T>
+class Bilinear : public Interp2DStrategyBuilder<T> {  // src/interp2d/strategies/bilinear.rs
+  bool extrapolate_ = false;
+ public:
+  static Bilinear new_() { return Bilinear(); }
+  Bilinear extrapolate(bool yes) && { extrapolate_ = yes; return std::move(*this); }
+  size_t MINIMUM_DATA_LENGHT() const override { return 2; }  // bilinear.rs:41
+  std::shared_ptr<Interp2DStrategy<T>> build(const std::vector<T>& x, const std::vector<T>& y,
+                                             const Array<T>& data) override {
+    auto s = std::make_shared<detail::Device2D<T>>();
+    ndi_interp2d_desc d{};
+    d.dtype = detail::DType<T>::id; d.extrapolate = extrapolate_; d.device = 0; d.memspace = NDI_MEM_HOST;
+    d.nx = data.shape[0]; d.ny = data.shape[1]; d.lanes = s->lanes = detail::prod(data.shape, 2);
+    d.x_len = x.size(); d.y_len = y.size(); d.x = x.data(); d.y = y.data(); d.data = data.data.data();
+    d.validate = 0;
+    int st = ndi_interp2d_create(&d, &s->h);
+    if (st != NDI_OK) detail::throw_builder(st);
+    return s;
+  }
+};
+
+template <class T>
+class Interp2D {  // interp2d/mod.rs:36-48
+ public:
+  std::vector<T> x, y;
+  Array<T> data;
+  std::shared_ptr<Interp2DStrategy<T>> strategy;
+  size_t lanes() const { return detail::prod(data.shape, 2); }
+  std::vector<size_t> lanes_shape() const { return {data.shape.begin() + 2, data.shape.end()}; }
+  bool is_in_x_range(T v) const { return x.front() <= v && v <= x.back(); }
+  bool is_in_y_range(T v) const { return y.front() <= v && v <= y.back(); }
+  T interp_scalar(T xv, T yv) const {
+    if (data.ndim() != 2) throw Panic("interp_scalar needs 2-D data");
+    T out = T(0);
+    strategy->interp_into(*this, &out, xv, yv);
+    return out;
+  }
+  Array<T> interp(T xv, T yv) const {
+    Array<T> t(lanes_shape());
+    strategy->interp_into(*this, t.data.data(), xv, yv);
+    return t;
+  }
+  Array<T> interp_array(const Array<T>& xs, const Array<T>& ys) const {  // :175-196
+    if (xs.shape != ys.shape) throw Panic("`xs.shape()` and `ys.shape()` do not match");
+    std::vector<size_t> s = xs.shape;
+    s.insert(s.end(), data.shape.begin() + 2, data.shape.end());
+    Array<T> zs(s);
+    strategy->interp_array_into(*this, xs.data.data(), ys.data.data(), xs.len(), zs.data.data(), lanes());
+    return zs;
+  }
+};
+
+template <class T>
+class Interp2DBuilder {  // interp2d/mod.rs:52-64, 382-519
+  Array<T> data_;
+  std::vector<T> x_, y_;
+  bool has_x_ = false, has_y_ = false;
+  std::shared_ptr<Interp2DStrategyBuilder<T>> strategy_;
+ public:
+  static Interp2DBuilder new_(Array<T> data) {
+    Interp2DBuilder b; b.data_ = std::move(data); b.strategy_ = std::make_shared<Bilinear<T>>(); return b;
+  }
+  Interp2DBuilder x(std::vector<T> v) && { x_ = std::move(v); has_x_ = true; return std::move(*this); }
+  Interp2DBuilder y(std::vector<T> v) && { y_ = std::move(v); has_y_ = true; return std::move(*this); }
+  template <class S> Interp2DBuilder strategy(S s) && { strategy_ = std::make_shared<S>(std::move(s)); return std::move(*this); }
+  Interp2D<T> build() && {  // :468-518, check order preserved
+    if (data_.ndim() < 2) throw BuilderError(BuilderError::ShapeError, "data dimension needs to be at least 2");
+    const size_t nx = data_.shape[0], ny = data_.shape[1], need = strategy_->MINIMUM_DATA_LENGHT();
+    auto ne = [&](int dim, size_t have) {
+      return BuilderError(BuilderError::NotEnoughData,
+                          "The " + std::to_string(dim) + "-dimension has not enough data for the chosen interpolation "
+                          "strategy. Provided: " + std::to_string(have) + ", Reqired: " + std::to_string(need));
+    };
+    if (nx < need) throw ne(0, nx);
+    if (ny < need) throw ne(1, ny);
+    if (!has_x_) { x_.resize(nx); for (size_t i = 0; i < nx; ++i) x_[i] = T(i); }
+    if (!has_y_) { y_.resize(ny); for (size_t i = 0; i < ny; ++i) y_[i] = T(i); }
+    if (x_.size() != nx)
+      throw BuilderError(BuilderError::ShapeError, "Lenghts of x-axis and data-0-axis need to match. Got x: " +
+                                                       std::to_string(x_.size()) + ", data-0: " + std::to_string(nx));
+    if (y_.size() != ny)
+      throw BuilderError(BuilderError::ShapeError, "Lenghts of y-axis and data-1-axis need to match. Got y: " +
+                                                       std::to_string(y_.size()) + ", data-1: " + std::to_string(ny));
+    if (monotonic_prop(x_) != Monotonic::RisingStrict)
+      throw BuilderError(BuilderError::Monotonic, "The x-axis needs to be strictly monotonic rising");
+    if (monotonic_prop(y_) != Monotonic::RisingStrict)
+      throw BuilderError(BuilderError::Monotonic, "The y-axis needs to be strictly monotonic rising");
+    Interp2D<T> ip;
+    ip.strategy = strategy_->build(x_, y_, data_);
+    ip.x = std::move(x_); ip.y = std::move(y_); ip.data = std::move(data_);
+    return ip;
+  }
+};
+
+}  // namespace ndarray_interp

@@ -1,0 +1,165 @@
+// tests/cpp/test_host_mirror.cpp -- the C++ host mirror (ndarray-interp_amd/host/ndarray_interp.hpp) driven the
+// way the reference's own tests drive the crate (tests/interp1d.rs, tests/interp2d.rs,
+// tests/cubic_spline_strat.rs, examples/custom_strategy.rs).  `--host-only` runs the cases that need no GPU
+// (builder validation); without it the device cases run too.  Exit code = number of failed checks.
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "../../ndarray-interp_amd/host/ndarray_interp.hpp"
+
+using namespace ndarray_interp;
+static int failures = 0;
+#define CHECK(cond)                                                                  \
+  do {                                                                               \
+    if (!(cond)) { ++failures; std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); } \
+  } while (0)
+template <class E, class F>
+static bool throws(F&& f) {
+  try { f(); } catch (const E&) { return true; } catch (...) { return false; }
+  return false;
+}
+template <class E, class F>
+static bool throws(F&& f, int kind) {
+  try { f(); } catch (const E& e) { return (int)e.kind == kind; } catch (...) { return false; }
+  return false;
+}
+static Array<double> arr(std::vector<double> v) { return Array<double>::from_vec(std::move(v)); }
+
+static void host_only() {
+  // tests/interp1d.rs:123-140 (builder errors) and the check order of interp1d/mod.rs:454-471
+  CHECK(throws<BuilderError>([] { Interp1DBuilder<double>::new_(arr({1})).build(); }, BuilderError::NotEnoughData));
+  CHECK(throws<BuilderError>([] { Interp1DBuilder<double>::new_(arr({1, 2})).x({1, 2, 3}).build(); }, BuilderError::ShapeError));
+  CHECK(throws<BuilderError>([] { Interp1DBuilder<double>::new_(arr({1, 2, 3})).x({1, 2, 2}).build(); }, BuilderError::Monotonic));
+  CHECK(throws<BuilderError>([] { Interp1DBuilder<double>::new_(arr({1, 2})).strategy(CubicSpline<double>::new_()).build(); },
+                             BuilderError::NotEnoughData));  // tests/cubic_spline_strat.rs:30-35
+  CHECK(throws<BuilderError>([] { Interp1DBuilder<double>::new_(arr({1})).x({2, 1}).build(); }, BuilderError::NotEnoughData));
+  // tests/interp2d.rs:280-329
+  auto g = [](size_t a, size_t b) { return Array<double>({a, b}, 1.0); };
+  CHECK(throws<BuilderError>([&] { Interp2DBuilder<double>::new_(g(1, 1)).build(); }, BuilderError::NotEnoughData));
+  CHECK(throws<BuilderError>([&] { Interp2DBuilder<double>::new_(g(1, 2)).build(); }, BuilderError::NotEnoughData));
+  CHECK(throws<BuilderError>([&] { Interp2DBuilder<double>::new_(g(2, 1)).build(); }, BuilderError::NotEnoughData));
+  CHECK(throws<BuilderError>([&] { Interp2DBuilder<double>::new_(g(2, 2)).x({1}).build(); }, BuilderError::ShapeError));
+  CHECK(throws<BuilderError>([&] { Interp2DBuilder<double>::new_(g(2, 2)).y({1, 2, 3}).build(); }, BuilderError::ShapeError));
+  CHECK(throws<BuilderError>([&] { Interp2DBuilder<double>::new_(g(2, 2)).x({2, 2}).build(); }, BuilderError::Monotonic));
+  CHECK(throws<BuilderError>([&] { Interp2DBuilder<double>::new_(g(2, 2)).y({2, 2}).build(); }, BuilderError::Monotonic));
+  CHECK(monotonic_prop<double>({1.1, 2.0, 3.123, 4.5}) == Monotonic::RisingStrict);  // vector_extensions.rs:318-346
+  CHECK(monotonic_prop<double>({1.1, 2.0, 3.123, 3.123, 4.5}) == Monotonic::Rising);
+  CHECK(monotonic_prop<float>({5.8f, 4.1f, 3.1f, 3.1f, 2.0f}) == Monotonic::Falling);
+  CHECK(monotonic_prop<double>({1, 1, 1}) == Monotonic::NotMonotonic);
+}
+
+// examples/custom_strategy.rs
+struct StepInterpolator : Interp1DStrategyBuilder<double>, Interp1DStrategy<double>,
+                          std::enable_shared_from_this<StepInterpolator> {
+  size_t MINIMUM_DATA_LENGHT() const override { return 2; }
+  std::shared_ptr<Interp1DStrategy<double>> build(const std::vector<double>&, const Array<double>&) override {
+    return std::make_shared<StepInterpolator>();
+  }
+  void interp_into(const Interp1D<double>& ip, double* target, double x) const override {
+    size_t idx = ip.get_index_left_of(x);
+    auto [xl, dl] = ip.index_point(idx);
+    auto [xr, dr] = ip.index_point(idx + 1);
+    const double* src = ((xr - xl) / 2.0 > (x - xl)) ? dl : dr;
+    for (size_t l = 0; l < ip.lanes(); ++l) target[l] = src[l];
+  }
+};
+
+static void device() {
+  const double EPS = std::numeric_limits<double>::epsilon();
+  {  // tests/interp1d.rs:21-30 interp_y_only
+    auto ip = Interp1DBuilder<double>::new_(arr({1.5, 2.0, 3.0, 4.0, 5.0, 7.0, 7.0, 8.0, 9.0, 10.5})).build();
+    CHECK(ip.interp_scalar(0.0) == 1.5); CHECK(ip.interp_scalar(9.0) == 10.5); CHECK(ip.interp_scalar(4.5) == 6.0);
+    CHECK(ip.interp_scalar(0.25) == 1.625); CHECK(ip.interp_scalar(8.75) == 10.125);
+  }
+  {  // tests/interp1d.rs:72-80 extrapolate_with_x_and_y
+    auto ip = Interp1DBuilder<double>::new_(arr({1.0, 0.0, 1.5})).x({0.0, 1.0, 1.5})
+                  .strategy(Linear<double>::new_().extrapolate(true)).build();
+    CHECK(ip.interp_scalar(-1.0) == 2.0); CHECK(ip.interp_scalar(2.0) == 3.0);
+  }
+  {  // tests/interp1d.rs:83-90 interp_array with a 2-D query
+    auto ip = Interp1DBuilder<double>::new_(arr({1, 2, 3, 4, 5, 5, 4, 3, 2, 1})).build();
+    Array<double> q({2, 3}, std::vector<double>{1.0, 2.0, 9.0, 4.0, 5.0, 7.5});
+    auto r = ip.interp_array(q);
+    CHECK((r.shape == std::vector<size_t>{2, 3}));
+    CHECK((r.data == std::vector<double>{2.0, 3.0, 1.0, 5.0, 5.0, 2.5}));
+  }
+  {  // tests/interp1d.rs:93-120 out of bounds, message of linear.rs:81-83
+    auto ip = Interp1DBuilder<double>::new_(arr({1, 2, 3})).build();
+    CHECK(throws<InterpolateError>([&] { ip.interp(-0.1); }));
+    CHECK(throws<InterpolateError>([&] { ip.interp(9.0); }));
+    try { ip.interp_array(arr({0.5, 1.5, -0.1, 7.0})); CHECK(false); }
+    catch (const InterpolateError& e) { CHECK(e.index == 2); CHECK(std::string(e.what()) == "x = -0.1 is not in range"); }
+  }
+  {  // tests/interp1d.rs:158-195 interp_multi_fn
+    Array<double> data({4, 5}, std::vector<double>{0.1, 0.2, 0.3, 0.4, 0.5, 2, 2, 3, 4, 5, 10, 20, 30, 40, 50, 20, 40, 60, 80, 100});
+    auto ip = Interp1DBuilder<double>::new_(data).x({1, 2, 3, 4}).build();
+    auto r = ip.interp(1.5);
+    const double e[5] = {1.05, 1.1, 1.65, 2.2, 2.75};
+    for (int i = 0; i < 5; ++i) CHECK(std::fabs(r[i] - e[i]) <= EPS);
+    Array<double> q({2, 2}, std::vector<double>{1.0, 1.5, 3.5, 4.0});
+    auto rr = ip.interp_array(q);
+    CHECK((rr.shape == std::vector<size_t>{2, 2, 5}));
+    CHECK(std::fabs(rr[15] - 20.0) <= EPS && std::fabs(rr[19] - 100.0) <= EPS && std::fabs(rr[10] - 15.0) <= EPS);
+    Array<double> bad({4});
+    CHECK(throws<Panic>([&] { ip.interp_into(1.5, bad); }));
+  }
+  {  // cubic_spline.rs:62-82 doctest (abs f64::EPSILON)
+    auto ip = Interp1DBuilder<double>::new_(arr({0.5, 0.0, 3.0})).strategy(CubicSpline<double>::new_()).x({-1.0, 0.0, 3.0}).build();
+    auto r = ip.interp_array(Array<double>::linspace(-1.0, 3.0, 10));
+    const double e[10] = {0.5, 0.1851851851851852, 0.01851851851851853, -5.551115123125783e-17, 0.12962962962962965,
+                          0.40740740740740755, 0.8333333333333331, 1.407407407407407, 2.1296296296296293, 3.0};
+    for (int i = 0; i < 10; ++i) CHECK(std::fabs(r[i] - e[i]) <= EPS);
+  }
+  {  // tests/cubic_spline_strat.rs:46-55, 442-452, 455-501 (first and last periodic values)
+    auto ip = Interp1DBuilder<double>::new_(arr({1, 2, 1})).strategy(CubicSpline<double>::new_()).build();
+    CHECK(throws<InterpolateError>([&] { ip.interp(-0.5); }));
+    CHECK(throws<InterpolateError>([&] { ip.interp(3.5); }));
+    Array<double> y({3, 2}, std::vector<double>{0.5, 1.0, 0.0, 1.5, 0.5, 1.1});
+    CHECK(throws<BuilderError>([&] { Interp1DBuilder<double>::new_(y).strategy(
+        CubicSpline<double>::new_().boundary(BoundaryCondition::Periodic())).build(); }, BuilderError::ValueError));
+    auto per = Interp1DBuilder<double>::new_(arr({1.0, 2.0, 2.5, 2.5, 3.0, 2.0, 1.0, -2.0, 3.0, 5.0, 6.3, 1.0}))
+                   .strategy(CubicSpline<double>::new_().extrapolate(true).boundary(BoundaryCondition::Periodic())).build();
+    auto r = per.interp_array(Array<double>::linspace(-3.0, 15.0, 30));
+    CHECK(std::fabs(r[0] - 3.0) <= 1e-3 * 3.0 && std::fabs(r[29] - 3.0) <= 1e-3 * 3.0 && std::fabs(r[1] - 4.45171164) <= 1e-3 * 4.45);
+    auto d1 = Interp1DBuilder<double>::new_(arr({1.0, 2.0, 2.5, 2.5, 3.0, 2.0, 1.0, -2.0, 3.0, 5.0, 6.3, 8.0}))
+                  .strategy(CubicSpline<double>::new_().extrapolate(true).boundary(
+                      BoundaryCondition::Mixed(SingleBoundary::FirstDeriv(-0.1), SingleBoundary::FirstDeriv(-0.5)))).build();
+    auto r1 = d1.interp_array(Array<double>::linspace(-3.0, 15.0, 30));
+    CHECK(std::fabs(r1[0] - 45.12263976) <= 1e-3 * 45.2 && std::fabs(r1[29] + 165.7395108) <= 1e-3 * 166.0);
+  }
+  {  // examples/custom_strategy.rs:56-68 -- user strategy through the default batched hook
+    auto ip = Interp1DBuilder<double>::new_(arr({2.0, 4.0, 5.0})).strategy(StepInterpolator()).build();
+    auto r = ip.interp_array(Array<double>::linspace(-0.5, 2.5, 6));
+    CHECK((r.data == std::vector<double>{2.0, 2.0, 4.0, 4.0, 5.0, 5.0}));
+  }
+  {  // tests/interp2d.rs:50-60, 63-82, 241-277
+    Array<double> data({3, 4}, std::vector<double>{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12});
+    auto ip = Interp2DBuilder<double>::new_(data).y({-3.0, -2.0, -1.0, 0.0}).build();
+    CHECK(ip.interp_scalar(0.0, -3.0) == 1.0); CHECK(ip.interp_scalar(2.0, 0.0) == 12.0);
+    CHECK(ip.interp_scalar(2.0, -3.0) == 9.0); CHECK(ip.interp_scalar(0.0, 0.0) == 4.0);
+    auto ip2 = Interp2DBuilder<double>::new_(data).build();
+    try { ip2.interp(1.0, -1.0); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.axis == 1); }
+    try { ip2.interp(3.0, 9.0); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.axis == 0); }
+    CHECK(throws<Panic>([&] { ip2.interp_array(arr({0.0, 1.0}), arr({0.0, 1.0, 2.0})); }));
+    Array<double> nd({2, 2, 2, 2}, std::vector<double>{1, 10, -1, -10, 2, 20, -2, -20, 3, 30, -3, -30, 5, 50, -5, -50});
+    auto ip3 = Interp2DBuilder<double>::new_(nd).build();
+    auto r = ip3.interp_array(arr({0.0, 0.5}), arr({0.5, 1.0}));
+    CHECK((r.shape == std::vector<size_t>{2, 2, 2}));
+    CHECK((r.data == std::vector<double>{1.5, 15.0, -1.5, -15.0, 3.5, 35.0, -3.5, -35.0}));
+  }
+  {  // f32 is a first-class type (tests/cubic_spline_strat.rs:108-154)
+    Array<float> d = Array<float>::from_vec({1.f, 2.f, 2.5f, 2.5f, 3.f, 2.f, 1.f, -2.f, 3.f, 5.f, 6.3f, 8.f});
+    auto ip = Interp1DBuilder<float>::new_(d).strategy(CubicSpline<float>::new_().extrapolate(true)).build();
+    auto r = ip.interp_array(Array<float>::linspace(-3.f, 15.f, 30));
+    CHECK(std::fabs(r[0] - 0.94398816f) <= 1e-3f && std::fabs(r[29] - 5.825231f) <= 6e-3f);
+  }
+}
+
+int main(int argc, char** argv) {
+  const bool host_only_flag = argc > 1 && std::strcmp(argv[1], "--host-only") == 0;
+  host_only();
+  if (!host_only_flag) device();
+  std::printf("%s: %d failed check(s)\n", host_only_flag ? "host-only" : "host+device", failures);
+  return failures;
+}

@@ -76,6 +76,50 @@ def cpu_baseline(x, y, q_all, budget_s=20.0):
     return res, build_s
 
 
+def extra_workload(args, pkg, torch, dev, rank, world):
+    """Secondary measurements (not the driver's bench line): C3 bilinear, Linear on the C2 shape."""
+    rng = np.random.default_rng(42)
+    if args.workload == "c3":   # BASELINE configs[2]: 2048x2048 grid x 64 channels f32, 1e7 (x, y) queries
+        nx = ny = 2048; C = 64; nq = 10_000_000 if args.queries == 1_000_000 else args.queries
+        x = np.unique(rng.uniform(0, 1, 2 * nx).astype(np.float32))[:nx]
+        y = np.unique(rng.uniform(0, 1, 2 * ny).astype(np.float32))[:ny]
+        g = torch.rand((nx, ny, C), dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+        interp = pkg.Interp2DBuilder.new(g).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
+        qx = torch.as_tensor(np.random.default_rng(123).uniform(x[0], x[-1], nq).astype(np.float32), device=dev)
+        qy = torch.as_tensor(np.random.default_rng(96).uniform(y[0], y[-1], nq).astype(np.float32), device=dev)
+        out = torch.empty((nq, C), dtype=torch.float32, device=dev)
+        step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
+        points, alg = nq * C, nq * C * 20 + nq * 8
+        name = f"C3: 2D Bilinear, {nx}x{ny} grid x {C} channels f32, {nq} queries"
+    else:                        # Linear on the C2 shape
+        n = lanes = 4096; nq = args.queries
+        x, yv, q = synth_c2(n, lanes, nq, rank)
+        interp = pkg.Interp1DBuilder.new(torch.as_tensor(yv, device=dev)).x(torch.as_tensor(x, device=dev)).build()
+        interp.strategy.path = {"auto": pkg.PATH_AUTO, "gather": pkg.PATH_GATHER, "bucketed": pkg.PATH_BUCKETED}[args.path]
+        qd = torch.as_tensor(q, device=dev)
+        out = torch.empty((nq, lanes), dtype=torch.float64, device=dev)
+        step = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
+        points, alg = nq * lanes, nq * lanes * 24 + nq * 8
+        name = f"1D Linear, {n} knots x {lanes} lanes f64, {nq} queries"
+    for _ in range(args.warmup):
+        step()
+    interp.strategy.finish()
+    pkg.profile_enable(True); pkg.profile_read(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    interp.strategy.finish()
+    prof = pkg.profile_read(reset=True)
+    kms = prof["eval_ms"] / max(1, prof["eval_launches"])
+    print(json.dumps({"workload": name, "path": prof["last_path"], "value_Mpoints_s": round(points * args.steps / el / 1e6, 1),
+                      "ms_per_step": round(el / args.steps * 1e3, 4), "eval_kernel_ms": round(kms, 4),
+                      "algorithmic_GBs": round(alg / (kms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "stages_ms_per_step": {k: round(prof[k + "_ms"] / args.steps, 4) for k in ("locate", "group", "eval")}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +130,10 @@ def main():
     ap.add_argument("--queries", type=int, default=1_000_000, help="queries per GPU per step")
     ap.add_argument("--path", choices=["auto", "gather", "bucketed"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c2", "c3", "c2-linear"], default="c2",
+                    help="c2 = headline (BASELINE configs[1]); c3 / c2-linear are extra measurements for DESIGN.md")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -93,13 +141,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device_override is not None:
+        local_rank = args.device_override
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     pkg = load_package()
+    if args.workload != "c2":
+        return extra_workload(args, pkg, torch, dev, rank, world)
 
     n, lanes, nq = args.knots, args.lanes, args.queries
     x, y, q = synth_c2(n, lanes, nq, rank)
@@ -154,7 +209,7 @@ def main():
         comp_bytes = points_per_step * 8 + (n + 2 * (n - 1)) * lanes * 8 + nq * 8
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (n, lanes, nq) == (4096, 4096, 1_000_000):  # measured on exactly this workload
             try:
                 traffic = json.load(open(tpath)).get(f"{prof['last_path']}_bytes_per_launch")
             except Exception:

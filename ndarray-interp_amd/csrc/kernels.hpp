@@ -605,11 +605,25 @@ struct BuildArgs {
   T nkL_tmp1, nkL_d, nkR_tmp1, nkR_d, dx0_sq, dxl_sq;
   T per_den;
   StatusBlock* status;
+  // BoundaryCondition::Individual (cubic_spline.rs:332-347, 370-403): per-lane end kinds / values.
+  // The elimination factors depend on the LEFT end kind only (rows 1..n-2) and the last row on both,
+  // so the host prepares 4 forward plans (NotAKnot, FirstDeriv, SecondDeriv, parabola-end) and 4x4 last rows.
+  const uint8_t* lane_cls;   // left | right << 2   (EndKind, 3 = the n == 3 not-a-knot parabola rows)
+  const T* lane_lval;
+  const T* lane_rval;
+  const T* w4;      // [4][n]
+  const T* midp4;   // [4][n]
+  const T* up0_4;   // [4]
+  const T* wl;      // [4][4]  w[n-1]
+  const T* midl;    // [4][4]  mid'[n-1]
 };
 
 // SPLINE_GENERAL: rows 0 and n-1 from the boundary kinds (cubic_spline.rs:597-670), interior
 // rows :456-471, thomas :678-721, then a/b :354-365 fused into the back substitution.
-template <class T>
+// PER_LANE: BoundaryCondition::Individual -- every lane selects its own end kinds / values and the
+// matching precomputed elimination plan (arithmetic per lane identical to a scalar solve of that column,
+// which is what solve_for_k_individual :370-403 does).
+template <class T, bool PER_LANE>
 __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A) {
   const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= A.lanes) return;
@@ -618,21 +632,42 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
   const T* y = A.data + l;
   T* sa = A.ca + l;
   T* sb = A.cb + l;
+  int lk = A.left_kind, rk = A.right_kind;
+  T lval = A.left_val, rval = A.right_val;
+  const T* w = A.w;
+  const T* midp = A.midp;
+  T up0 = A.up[0], w_last = A.w[n - 1], mid_last = A.midp[n - 1];
+  if (PER_LANE) {
+    const uint32_t cls = A.lane_cls[l];
+    lk = (int)(cls & 3u);
+    rk = (int)(cls >> 2);
+    lval = A.lane_lval[l];
+    rval = A.lane_rval[l];
+    w = A.w4 + (uint64_t)lk * n;
+    midp = A.midp4 + (uint64_t)lk * n;
+    up0 = A.up0_4[lk];
+    w_last = A.wl[lk * 4 + rk];
+    mid_last = A.midl[lk * 4 + rk];
+  }
   T ym = y[0], yc = y[L], yp = y[2 * L];
   const T dx0 = A.dx[0], dx1 = A.dx[1];
   T r_prev;
-  if (A.left_kind == 0) {
+  if (lk == 0) {
     r_prev = (A.nkL_tmp1 * (yc - ym) / dx0 + A.dx0_sq * (yp - yc) / dx1) / A.nkL_d;
-  } else if (A.left_kind == 1) {
-    r_prev = A.left_val;
-  } else {
-    r_prev = three * (yc - ym) - A.left_val * A.dx0_sq / two;
+  } else if (lk == 1) {
+    r_prev = lval;
+  } else if (lk == 2) {
+    r_prev = three * (yc - ym) - lval * A.dx0_sq / two;
+  } else {  // parabola rows (:592), n == 3 only
+    r_prev = ((yc - ym) / dx0) * two;
   }
   sa[0] = r_prev;
   for (uint64_t i = 1; i + 1 < n; ++i) {
     const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
-    const T rhs = three * (dxn * (yc - ym) / dxn_1 + dxn_1 * (yp - yc) / dxn);
-    const T r = rhs - A.w[i] * r_prev;
+    T rhs;
+    if (PER_LANE && lk == 3) rhs = (((yp - yc) / dx1) * dx0 + ((yc - ym) / dx0) * dx1) * three;  // :593-594
+    else rhs = three * (dxn * (yc - ym) / dxn_1 + dxn_1 * (yp - yc) / dxn);
+    const T r = rhs - w[i] * r_prev;
     sa[i * L] = r;
     r_prev = r;
     if (i + 2 < n) {
@@ -644,20 +679,22 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
   // window is now (y[n-3], y[n-2], y[n-1])
   const T dxl = A.dx[n - 2], dxl2 = A.dx[n - 3];
   T rhs_last;
-  if (A.right_kind == 0) {
+  if (rk == 0) {
     rhs_last = (A.dxl_sq * (yc - ym) / dxl2 + A.nkR_tmp1 * (yp - yc) / dxl) / A.nkR_d;
-  } else if (A.right_kind == 1) {
-    rhs_last = A.right_val;
-  } else {
-    rhs_last = three * (yp - yc) + A.right_val * A.dxl_sq / two;
+  } else if (rk == 1) {
+    rhs_last = rval;
+  } else if (rk == 2) {
+    rhs_last = three * (yp - yc) + rval * A.dxl_sq / two;
+  } else {  // parabola rows (:595)
+    rhs_last = ((yp - yc) / dxl) * two;
   }
-  const T r_last = rhs_last - A.w[n - 1] * r_prev;
-  T k_next = r_last / A.midp[n - 1];
+  const T r_last = rhs_last - w_last * r_prev;
+  T k_next = r_last / mid_last;
   T y_hi = yp;
   for (uint64_t i = n - 1; i-- > 0;) {
     const T ri = sa[i * L];
     const T y_lo = y[i * L];
-    const T k = (ri - A.up[i] * k_next) / A.midp[i];
+    const T k = (ri - (i == 0 ? up0 : A.up[i]) * k_next) / midp[i];
     const T dy = y_hi - y_lo;
     const T dxi = A.dx[i];
     sa[i * L] = k * dxi - dy;

@@ -254,11 +254,14 @@ struct Interp1DImpl final : Interp1DBase {
 
   // ---- build (CubicSpline::build, cubic_spline.rs:754-771) --------------------------------
   ndi_status build_spline(const ndi_interp1d_desc& d) {
-    if (d.lane_left_kind || d.lane_left_value || d.lane_right_kind || d.lane_right_value)
-      return fail(NDI_UNSUPPORTED,
-                  "BoundaryCondition::Individual (per-lane boundaries) is not on the device path yet");
+    const bool per_lane = d.lane_left_kind || d.lane_left_value || d.lane_right_kind || d.lane_right_value;
+    if (per_lane) {
+      if (!(d.lane_left_kind && d.lane_left_value && d.lane_right_kind && d.lane_right_value))
+        return fail(NDI_BAD_ARG, "BoundaryCondition::Individual needs all four lane_* arrays");
+      if (d.periodic) return fail(NDI_BAD_ARG, "Periodic cannot be combined with per-lane boundaries");
+      return build_spline_individual(d);
+    }
     const bool periodic = d.periodic != 0;
-    if (periodic && n == 3) { /* closed form */ }
     SplinePlan<T> P = make_spline_plan<T>(pyr.host_knots.data(), n, periodic, d.left.kind,
                                           d.left.value, d.right.kind, d.right.value);
     const size_t tab = (size_t)(n - 1) * lanes * sizeof(T);
@@ -308,7 +311,7 @@ struct Interp1DImpl final : Interp1DBase {
     hipStream_t s = nullptr;
     switch (P.mode) {
       case SPLINE_GENERAL:
-        hipLaunchKernelGGL(spline_build_general_kernel<T>, dim3(grid), dim3(64), 0, s, A);
+        hipLaunchKernelGGL((spline_build_general_kernel<T, false>), dim3(grid), dim3(64), 0, s, A);
         break;
       case SPLINE_PARABOLA3:
         hipLaunchKernelGGL(spline_build_n3_kernel<T>, dim3(grid), dim3(64), 0, s, A, 0);
@@ -329,6 +332,80 @@ struct Interp1DImpl final : Interp1DBase {
                   "(%llu lane(s) differ)", hs.periodic_mismatch);
     // Extrapolate::{No,Yes,Periodic}, cubic_spline.rs:763-769
     if (mode != EX_NO && periodic) mode = EX_PERIODIC;
+    return NDI_OK;
+  }
+
+  // BoundaryCondition::Individual (cubic_spline.rs:332-347 + solve_for_k_individual :370-403): one scalar
+  // solve per trailing element in the reference; here every lane picks its end kinds / values and one of
+  // the precomputed elimination plans (4 left kinds x 4 right kinds, kind 3 = the n == 3 parabola rows).
+  ndi_status build_spline_individual(const ndi_interp1d_desc& d) {
+    const T* x = pyr.host_knots.data();
+    std::vector<uint8_t> cls(lanes);
+    std::vector<T> lval(lanes), rval(lanes);
+    for (uint64_t l = 0; l < lanes; ++l) {
+      int lk, rk;
+      double lv, rv;
+      specialize_end(d.lane_left_kind[l], d.lane_left_value[l], lk, lv);
+      specialize_end(d.lane_right_kind[l], d.lane_right_value[l], rk, rv);
+      if (n == 3 && lk == END_NOT_A_KNOT && rk == END_NOT_A_KNOT) lk = rk = 3;  // :569-596
+      cls[l] = (uint8_t)(lk | (rk << 2));
+      lval[l] = T(lv);
+      rval[l] = T(rv);
+    }
+    static const int to_ndi[3] = {NDI_BC_NOT_A_KNOT, NDI_BC_FIRST_DERIV, NDI_BC_SECOND_DERIV};
+    std::vector<T> w4(4 * n, T(0)), midp4(4 * n, T(1)), up0_4(4, T(0)), wl(16, T(0)), midl(16, T(1));
+    SplinePlan<T> ref;
+    for (int lk = 0; lk < 3; ++lk)
+      for (int rk = 0; rk < 3; ++rk) {
+        SplinePlan<T> P = make_spline_plan<T>(x, n, false, to_ndi[lk], 0.0, to_ndi[rk], 0.0);
+        int a = lk, b = rk;
+        if (P.mode == SPLINE_PARABOLA3) a = b = 3;
+        for (uint64_t i = 0; i + 1 < n; ++i) {
+          w4[a * n + i] = P.w[i];
+          midp4[a * n + i] = P.midp[i];
+        }
+        up0_4[a] = P.up[0];
+        wl[a * 4 + b] = P.w[n - 1];
+        midl[a * 4 + b] = P.midp[n - 1];
+        if (lk == 2 && rk == 2) ref = P;  // a general-mode plan: shared dx / interior up / not-a-knot scalars
+        if (P.mode != SPLINE_PARABOLA3 && lk == 0) { ref.nkL_tmp1 = P.nkL_tmp1; ref.nkL_d = P.nkL_d; }
+        if (P.mode != SPLINE_PARABOLA3 && rk == 0) { ref.nkR_tmp1 = P.nkR_tmp1; ref.nkR_d = P.nkR_d; }
+      }
+    {  // not-a-knot row scalars depend on x only; take them from plans that have them (n == 3 included)
+      SplinePlan<T> PL = make_spline_plan<T>(x, n, false, NDI_BC_NOT_A_KNOT, 0.0, NDI_BC_FIRST_DERIV, 0.0);
+      SplinePlan<T> PR = make_spline_plan<T>(x, n, false, NDI_BC_FIRST_DERIV, 0.0, NDI_BC_NOT_A_KNOT, 0.0);
+      ref.nkL_tmp1 = PL.nkL_tmp1; ref.nkL_d = PL.nkL_d;
+      ref.nkR_tmp1 = PR.nkR_tmp1; ref.nkR_d = PR.nkR_d;
+    }
+    const size_t tab = (size_t)(n - 1) * lanes * sizeof(T);
+    ca.reserve(tab);
+    cb.reserve(tab);
+    std::vector<T> pack;
+    auto put = [&pack](const std::vector<T>& v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); return o; };
+    const size_t o_dx = put(ref.dx), o_up = put(ref.up), o_w4 = put(w4), o_m4 = put(midp4), o_u0 = put(up0_4),
+                 o_wl = put(wl), o_ml = put(midl), o_lv = put(lval), o_rv = put(rval);
+    DevBuf plan, dcls;
+    plan.reserve(pack.size() * sizeof(T));
+    NDI_HIP(hipMemcpy(plan.p, pack.data(), pack.size() * sizeof(T), hipMemcpyHostToDevice));
+    dcls.reserve(lanes);
+    NDI_HIP(hipMemcpy(dcls.p, cls.data(), lanes, hipMemcpyHostToDevice));
+    BuildArgs<T> A{};
+    A.data = data.as<T>();
+    A.ca = ca.as<T>();
+    A.cb = cb.as<T>();
+    const T* base = plan.as<T>();
+    A.dx = base + o_dx; A.up = base + o_up; A.w = base + o_w4; A.midp = base + o_m4;
+    A.w4 = base + o_w4; A.midp4 = base + o_m4; A.up0_4 = base + o_u0; A.wl = base + o_wl; A.midl = base + o_ml;
+    A.lane_lval = base + o_lv; A.lane_rval = base + o_rv;
+    A.lane_cls = dcls.as<uint8_t>();
+    A.n = n;
+    A.lanes = lanes;
+    A.nkL_tmp1 = ref.nkL_tmp1; A.nkL_d = ref.nkL_d; A.nkR_tmp1 = ref.nkR_tmp1; A.nkR_d = ref.nkR_d;
+    A.dx0_sq = ref.dx0_sq; A.dxl_sq = ref.dxl_sq;
+    hipLaunchKernelGGL((spline_build_general_kernel<T, true>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0,
+                       (hipStream_t) nullptr, A);
+    NDI_HIP(hipGetLastError());
+    NDI_HIP(hipDeviceSynchronize());
     return NDI_OK;
   }
 

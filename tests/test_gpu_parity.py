@@ -71,12 +71,7 @@ def test_reference_cubic_vectors(pkg, refvec):
         dt = DT[case["dtype"]]
         x = np.array(case["x"], dtype=dt); data = np.array(case["data"], dtype=dt)
         strat = pkg.CubicSpline.new().extrapolate(case["extrapolate"]).boundary(_bc_from_case(pkg, case))
-        try:
-            interp = pkg.Interp1DBuilder.new(data).x(x).strategy(strat).build()
-        except pkg.DeviceError as e:
-            if "per_lane" in case and "Individual" in str(e):
-                pytest.xfail("BoundaryCondition::Individual with distinct rows is SURVEY 8(f) rank 2 (next)")
-            raise
+        interp = pkg.Interp1DBuilder.new(data).x(x).strategy(strat).build()
         res = interp.interp_array(np.array(case["q"], dtype=dt))
         assert_rel(res, np.array(case["expect"]), case["atol"], case["rtol"], case["name"])
 
@@ -223,6 +218,42 @@ def test_spline_coefficients_bit_exact(pkg, dt, n, L):
         assert st == oracle.OK
         check_equal(a, ra, f"a[{name}] n={n} L={L} {np.dtype(dt)}")
         check_equal(b, rb, f"b[{name}] n={n} L={L} {np.dtype(dt)}")
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("n,shape", [(3, (7,)), (3, (70,)), (4, (5,)), (12, (3, 4)), (257, (130,)), (1024, (2, 3, 5))])
+def test_individual_boundaries_bit_exact(pkg, dt, n, shape):
+    """BoundaryCondition::Individual (cubic_spline.rs:332-347, 370-403): every trailing element has its own
+    RowBoundary; the device solve must equal one scalar solve per column (what the oracle does)."""
+    rng = np.random.default_rng(n * 31 + len(shape))
+    L = int(np.prod(shape))
+    x = knots("jit", n, rng, dt) if n > 3 else np.array([-1.0, 0.0, 3.0], dtype=dt)
+    y = rng.uniform(0.0, 1.0, (n,) + shape).astype(dt)
+    S, R, B = pkg.SingleBoundary, pkg.RowBoundary, pkg.BoundaryCondition
+    lk = rng.integers(0, 5, L); rk = rng.integers(0, 5, L)
+    if n == 3:
+        lk[:3] = 0; rk[:3] = 0          # some NotAKnot/NotAKnot columns -> parabola rows (:569-596)
+    lv = np.where(lk >= 3, rng.uniform(-1, 1, L), 0.0); rv = np.where(rk >= 3, rng.uniform(-1, 1, L), 0.0)
+    def single(kind, val):
+        return {0: S.NotAKnot, 1: S.Natural, 2: S.Clamped}.get(int(kind)) or \
+            (S.FirstDeriv(val) if kind == 3 else S.SecondDeriv(val))
+    rows = np.empty(L, dtype=object)
+    for i in range(L):
+        # exercise the shorthand rows too
+        if lk[i] == rk[i] and lk[i] < 3:
+            rows[i] = [R.NotAKnot, R.Natural, R.Clamped][lk[i]]
+        else:
+            rows[i] = R.Mixed(single(lk[i], lv[i]), single(rk[i], rv[i]))
+    strat = pkg.CubicSpline.new().extrapolate(True).boundary(B.Individual(rows.reshape((1,) + shape)))
+    interp = pkg.Interp1DBuilder.new(y).x(x).strategy(strat).build()
+    a, b = interp.strategy.coefficients()
+    st, ra, rb = oracle.cubic_build(x, y, per_lane=(lk, lv, rk, rv))
+    assert st == oracle.OK
+    check_equal(a, ra, f"a individual n={n}")
+    check_equal(b, rb, f"b individual n={n}")
+    q = rng.uniform(x[0] - 0.1, x[-1] + 0.1, 300).astype(dt)
+    _, _, ref = oracle.interp1d_cubic(x, y, ra, rb, q, oracle.EXTRAPOLATE_YES)
+    check_equal(interp.interp_array(q).reshape(300, L), ref, "eval individual")
 
 
 def test_periodic_value_error(pkg):

@@ -94,10 +94,21 @@ using lds_ptr = const __attribute__((address_space(3))) T*;  // explicit LDS poi
 template <class T>
 using PyramidLds = PyramidT<T, lds_ptr<T>>;
 
+// Cross-lane gather of a register value (ds_bpermute: the LDS crossbar, no memory access).
+__device__ __forceinline__ float lane_gather(float v, uint32_t src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double lane_gather(double v, uint32_t src_lane) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // Number of knots <= x, one query per lane, wavefront-cooperative:
-//  * top pyramid level (<= 64 entries): every lane holds one entry in a register; the entries are
-//    broadcast one after the other (v_readlane) and each lane counts against its own query --
-//    64 queries are ranked against the whole level with no memory access at all;
+//  * top pyramid level (<= 64 entries): the wave holds the level in registers, one entry per lane, and
+//    every lane bisects over it with cross-lane gathers (ds_bpermute) -- 64 queries are ranked against
+//    the whole level in 7 exchange steps with no memory access at all;
 //  * each lower level: the 64-entry block selected by the level above is searched by the lane itself
 //    with a 6-step branch-free bisection in LDS (the block's first entry is known to be <= x).
 // NaN compares false everywhere -> 0.
@@ -118,12 +129,19 @@ template <class T, class PTR>
 __device__ __forceinline__ uint32_t wave_count_le(const PyramidT<T, PTR>& P, T x, uint32_t lane) {
   const PTR top = P.levels == 3 ? P.lv2 : (P.levels == 2 ? P.lv1 : P.lv0);
   const uint32_t ntop = P.levels == 3 ? P.n2 : (P.levels == 2 ? P.n1 : P.n);
-  const T mine = top[lane < ntop ? lane : ntop - 1];
-  uint32_t c = 0;
-#pragma unroll 8
-  for (uint32_t j = 0; j < ntop; ++j) c += (readlane_t(mine, (int)j) <= x) ? 1u : 0u;
-  if (P.levels == 1 || c == 0) return c;
-  uint32_t i = c - 1;  // index (within the level just searched) of the last entry <= x
+  const uint32_t last = ntop - 1u;
+  const T mine = top[lane < last ? lane : last];   // lane j holds entry j of the top level
+  const bool any = lane_gather(mine, 0u) <= x;
+  uint32_t lo = 0;  // invariant (when any): top[lo] <= x
+#pragma unroll
+  for (uint32_t step = 32; step >= 1; step >>= 1) {
+    const uint32_t probe = lo + step;
+    const T v = lane_gather(mine, probe < last ? probe : last);
+    lo = (probe <= last && v <= x) ? probe : lo;
+  }
+  if (!any) return 0;
+  if (P.levels == 1) return lo + 1u;
+  uint32_t i = lo;  // index (within the level just searched) of the last entry <= x
   if (P.levels == 3) {
     const uint32_t base = i * 64u;
     const uint32_t len = (P.n1 - base < 64u) ? P.n1 - base : 64u;
@@ -162,10 +180,14 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
   const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
   uint64_t q_end = q_begin + A.slice;
   if (q_end > A.nq) q_end = A.nq;
-  for (uint64_t base = q_begin + (uint64_t)(tid >> 6) * 64u; base < q_end; base += BLOCK) {
+  // software-pipelined: the next batch's queries are requested before the current batch is searched
+  const uint64_t first = q_begin + (uint64_t)(tid >> 6) * 64u;
+  T x_next = (first + lane < q_end) ? A.q[first + lane] : k0;
+  for (uint64_t base = first; base < q_end; base += BLOCK) {
     const uint64_t qi = base + lane;
     const bool active = qi < q_end;
-    const T x = active ? A.q[qi] : k0;
+    const T x = x_next;
+    x_next = (qi + BLOCK < q_end) ? A.q[qi + BLOCK] : k0;
     const bool inr = (k0 <= x) && (x <= kn);   // Interp1D::is_in_range, interp1d/mod.rs:384-386
     T xs = x;
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;

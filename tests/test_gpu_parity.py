@@ -548,3 +548,57 @@ def test_full_size_c3_bilinear(pkg):
     assert np.array_equal(out[torch.as_tensor(pick, device=dev)].cpu().numpy(), ref)
     # convexity: every value lies within the range of its four corners' channel values (here [0, 1))
     assert float(out.min()) >= -1e-6 and float(out.max()) <= 1.0 + 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# host-buffer streaming mode and re-entrancy
+# ------------------------------------------------------------------------------------------------
+def test_host_output_is_streamed_in_chunks(pkg):
+    """out_memspace = HOST: the batch goes through a 256 MiB device staging buffer in query chunks
+    (8192 rows of 32 KiB here); first-error index and untouched rows must survive the chunking."""
+    rng = np.random.default_rng(8)
+    n, L, Q = 50, 4096, 20000           # 3 chunks
+    x = knots("rand", n, rng, np.float64); y = rng.uniform(0, 1, (n, L)); q = rng.uniform(x[0], x[-1], Q)
+    interp = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new()).build()
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+    assert np.array_equal(interp.interp_array(q), ref)
+    q[13000] = 7.0                       # inside the second chunk
+    buf = np.full((Q, L), -2.0)
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        interp.interp_array_into(q, buf)
+    assert ei.value.index == 13000 and ei.value.value == 7.0
+    assert np.array_equal(buf[:13000], ref[:13000]) and np.all(buf[13000:] == -2.0)
+    # 2-D
+    g = rng.uniform(0, 1, (20, 30, 2048)); qx = rng.uniform(0, 19, 40000); qy = rng.uniform(0, 29, 40000)
+    it = pkg.Interp2D.builder(g).build()
+    _, _, _, ref2 = oracle.interp2d_bilinear(np.arange(20.0), np.arange(30.0), g, qx, qy)
+    assert np.array_equal(it.interp_array(qx, qy), ref2)
+
+
+def test_eval_is_reentrant_across_host_threads(pkg):
+    """Query methods take &self and the reference's benches call one interpolator from many rayon workers
+    (benches/bench_interp1d.rs:54-78): concurrent evaluations on one handle must not interfere."""
+    import threading
+    rng = np.random.default_rng(12)
+    n, L = 200, 1024
+    x = knots("rand", n, rng, np.float64); y = rng.uniform(0, 1, (n, L))
+    interp = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new()).build()
+    st, a, b = oracle.cubic_build(x, y)
+    qs = [rng.uniform(x[0], x[-1], 3000 + 500 * i) for i in range(6)]
+    refs = [oracle.interp1d_cubic(x, y, a, b, q)[2] for q in qs]
+    outs = [None] * 6
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                outs[i] = interp.interp_array(qs[i])
+                assert np.array_equal(outs[i], refs[i])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs

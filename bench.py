@@ -85,6 +85,7 @@ def extra_workload(args, pkg, torch, dev, rank, world):
         y = np.unique(rng.uniform(0, 1, 2 * ny).astype(np.float32))[:ny]
         g = torch.rand((nx, ny, C), dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
         interp = pkg.Interp2DBuilder.new(g).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
+        interp.strategy.path = {"auto": pkg.PATH_AUTO, "gather": pkg.PATH_GATHER, "bucketed": pkg.PATH_BUCKETED}[args.path]
         qx = torch.as_tensor(np.random.default_rng(123).uniform(x[0], x[-1], nq).astype(np.float32), device=dev)
         qy = torch.as_tensor(np.random.default_rng(96).uniform(y[0], y[-1], nq).astype(np.float32), device=dev)
         out = torch.empty((nq, C), dtype=torch.float32, device=dev)

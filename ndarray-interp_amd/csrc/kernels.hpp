@@ -567,7 +567,56 @@ struct Eval2Args {
   T* out;
   uint64_t ny, lanes, out_stride, nq;
   const StatusBlock* status;
+  // tile-grouped order (nullptr: query order): per grouped position the query's record
+  const uint4* rec_i;    // {query index, xi, yi, 0}
+  const T* rec_q;        // {qx, qy} pairs
 };
+
+// 2-D grouping key: the tile (2^sx x 2^sy cells) a query's cell falls in.  One workgroup per contiguous
+// query slice; leaves the keys and the slice's tile histogram (same layout as locate_kernel's).
+__global__ __launch_bounds__(BLOCK) void tile_hist_kernel(const uint32_t* xi, const uint32_t* yi, uint64_t nq,
+                                                          uint64_t slice, uint32_t sx, uint32_t sy, uint32_t nty,
+                                                          uint32_t nb, uint32_t* key, uint32_t* hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem_raw);
+  for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) s_hist[i] = 0u;
+  __syncthreads();
+  const uint64_t q_begin = (uint64_t)blockIdx.x * slice;
+  uint64_t q_end = q_begin + slice;
+  if (q_end > nq) q_end = nq;
+  for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += BLOCK) {
+    const uint32_t k = (xi[qi] >> sx) * nty + (yi[qi] >> sy);
+    key[qi] = k;
+    atomicAdd(&s_hist[k], 1u);
+  }
+  __syncthreads();
+  uint32_t* dst = hist + (uint64_t)blockIdx.x * nb;
+  for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) dst[i] = s_hist[i];
+}
+
+// Places every query's record at its tile-grouped position (block-local cursors in LDS, see
+// group_scatter_kernel): sequential reads in query order, one 16-byte and one 2*sizeof(T) write per query.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void group_scatter2d_kernel(const uint32_t* key, const uint32_t* xi,
+                                                                const uint32_t* yi, const T* qx, const T* qy,
+                                                                uint64_t nq, uint64_t slice,
+                                                                const uint32_t* slice_off, const uint32_t* base,
+                                                                uint32_t nb, uint4* rec_i, T* rec_q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem_raw);
+  const uint32_t* off = slice_off + (uint64_t)blockIdx.x * nb;
+  for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) cur[i] = off[i] + base[i];
+  __syncthreads();
+  const uint64_t q_begin = (uint64_t)blockIdx.x * slice;
+  uint64_t q_end = q_begin + slice;
+  if (q_end > nq) q_end = nq;
+  for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += BLOCK) {
+    const uint32_t pos = atomicAdd(&cur[key[qi]], 1u);
+    rec_i[pos] = make_uint4((uint32_t)qi, xi[qi], yi[qi], 0u);
+    rec_q[2 * (uint64_t)pos] = qx[qi];
+    rec_q[2 * (uint64_t)pos + 1] = qy[qi];
+  }
+}
 
 template <class T, class V>
 __device__ __forceinline__ V frac_v(T x1, V y1, T x2, V y2, T x) {
@@ -582,17 +631,33 @@ __global__ __launch_bounds__(BLOCK) void eval_bilinear_kernel(Eval2Args<T> A, ui
   unsigned long long limit = A.status->first_fail[0];
   if (A.status->first_fail[1] < limit) limit = A.status->first_fail[1];
   if (limit > A.nq) limit = A.nq;
-  const uint64_t ntiles = (limit + tile_q - 1) / tile_q;
+  // grouped order covers every query (rows at/after the first failure are skipped one by one)
+  const uint64_t span = A.rec_i ? A.nq : limit;
+  const uint64_t ntiles = (span + tile_q - 1) / tile_q;
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint64_t q0 = tile * tile_q;
-    const uint32_t nq_here = (limit - q0 < tile_q) ? (uint32_t)(limit - q0) : tile_q;
+    const uint32_t nq_here = (span - q0 < tile_q) ? (uint32_t)(span - q0) : tile_q;
     const uint32_t items = nq_here * LV;
     for (uint32_t it = threadIdx.x; it < items; it += BLOCK) {
       const uint32_t ql = it / LV;
       const uint32_t v = it - ql * LV;
-      const uint64_t qi = q0 + ql;
-      const uint32_t xi = A.xi[qi], yi = A.yi[qi];
-      const T x = A.qx[qi], y = A.qy[qi];
+      uint64_t qi = q0 + ql;
+      uint32_t xi, yi;
+      T x, y;
+      if (A.rec_i) {
+        const uint4 r = A.rec_i[qi];
+        x = A.rec_q[2 * qi];
+        y = A.rec_q[2 * qi + 1];
+        qi = r.x;
+        xi = r.y;
+        yi = r.z;
+        if (qi >= limit) continue;
+      } else {
+        xi = A.xi[qi];
+        yi = A.yi[qi];
+        x = A.qx[qi];
+        y = A.qy[qi];
+      }
       const T x1 = A.xk[xi], x2 = A.xk[xi + 1];
       const T y1 = A.yk[yi], y2 = A.yk[yi + 1];
       const V* z11 = reinterpret_cast<const V*>(A.data + ((uint64_t)xi * A.ny + yi) * A.lanes);

@@ -700,7 +700,7 @@ struct Interp2DImpl final : Interp2DBase {
   }
 
   void enqueue(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t nq, T* out,
-               uint64_t out_stride) {
+               uint64_t out_stride, int path) {
     ws.idx.reserve(nq * sizeof(uint32_t));
     ws.idx2.reserve(nq * sizeof(uint32_t));
     reset_status(ws, s);
@@ -721,7 +721,60 @@ struct Interp2DImpl final : Interp2DBase {
     A.out_stride = out_stride;
     A.nq = nq;
     A.status = st;
-    g_last_path.store(NDI_PATH_GATHER);
+    A.rec_i = nullptr;
+    A.rec_q = nullptr;
+
+    // BUCKETED for 2-D = tile grouping: queries are ordered by the tile of cells they fall in, so the
+    // corner rows of a tile are fetched from HBM once and re-served by L2 / Infinity Cache.  Measured on
+    // C3: the evaluation gets 17 % faster but placing the grouped records costs more
+    // than that, and the kernel is partly VALU-bound (12 IEEE divisions per output vector), so AUTO
+    // keeps the gather order; the grouped order stays available as an explicit choice.
+    bool tiled = false;
+    if (path == NDI_PATH_BUCKETED) tiled = nq >= 2 && nq < 0xffffffffull;
+    uint32_t sx = 5, sy = 5;   // 32 x 32 cells per tile, grown until the histogram fits LDS
+    auto tiles = [&](uint32_t cells, uint32_t sh) { return (uint32_t)(((uint64_t)cells + (1u << sh) - 1) >> sh); };
+    while ((uint64_t)tiles((uint32_t)nx - 1, sx) * tiles((uint32_t)ny - 1, sy) > GROUP_MAX_BINS) {
+      if (sx <= sy) ++sx; else ++sy;
+    }
+    g_last_path.store(tiled ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
+    if (tiled) {
+      const uint32_t nty = tiles((uint32_t)ny - 1, sy);
+      const uint32_t nb = tiles((uint32_t)nx - 1, sx) * nty;
+      uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 4095) / 4096, GROUP_MAX_BLOCKS));
+      uint64_t slice = (nq + blocks - 1) / blocks;
+      slice = (slice + BLOCK - 1) / BLOCK * BLOCK;
+      blocks = (nq + slice - 1) / slice;
+      ws.t.reserve(nq * sizeof(uint32_t));      // keys
+      ws.perm.reserve(nq * sizeof(uint4));            // grouped records {qi, xi, yi}
+      ws.qdev2.reserve(0);
+      ws.stage[1].reserve(nq * 2 * sizeof(T));        // grouped {qx, qy}
+      ws.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
+      ws.counts.reserve((size_t)nb * sizeof(uint32_t));
+      ws.cursor.reserve((size_t)nb * sizeof(uint32_t));
+      static std::once_flag once;
+      std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&group_scatter2d_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GROUP_MAX_BINS * 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_hist_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GROUP_MAX_BINS * 4));
+      });
+      ProfScope ps(s, PC_GROUP);
+      hipLaunchKernelGGL(tile_hist_kernel, dim3((unsigned)blocks), dim3(BLOCK), (size_t)nb * 4, s,
+                         (const uint32_t*)A.xi, (const uint32_t*)A.yi, nq, slice, sx, sy, nty, nb,
+                         ws.t.as<uint32_t>(), ws.hist.as<uint32_t>());
+      hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
+                         ws.hist.as<uint32_t>(), (uint32_t)blocks, nb, ws.counts.as<uint32_t>());
+      hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
+                         ws.cursor.as<uint32_t>(), st);
+      hipLaunchKernelGGL(group_scatter2d_kernel<T>, dim3((unsigned)blocks), dim3(BLOCK), (size_t)nb * 4, s,
+                         (const uint32_t*)ws.t.as<uint32_t>(), (const uint32_t*)A.xi, (const uint32_t*)A.yi, qx, qy,
+                         nq, slice, (const uint32_t*)ws.hist.as<uint32_t>(),
+                         (const uint32_t*)ws.cursor.as<uint32_t>(), nb, ws.perm.as<uint4>(), ws.stage[1].as<T>());
+      NDI_HIP(hipGetLastError());
+      ps.done();
+      A.rec_i = ws.perm.as<uint4>();
+      A.rec_q = ws.stage[1].as<T>();
+    }
     constexpr int VN = Wide<T>::N;
     const bool vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
     const uint64_t LV = vec_ok ? lanes / VN : lanes;
@@ -788,7 +841,7 @@ struct Interp2DImpl final : Interp2DBase {
     ws.last_q_space = o.q_memspace;
     ws.last_nq = nq;
     if (o.out_memspace == NDI_MEM_DEVICE) {
-      enqueue(s, ws, qx, qy, nq, (T*)out_, out_stride);
+      enqueue(s, ws, qx, qy, nq, (T*)out_, out_stride, o.path);
       ws.pending = true;
       if (o.async_launch) return NDI_OK;
       return collect(s, ws, 0, info);
@@ -798,7 +851,7 @@ struct Interp2DImpl final : Interp2DBase {
     ws.stage[0].reserve(chunk_q * row_bytes);
     for (uint64_t off = 0; off < nq; off += chunk_q) {
       const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
-      enqueue(s, ws, qx + off, qy + off, cq, ws.stage[0].as<T>(), lanes);
+      enqueue(s, ws, qx + off, qy + off, cq, ws.stage[0].as<T>(), lanes, o.path);
       ws.last_q = (const T*)qx_ + off;
       ws.last_q2 = (const T*)qy_ + off;
       NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));

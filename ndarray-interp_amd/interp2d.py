@@ -44,6 +44,7 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
     as in the reference (`type FinishedStrat = Self`, :43)."""
 
     MINIMUM_DATA_LENGHT = 2  # bilinear.rs:41
+    path = _capi.PATH_AUTO   # evaluation formulation (ndi_path): BUCKETED = tile-grouped query order
 
     def __init__(self):
         self._extrapolate = False
@@ -112,6 +113,7 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
             raise TypeError("xs and ys must live in the same memory space")
         opts = _capi.EvalOpts()
         opts.q_memspace = qx.memspace
+        opts.path = self.path
         opts.async_launch = int(bool(async_launch))
         if is_torch(out2d):
             if not out2d.is_cuda:

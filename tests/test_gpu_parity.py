@@ -451,13 +451,17 @@ def test_bilinear_bit_exact(pkg, dt, nx, ny, C, Q):
     qx[:2] = [x[0], x[-1]]; qy[:2] = [y[-1], y[0]]
     interp = pkg.Interp2DBuilder.new(g).x(x).y(y).build()
     _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy)
-    check_equal(interp.interp_array(qx, qy), ref, f"bilinear {nx}x{ny}x{C}")
+    for path in (pkg.PATH_GATHER, pkg.PATH_BUCKETED, pkg.PATH_AUTO):   # BUCKETED = tile-grouped query order
+        interp.strategy.path = path
+        check_equal(interp.interp_array(qx, qy), ref, f"bilinear {nx}x{ny}x{C} path={path}")
     # extrapolation
     ex = pkg.Interp2DBuilder.new(g).x(x).y(y).strategy(pkg.Bilinear.new().extrapolate(True)).build()
     sx, sy = x[-1] - x[0], y[-1] - y[0]
     qx2 = rng.uniform(x[0] - sx, x[-1] + sx, Q).astype(dt); qy2 = rng.uniform(y[0] - sy, y[-1] + sy, Q).astype(dt)
     _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx2, qy2, True)
-    check_equal(ex.interp_array(qx2, qy2), ref, f"bilinear extrapolate {nx}x{ny}x{C}")
+    for path in (pkg.PATH_GATHER, pkg.PATH_BUCKETED):
+        ex.strategy.path = path
+        check_equal(ex.interp_array(qx2, qy2), ref, f"bilinear extrapolate {nx}x{ny}x{C} path={path}")
 
 
 def test_bilinear_errors(pkg):
@@ -467,12 +471,14 @@ def test_bilinear_errors(pkg):
     qx = rng.uniform(0, 5, Q); qy = rng.uniform(0, 6, Q)
     qx[400] = 9.0; qy[400] = -1.0   # both out: x is reported (bilinear.rs:71-80)
     qy[650] = 11.0
-    buf = np.full((Q, 8), -3.0)
-    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
-        interp.interp_array_into(qx, qy, buf)
-    assert (ei.value.index, ei.value.axis, str(ei.value)) == (400, 0, "x = 9.0 is not in range")
     _, _, _, ref = oracle.interp2d_bilinear(np.arange(6.0), np.arange(7.0), g, qx[:400], qy[:400])
-    assert np.array_equal(buf[:400], ref) and np.all(buf[400:] == -3.0)
+    for path in (pkg.PATH_GATHER, pkg.PATH_BUCKETED):
+        interp.strategy.path = path
+        buf = np.full((Q, 8), -3.0)
+        with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+            interp.interp_array_into(qx, qy, buf)
+        assert (ei.value.index, ei.value.axis, str(ei.value)) == (400, 0, "x = 9.0 is not in range")
+        assert np.array_equal(buf[:400], ref) and np.all(buf[400:] == -3.0)
     qx[400] = 1.0
     with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
         interp.interp_array(qx, qy)
@@ -540,8 +546,13 @@ def test_full_size_c3_bilinear(pkg):
     qx = rng.uniform(0, nx - 1, Q).astype(np.float32); qy = rng.uniform(y[0], y[-1], Q).astype(np.float32)
     hx = rng.integers(0, nx - 1, 1000); hy = rng.integers(0, ny - 1, 1000)
     qx[:1000] = x[hx]; qy[:1000] = y[hy]              # grid points reproduce the grid values exactly
+    interp.strategy.path = pkg.PATH_GATHER
     out = interp.interp_array(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev))
     assert tuple(out.shape) == (Q, C)
+    interp.strategy.path = pkg.PATH_BUCKETED      # tile-grouped order: identical results on all 6.4e8 points
+    out_t = interp.interp_array(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev))
+    assert torch.equal(out, out_t)
+    del out_t
     assert np.array_equal(out[:1000].cpu().numpy(), g[hx, hy])
     pick = rng.integers(0, Q, 20000)
     _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx[pick], qy[pick])

@@ -68,3 +68,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in text and "import oracle" not in text and "oracle/" not in text, f
+
+
+def test_argument_validation_needs_no_device(pkg):
+    """BAD_ARG / builder errors that are decided before any device work behave the same with and without a GPU."""
+    import ctypes
+    lib = pkg._capi.lib()
+    h = ctypes.c_void_p()
+    assert lib.ndi_interp1d_create(None, ctypes.byref(h)) == pkg._capi.BAD_ARG
+    d = pkg._capi.Interp1DDesc()
+    d.dtype = 7
+    assert lib.ndi_interp1d_create(ctypes.byref(d), ctypes.byref(h)) == pkg._capi.BAD_ARG
+    assert "dtype" in pkg._capi.last_error()
+    # validate=1 with host axes: the reference's builder errors come back without touching a device
+    x = np.array([1.0, 2.0, 2.0]); y = np.array([1.0, 2.0, 3.0])
+    d = pkg._capi.Interp1DDesc()
+    d.dtype, d.strategy, d.n, d.lanes, d.x_len = pkg._capi.F64, pkg._capi.LINEAR, 3, 1, 3
+    d.x, d.data, d.memspace, d.validate = x.ctypes.data, y.ctypes.data, pkg._capi.MEM_HOST, 1
+    assert lib.ndi_interp1d_create(ctypes.byref(d), ctypes.byref(h)) == pkg._capi.MONOTONIC
+    assert "strictly monotonic rising" in pkg._capi.last_error()
+    d.x = None; d.n = 1; d.x_len = 1
+    assert lib.ndi_interp1d_create(ctypes.byref(d), ctypes.byref(h)) == pkg._capi.NOT_ENOUGH_DATA
+    assert lib.ndi_interp1d_eval(None, None, 0, None, 0, None, None) == pkg._capi.BAD_ARG
+    assert lib.ndi_interp2d_eval(None, None, None, 0, None, 0, None, None) == pkg._capi.BAD_ARG
+    assert lib.ndi_profile_read(None, 0) == pkg._capi.BAD_ARG

@@ -613,3 +613,40 @@ def test_eval_is_reentrant_across_host_threads(pkg):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs
+
+
+def test_raw_c_abi_contract(pkg):
+    """The C ABI used directly (as the Rust shim would): validate=1 create from host arrays, strided eval,
+    BAD_ARG on a short row stride, coefficients copy-out, destroy."""
+    import ctypes as C
+    cap = pkg._capi
+    lib = cap.lib()
+    rng = np.random.default_rng(2)
+    n, L, Q = 30, 8, 100
+    x = np.sort(rng.uniform(0, 1, n)); y = rng.uniform(0, 1, (n, L)); q = rng.uniform(x[0], x[-1], Q)
+    d = cap.Interp1DDesc()
+    d.dtype, d.strategy, d.extrapolate, d.device = cap.F64, cap.CUBIC_SPLINE, 0, 0
+    d.n, d.lanes, d.x_len = n, L, n
+    d.x, d.data, d.memspace, d.validate = x.ctypes.data, y.ctypes.data, cap.MEM_HOST, 1
+    d.left = cap.Boundary(cap.BC_NATURAL, 0.0); d.right = cap.Boundary(cap.BC_FIRST_DERIV, 0.25)
+    h = C.c_void_p()
+    assert lib.ndi_interp1d_create(C.byref(d), C.byref(h)) == cap.OK
+    a = np.empty((n - 1, L)); b = np.empty((n - 1, L))
+    assert lib.ndi_interp1d_coefficients(h, a.ctypes.data, b.ctypes.data, cap.MEM_HOST) == cap.OK
+    st, ra, rb = oracle.cubic_build(x, y, left=(1, 0.0), right=(3, 0.25))
+    assert np.array_equal(a, ra) and np.array_equal(b, rb)
+    out = np.full((Q, L + 3), -9.0)
+    info = cap.OobInfo()
+    opts = cap.EvalOpts()   # host queries, host output, default stream, AUTO
+    assert lib.ndi_interp1d_eval(h, q.ctypes.data, Q, out.ctypes.data, L + 3, C.byref(opts), C.byref(info)) == cap.OK
+    _, _, ref = oracle.interp1d_cubic(x, y, ra, rb, q)
+    assert np.array_equal(out[:, :L], ref) and np.all(out[:, L:] == -9.0)
+    assert lib.ndi_interp1d_eval(h, q.ctypes.data, Q, out.ctypes.data, L - 1, C.byref(opts), C.byref(info)) == cap.BAD_ARG
+    assert lib.ndi_interp1d_eval(h, q.ctypes.data, 0, out.ctypes.data, L, C.byref(opts), C.byref(info)) == cap.OK
+    q[5] = 3.0
+    assert lib.ndi_interp1d_eval(h, q.ctypes.data, Q, out.ctypes.data, L + 3, C.byref(opts), C.byref(info)) == cap.OUT_OF_BOUNDS
+    assert (info.index, info.value, info.axis, info.status) == (5, 3.0, 0, cap.OUT_OF_BOUNDS)
+    assert "x = 3 is not in range" in cap.last_error()
+    lib.ndi_interp1d_destroy(h)
+    d.device = 99
+    assert lib.ndi_interp1d_create(C.byref(d), C.byref(h)) == cap.BAD_ARG

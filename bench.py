@@ -92,16 +92,45 @@ def extra_workload(args, pkg, torch, dev, rank, world):
         step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
         points, alg = nq * C, nq * C * 20 + nq * 8
         name = f"C3: 2D Bilinear, {nx}x{ny} grid x {C} channels f32, {nq} queries"
-    else:                        # Linear on the C2 shape
+    elif args.workload == "c1":  # BASELINE configs[0]: 1D Linear, 1024 f64 knots (index axis), scalar data, 1e4 queries
+        import oracle
+        n, nq = 1024, 10_000
+        yv = rng.uniform(0, 1, n); q = np.random.default_rng(123).uniform(0, n - 1, nq)
+        x = np.arange(n, dtype=np.float64)
+        t0 = time.perf_counter(); reps = 2000
+        for _ in range(reps):
+            oracle.interp1d_linear(x, yv, q)
+        cpu_us = (time.perf_counter() - t0) / reps * 1e6
+        interp = pkg.Interp1DBuilder.new(yv).build()
+        res = interp.interp_array(q)
+        assert np.array_equal(res, oracle.interp1d_linear(x, yv, q)[2][:, 0])
+        t0 = time.perf_counter()
+        for _ in range(200):
+            interp.interp_array(q)          # host arrays in, host array out: includes H2D / D2H and the sync
+        gpu_us = (time.perf_counter() - t0) / 200 * 1e6
+        print(json.dumps({"workload": "C1: 1D Linear, 1024 knots, scalar f64 data, 1e4 queries (CPU-reference config)",
+                          "cpu_port_us_per_batch": round(cpu_us, 1), "cpu_port_Mpoints_s": round(nq / cpu_us, 1),
+                          "gpu_host_to_host_us_per_batch": round(gpu_us, 1), "gpu_Mpoints_s": round(nq / gpu_us, 1)}))
+        return
+    else:                        # Linear f64 / CubicSpline f32 on the C2 shape
         n = lanes = 4096; nq = args.queries
         x, yv, q = synth_c2(n, lanes, nq, rank)
-        interp = pkg.Interp1DBuilder.new(torch.as_tensor(yv, device=dev)).x(torch.as_tensor(x, device=dev)).build()
+        dt, tdt, strat = (np.float64, torch.float64, None) if args.workload == "c2-linear" else (np.float32, torch.float32, pkg.CubicSpline.new())
+        x = np.unique(x.astype(dt)); yv = yv[:x.size].astype(dt); n = x.size
+        q = np.clip(q.astype(dt), x[0], x[-1])
+        if args.sorted_queries:
+            q = np.sort(q)
+        b = pkg.Interp1DBuilder.new(torch.as_tensor(yv, device=dev)).x(torch.as_tensor(x, device=dev))
+        interp = (b.strategy(strat) if strat is not None else b).build()
         interp.strategy.path = {"auto": pkg.PATH_AUTO, "gather": pkg.PATH_GATHER, "bucketed": pkg.PATH_BUCKETED}[args.path]
         qd = torch.as_tensor(q, device=dev)
-        out = torch.empty((nq, lanes), dtype=torch.float64, device=dev)
+        out = torch.empty((nq, lanes), dtype=tdt, device=dev)
         step = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
-        points, alg = nq * lanes, nq * lanes * 24 + nq * 8
-        name = f"1D Linear, {n} knots x {lanes} lanes f64, {nq} queries"
+        el_b = np.dtype(dt).itemsize
+        points = nq * lanes
+        alg = nq * lanes * (3 if strat is None else 5) * el_b + nq * el_b
+        name = f"1D {'Linear' if strat is None else 'CubicSpline'}, {n} knots x {lanes} lanes {np.dtype(dt).name}, {nq} queries" + \
+            (" (sorted)" if args.sorted_queries else "")
     for _ in range(args.warmup):
         step()
     interp.strategy.finish()
@@ -131,7 +160,8 @@ def main():
     ap.add_argument("--queries", type=int, default=1_000_000, help="queries per GPU per step")
     ap.add_argument("--path", choices=["auto", "gather", "bucketed"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c3", "c2-linear"], default="c2",
+    ap.add_argument("--sorted-queries", action="store_true", help="extra: sort the queries (cache reuse in the gather order)")
+    ap.add_argument("--workload", choices=["c2", "c3", "c2-linear", "c2-f32", "c1"], default="c2",
                     help="c2 = headline (BASELINE configs[1]); c3 / c2-linear are extra measurements for DESIGN.md")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this GPU")
@@ -155,10 +185,13 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     pkg = load_package()
     if args.workload != "c2":
+        sys.path.insert(0, ROOT)
         return extra_workload(args, pkg, torch, dev, rank, world)
 
     n, lanes, nq = args.knots, args.lanes, args.queries
     x, y, q = synth_c2(n, lanes, nq, rank)
+    if args.sorted_queries:
+        q = np.sort(q)
     yd = torch.as_tensor(y, device=dev)
     xd = torch.as_tensor(x, device=dev)
     t0 = time.perf_counter()

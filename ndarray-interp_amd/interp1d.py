@@ -292,7 +292,29 @@ class CubicSpline(Interp1DStrategyBuilder):
         else:
             k = {"NotAKnot": _capi.BC_NOT_A_KNOT, "Natural": _capi.BC_NATURAL, "Clamped": _capi.BC_CLAMPED}[bc.tag]
             kw["left"] = kw["right"] = (k, 0.0)
-        return strat._create(x, data, **kw)
+        try:
+            return strat._create(x, data, **kw)
+        except BuilderError.ValueError as e:
+            raise BuilderError.ValueError(_periodic_mismatch_message(data)) from e
+
+
+def _rust_debug_row(row: np.ndarray) -> str:
+    """`{:?}` of an ndarray row view, as ndarray 0.17 prints a small 1-D array."""
+    from .errors import _rust_float
+    body = ", ".join(_rust_float(float(v)) for v in row.reshape(-1))
+    if row.ndim == 1:
+        return f"[{body}], shape=[{row.shape[0]}], strides=[1], layout=CFcf (0xf), const ndim=1"
+    return f"[{body}], shape={list(row.shape)}"
+
+
+def _periodic_mismatch_message(data) -> str:
+    """cubic_spline.rs:483-488 / 501-506: the two message forms of the periodic ValueError."""
+    from .errors import _rust_float
+    d = _host(data)
+    head = "for periodic boundary condition the first and last value must be equal. "
+    if d.ndim == 1:
+        return head + f"First: {_rust_float(float(d[0]))}, last: {_rust_float(float(d[-1]))}"
+    return head + f"First: {_rust_debug_row(d[0])}, last: {_rust_debug_row(d[-1])}"
 
 
 class CubicSplineStrategy(_DeviceStrategy1D):

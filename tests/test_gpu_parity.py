@@ -258,8 +258,13 @@ def test_individual_boundaries_bit_exact(pkg, dt, n, shape):
 
 def test_periodic_value_error(pkg):
     y = np.array([[0.5, 1.0], [0.0, 1.5], [0.5, 1.1]])
-    with pytest.raises(pkg.BuilderError.ValueError, match="first and last value must be equal"):
+    with pytest.raises(pkg.BuilderError.ValueError, match="first and last value must be equal") as ei:
         pkg.Interp1DBuilder.new(y).strategy(pkg.CubicSpline.new().boundary(pkg.BoundaryCondition.Periodic)).build()
+    # the text tests/cubic_spline_strat.rs:442-452 expects
+    assert "First: [0.5, 1.0], shape=[2], strides=[1], layout=CFcf (0xf), const ndim=1, last: [0.5, 1.1]" in str(ei.value)
+    with pytest.raises(pkg.BuilderError.ValueError, match="First: 1.0, last: 2.0"):
+        pkg.Interp1DBuilder.new(np.array([1.0, 0.0, 2.0])).strategy(
+            pkg.CubicSpline.new().boundary(pkg.BoundaryCondition.Periodic)).build()
     y4 = np.array([[0.5, 1.0], [0.0, 1.5], [0.2, 0.1], [0.5, 1.1]])
     with pytest.raises(pkg.BuilderError.ValueError):
         pkg.Interp1DBuilder.new(y4).strategy(pkg.CubicSpline.new().boundary(pkg.BoundaryCondition.Periodic)).build()

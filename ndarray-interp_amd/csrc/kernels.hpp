@@ -618,13 +618,17 @@ __global__ __launch_bounds__(BLOCK) void group_scatter2d_kernel(const uint32_t* 
   }
 }
 
-template <class T, class V>
+// APPROX exists only for the tuning harness (tools/tune_eval.hip: how much of the kernel is division cost);
+// the library instantiates the exact form.
+template <class T, class V, bool APPROX = false>
 __device__ __forceinline__ V frac_v(T x1, V y1, T x2, V y2, T x) {
-  V m = (y2 - y1) / (x2 - x1);  // Linear::calc_frac, linear.rs:33-35
+  V m;
+  if (APPROX) m = (y2 - y1) * (T(1) / (x2 - x1));
+  else m = (y2 - y1) / (x2 - x1);  // Linear::calc_frac, linear.rs:33-35
   return m * (x - x1) + y1;
 }
 
-template <class T, int VEC>
+template <class T, int VEC, bool APPROX = false>
 __global__ __launch_bounds__(BLOCK) void eval_bilinear_kernel(Eval2Args<T> A, uint32_t tile_q) {
   using V = typename VecT<T, VEC>::type;
   const uint32_t LV = (uint32_t)(A.lanes / VEC);
@@ -665,10 +669,10 @@ __global__ __launch_bounds__(BLOCK) void eval_bilinear_kernel(Eval2Args<T> A, ui
       const V* z21 = reinterpret_cast<const V*>(A.data + ((uint64_t)(xi + 1) * A.ny + yi) * A.lanes);
       const V* z22 = z21 + LV;                                    // (xi+1, yi+1)
       const V a11 = z11[v], a12 = z12[v], a21 = z21[v], a22 = z22[v];
-      const V z1 = frac_v<T, V>(x1, a11, x2, a21, x);
-      const V z2 = frac_v<T, V>(x1, a12, x2, a22, x);
+      const V z1 = frac_v<T, V, APPROX>(x1, a11, x2, a21, x);
+      const V z2 = frac_v<T, V, APPROX>(x1, a12, x2, a22, x);
       V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
-      o[v] = frac_v<T, V>(y1, z1, y2, z2, y);
+      o[v] = frac_v<T, V, APPROX>(y1, z1, y2, z2, y);
     }
   }
 }

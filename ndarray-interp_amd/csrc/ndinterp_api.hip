@@ -727,8 +727,7 @@ struct Interp2DImpl final : Interp2DBase {
     // BUCKETED for 2-D = tile grouping: queries are ordered by the tile of cells they fall in, so the
     // corner rows of a tile are fetched from HBM once and re-served by L2 / Infinity Cache.  Measured on
     // C3: the evaluation gets 17 % faster but placing the grouped records costs more
-    // than that, and the kernel is partly VALU-bound (12 IEEE divisions per output vector), so AUTO
-    // keeps the gather order; the grouped order stays available as an explicit choice.
+    // than that, so AUTO keeps the gather order; the grouped order stays available as an explicit choice.
     bool tiled = false;
     if (path == NDI_PATH_BUCKETED) tiled = nq >= 2 && nq < 0xffffffffull;
     uint32_t sx = 5, sy = 5;   // 32 x 32 cells per tile, grown until the histogram fits LDS

@@ -154,7 +154,8 @@ typedef struct ndi_eval_opts {
                            (hipStreamPerThread is accepted like any other handle) */
   int32_t path;         /* ndi_path */
   int32_t async_launch; /* != 0 (device out only): enqueue and return; fetch the batch
-                           status later with ndi_interp{1,2}d_finish on the same stream */
+                           status later with ndi_interp{1,2}d_finish on the same stream (from the
+                           same host thread); the query array(s) must stay valid until then */
 } ndi_eval_opts;
 
 /* ---- build ------------------------------------------------------------------ */

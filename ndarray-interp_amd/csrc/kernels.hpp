@@ -127,10 +127,21 @@ __device__ __forceinline__ uint32_t block_last_le(PTR blk, uint32_t len, T x) {
 
 template <class T, class PTR>
 __device__ __forceinline__ uint32_t wave_count_le(const PyramidT<T, PTR>& P, T x, uint32_t lane) {
-  const PTR top = P.levels == 3 ? P.lv2 : (P.levels == 2 ? P.lv1 : P.lv0);
-  const uint32_t ntop = P.levels == 3 ? P.n2 : (P.levels == 2 ? P.n1 : P.n);
-  const uint32_t last = ntop - 1u;
-  const T mine = top[lane < last ? lane : last];   // lane j holds entry j of the top level
+  // The level is selected with plain branches on the (wave-uniform) level count: a `?:` chain over the
+  // struct's pointer members makes the compiler spill the struct to scratch and index it at run time.
+  T mine;
+  uint32_t last;
+  if (P.levels == 3) {
+    last = P.n2 - 1u;
+    mine = P.lv2[lane < last ? lane : last];
+  } else if (P.levels == 2) {
+    last = P.n1 - 1u;
+    mine = P.lv1[lane < last ? lane : last];
+  } else {
+    last = P.n - 1u;
+    mine = P.lv0[lane < last ? lane : last];
+  }
+  // lane j holds entry j of the top level
   const bool any = lane_gather(mine, 0u) <= x;
   uint32_t lo = 0;  // invariant (when any): top[lo] <= x
 #pragma unroll
@@ -246,6 +257,71 @@ __global__ __launch_bounds__(BLOCK) void locate_kernel(LocateArgs<T> A) {
     __syncthreads();
     uint32_t* dst = A.hist + (uint64_t)blockIdx.x * A.nb;
     for (uint32_t i = tid; i < A.nb; i += BLOCK) dst[i] = s_hist[i];
+  }
+}
+
+// 2-D: both axes in one launch (two independent searches per lane hide each other's LDS latency, one
+// staging pass, one launch).  Requires both pyramids to fit LDS; otherwise locate_kernel runs once per axis.
+template <class T>
+struct Locate2Args {
+  Pyramid<T> px, py;
+  const T* qx;
+  const T* qy;
+  uint64_t nq;
+  uint32_t* xi;
+  uint32_t* yi;
+  unsigned long long* first_fail;  // [2]: x, y
+  int mode;
+  uint64_t slice;
+};
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void locate2_kernel(Locate2Args<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nxa = A.px.n + A.px.n1 + A.px.n2, nya = A.py.n + A.py.n1 + A.py.n2;
+  T* sx = reinterpret_cast<T*>(smem_raw);
+  T* sy = sx + nxa;
+  for (uint32_t i = tid; i < nxa; i += BLOCK) sx[i] = A.px.lv0[i];   // the three levels are one allocation
+  for (uint32_t i = tid; i < nya; i += BLOCK) sy[i] = A.py.lv0[i];
+  __syncthreads();
+  PyramidLds<T> PX, PY;
+  PX.lv0 = (lds_ptr<T>)(smem_raw);
+  PX.lv1 = PX.lv0 + A.px.n;
+  PX.lv2 = PX.lv1 + A.px.n1;
+  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels;
+  PY.lv0 = PX.lv0 + nxa;
+  PY.lv1 = PY.lv0 + A.py.n;
+  PY.lv2 = PY.lv1 + A.py.n1;
+  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels;
+  const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
+  const uint32_t lane = tid & 63u;
+  const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
+  uint64_t q_end = q_begin + A.slice;
+  if (q_end > A.nq) q_end = A.nq;
+  const uint64_t first = q_begin + (uint64_t)(tid >> 6) * 64u;
+  T x_next = (first + lane < q_end) ? A.qx[first + lane] : x0;
+  T y_next = (first + lane < q_end) ? A.qy[first + lane] : y0;
+  for (uint64_t base = first; base < q_end; base += BLOCK) {
+    const uint64_t qi = base + lane;
+    const bool active = qi < q_end;
+    const T x = x_next, y = y_next;
+    x_next = (qi + BLOCK < q_end) ? A.qx[qi + BLOCK] : x0;
+    y_next = (qi + BLOCK < q_end) ? A.qy[qi + BLOCK] : y0;
+    const uint32_t ubx = wave_count_le<T, lds_ptr<T>>(PX, x, lane);
+    const uint32_t uby = wave_count_le<T, lds_ptr<T>>(PY, y, lane);
+    if (!active) continue;
+    uint32_t ix = (ubx == 0) ? 0u : ubx - 1u;
+    if (ix > PX.n - 2u) ix = PX.n - 2u;
+    uint32_t iy = (uby == 0) ? 0u : uby - 1u;
+    if (iy > PY.n - 2u) iy = PY.n - 2u;
+    // Interp2D::is_in_x_range / is_in_y_range (interp2d/mod.rs:374-379); NaN handling as in locate_slice
+    const bool badx = (A.mode == EX_NO) ? !((x0 <= x) && (x <= xn)) : !(x == x);
+    const bool bady = (A.mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
+    if (badx) atomicMin(&A.first_fail[0], (unsigned long long)qi);
+    if (bady) atomicMin(&A.first_fail[1], (unsigned long long)qi);
+    A.xi[qi] = ix;
+    A.yi[qi] = iy;
   }
 }
 

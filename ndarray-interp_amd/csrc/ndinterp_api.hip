@@ -705,8 +705,29 @@ struct Interp2DImpl final : Interp2DBase {
     ws.idx2.reserve(nq * sizeof(uint32_t));
     reset_status(ws, s);
     StatusBlock* st = ws.status.as<StatusBlock>();
-    run_locate<T>(s, px, qx, nq, ws.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
-    run_locate<T>(s, py, qy, nq, ws.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);
+    const size_t both = ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15);
+    if (both <= LDS_STAGE_LIMIT) {   // both axes in one launch
+      Locate2Args<T> LA{};
+      LA.px = px.view; LA.py = py.view;
+      LA.qx = qx; LA.qy = qy; LA.nq = nq;
+      LA.xi = ws.idx.as<uint32_t>(); LA.yi = ws.idx2.as<uint32_t>();
+      LA.first_fail = &st->first_fail[0];
+      LA.mode = mode;
+      uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, 2048));
+      uint64_t slice = (nq + blocks - 1) / blocks;
+      slice = (slice + BLOCK - 1) / BLOCK * BLOCK;
+      blocks = (nq + slice - 1) / slice;
+      LA.slice = slice;
+      static std::once_flag once;
+      std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate2_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+      });
+      launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(BLOCK), both, locate2_kernel<T>, LA);
+    } else {
+      run_locate<T>(s, px, qx, nq, ws.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
+      run_locate<T>(s, py, qy, nq, ws.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);
+    }
     Eval2Args<T> A{};
     A.xk = px.view.lv0;
     A.yk = py.view.lv0;

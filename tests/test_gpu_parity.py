@@ -297,6 +297,25 @@ def test_cubic_eval_bit_exact(pkg, dt, n, L, Q):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("n,Q", [(10000, 60000), (20000, 50000), (70000, 30000)])
+def test_cubic_many_knots_grouping_variants(pkg, dt, n, Q):
+    """Grouping back ends of the bucketed formulation: 10000 knots = block-local sort with a large LDS
+    histogram next to the staged pyramid; 20000 = more intervals than the LDS histogram holds -> global-atomic
+    histogram + placement; 70000 = three pyramid levels read from global memory."""
+    rng = np.random.default_rng(n)
+    L = 512 if dt == np.float64 else 1024
+    x = knots("jit", n, rng, dt)
+    y = rng.uniform(0.0, 1.0, (n, L)).astype(dt)
+    q = rng.uniform(x[0], x[-1], Q).astype(dt)
+    interp = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new()).build()
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+    for path in (pkg.PATH_BUCKETED, pkg.PATH_GATHER):
+        interp.strategy.path = path
+        check_equal(interp.interp_array(q), ref, f"cubic n={n} path={path}")
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("n,L,Q", SHAPES_1D)
 def test_linear_eval_bit_exact(pkg, dt, n, L, Q):
     rng = np.random.default_rng(n * 104729 + L)

@@ -84,3 +84,66 @@ def test_two_rank_shards_equal_single_process(pkg):
 def test_two_rank_first_error_is_global_minimum(pkg):
     firsts, parts = _run("err")
     assert firsts == [5203, 5203]          # both ranks learn the reference's first failing index
+
+
+GPU_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["NDI_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NDI_ROOT"], "tests"))
+from conftest import load_product_package
+pkg = load_product_package()
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")                     # rehearsal: both ranks share the one GPU of the box
+rng = np.random.default_rng(1)
+n, L, Q = 64, 1024, 20011
+x = np.sort(rng.uniform(0, 1, n)); y = rng.uniform(0, 1, (n, L)); q = rng.uniform(x[0], x[-1], Q)
+if os.environ["NDI_CASE"] == "err":
+    q[15001] = 5.0; q[19000] = -3.0; q[400 + 10005] = 9.0
+interp = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
+    .strategy(pkg.CubicSpline.new()).build()     # tables replicated per rank
+qd = torch.as_tensor(q, device=dev)
+lo, hi = pkg.sharding.shard_bounds(Q, rank, world)
+out = torch.full((hi - lo, L), -1.0, dtype=torch.float64, device=dev)
+def evaluate(a, b):
+    interp.interp_array_into(qd[a:b], out)
+local, exc = pkg.sharding.eval_shard(evaluate, Q, rank, world)
+first = pkg.sharding.first_error_across_ranks(local)
+np.save(os.path.join(os.environ["NDI_OUT"], f"out{rank}.npy"), out.cpu().numpy())
+with open(os.path.join(os.environ["NDI_OUT"], f"first{rank}.txt"), "w") as f:
+    f.write(f"{first} {lo} {hi}")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ok", "err"])
+def test_two_ranks_through_the_device_path(pkg, case):
+    """The same sharding helpers driving the real device evaluation (two processes, gloo, one GPU shared)."""
+    import oracle
+    global WORKER
+    saved, WORKER = WORKER, GPU_WORKER
+    try:
+        firsts, parts = _run(case)
+    finally:
+        WORKER = saved
+    rng = np.random.default_rng(1)
+    n, L, Q = 64, 1024, 20011
+    x = np.sort(rng.uniform(0, 1, n)); y = rng.uniform(0, 1, (n, L)); q = rng.uniform(x[0], x[-1], Q)
+    st, a, b = oracle.cubic_build(x, y)
+    if case == "ok":
+        assert firsts == [pkg.sharding.NO_FAIL] * 2
+        _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+        assert np.array_equal(np.concatenate([p[2] for p in parts]), ref)
+    else:
+        assert firsts == [10405, 10405]
+        # rank 1's shard: rows before its local first error are written, later rows untouched
+        lo1 = parts[1][0]
+        _, _, ref = oracle.interp1d_cubic(x, y, a, b, q[lo1:10405])
+        assert np.array_equal(parts[1][2][:10405 - lo1], ref) and np.all(parts[1][2][10405 - lo1:] == -1.0)

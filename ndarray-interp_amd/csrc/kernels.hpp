@@ -577,7 +577,14 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
   unsigned long long limit = A.status->first_fail[0];  // ... and rows at or after the first failure are skipped
   if (limit > A.nq) limit = A.nq;
   const uint64_t nchunks = (n_valid + CQ - 1) / CQ;
-  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  // XCD-aware chunk order: workgroups b and b+8 share an XCD (and its L2), so XCD k walks the contiguous
+  // chunk range [k*per, (k+1)*per): neighbouring chunks belong to the same or adjacent intervals and
+  // re-use each other's operand rows from that L2 instead of fetching them once per XCD.
+  // (Placement is a speed heuristic only -- any mapping gives the same result.)
+  const uint64_t per = (nchunks + 7) / 8;
+  for (uint64_t vb = blockIdx.x; vb < per * 8; vb += gridDim.x) {
+    const uint64_t chunk = (vb & 7u) * per + (vb >> 3);
+    if ((vb >> 3) >= per || chunk >= nchunks) continue;
     const uint64_t p0 = chunk * CQ;
     const uint32_t cnt = (n_valid - p0 < (uint64_t)CQ) ? (uint32_t)(n_valid - p0) : (uint32_t)CQ;
     __syncthreads();

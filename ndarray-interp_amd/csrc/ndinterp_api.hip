@@ -488,7 +488,9 @@ struct Interp1DImpl final : Interp1DBase {
       constexpr int CQ = 128;
       const int U = LV >= 2048 ? 8 : (LV >= 1024 ? 4 : (LV >= 512 ? 2 : 1));
       const uint64_t segs = (LV + (uint64_t)BLOCK * U - 1) / ((uint64_t)BLOCK * U);
-      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + CQ - 1) / CQ, 65535));
+      // a multiple of 8 so that a workgroup keeps its XCD residue when it strides (XCD-aware chunk order)
+      const uint64_t per_xcd = ((nq + CQ - 1) / CQ + 7) / 8;
+      const unsigned gx = (unsigned)std::max<uint64_t>(8, std::min<uint64_t>(per_xcd * 8, 65528));
       dim3 grid(gx, (unsigned)std::min<uint64_t>(segs, 64));
 #define NDI_BK(ST, UU) launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_bucketed_kernel<T, ST, UU, CQ>, A)
       if (strategy == NDI_CUBIC_SPLINE) {

@@ -719,3 +719,77 @@ def test_eval_can_be_captured_in_a_hip_graph(pkg):
             torch.cuda.synchronize()
             _, _, ref = oracle.interp1d_cubic(x, y, a, b, q_new)
             assert np.array_equal(out.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded fuzz: random shapes / dtypes / strategies / modes / formulations against the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_against_oracle(pkg, seed):
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(12):
+        dt = rng.choice([np.float64, np.float32])
+        kind = rng.choice(["linear", "cubic", "bilinear"])
+        Q = int(rng.integers(1, 3000))
+        path = int(rng.choice([pkg.PATH_AUTO, pkg.PATH_GATHER, pkg.PATH_BUCKETED]))
+        if kind == "bilinear":
+            nx, ny = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+            C = int(rng.choice([1, 2, 3, 4, 8, 12, 64, 100]))
+            x = knots(rng.choice(["rand", "jit", "log"]), nx, rng, dt) if nx > 2 else np.array([0.0, 2.0], dtype=dt)
+            y = knots(rng.choice(["rand", "jit", "log"]), ny, rng, dt) if ny > 2 else np.array([-1.0, 0.5], dtype=dt)
+            g = rng.uniform(-1, 1, (nx, ny, C)).astype(dt)
+            ext = bool(rng.integers(0, 2))
+            sx, sy = float(x[-1] - x[0]), float(y[-1] - y[0])
+            m = 0.3 if ext else 0.0
+            qx = rng.uniform(x[0] - m * sx, x[-1] + m * sx, Q).astype(dt)
+            qy = rng.uniform(y[0] - m * sy, y[-1] + m * sy, Q).astype(dt)
+            if not ext:
+                qx = np.clip(qx, x[0], x[-1]); qy = np.clip(qy, y[0], y[-1])
+            it = pkg.Interp2DBuilder.new(g).x(x).y(y).strategy(pkg.Bilinear.new().extrapolate(ext)).build()
+            it.strategy.path = path
+            _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy, ext)
+            check_equal(it.interp_array(qx, qy), ref, f"fuzz bilinear seed={seed} {nx}x{ny}x{C} ext={ext} path={path}")
+            continue
+        n = int(rng.integers(3 if kind == "cubic" else 2, 400))
+        L = int(rng.choice([1, 2, 3, 5, 8, 64, 130, 512, 1024, 1030, 2048]))
+        x = knots(rng.choice(["rand", "jit", "log", "lin"]), n, rng, dt) if n > 3 else np.arange(n).astype(dt)
+        y = rng.uniform(-1, 1, (n, L)).astype(dt)
+        span = float(x[-1] - x[0])
+        if kind == "linear":
+            ext = bool(rng.integers(0, 2))
+            m = 0.5 if ext else 0.0
+            q = rng.uniform(x[0] - m * span, x[-1] + m * span, Q).astype(dt)
+            if not ext:
+                q = np.clip(q, x[0], x[-1])
+            it = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.Linear.new().extrapolate(ext)).build()
+            it.strategy.path = path
+            _, _, ref = oracle.interp1d_linear(x, y, q, ext)
+            check_equal(it.interp_array(q), ref, f"fuzz linear seed={seed} n={n} L={L} ext={ext} path={path}")
+            continue
+        per = bool(rng.integers(0, 4) == 0) and n >= 3
+        ext = bool(rng.integers(0, 2))
+        lk, rk = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        lv, rv = float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))
+        yy = y.copy()
+        S, R, B = pkg.SingleBoundary, pkg.RowBoundary, pkg.BoundaryCondition
+        def single(k, v):
+            return {0: S.NotAKnot, 1: S.Natural, 2: S.Clamped}.get(k) or (S.FirstDeriv(v) if k == 3 else S.SecondDeriv(v))
+        if per:
+            yy[-1] = yy[0]
+            bc = B.Periodic
+        else:
+            rows = np.empty((1, L), dtype=object)
+            for i in range(L):
+                rows[0, i] = R.Mixed(single(lk, lv), single(rk, rv))
+            bc = B.Individual(rows)
+        m = 0.5 if ext else 0.0
+        q = rng.uniform(x[0] - m * span, x[-1] + m * span, Q).astype(dt)
+        if not ext:
+            q = np.clip(q, x[0], x[-1])
+        it = pkg.Interp1DBuilder.new(yy).x(x).strategy(pkg.CubicSpline.new().extrapolate(ext).boundary(bc)).build()
+        it.strategy.path = path
+        st, a, b = oracle.cubic_build(x, yy, periodic=per, left=(lk, lv), right=(rk, rv))
+        assert st == oracle.OK
+        mode = oracle.EXTRAPOLATE_NO if not ext else (oracle.EXTRAPOLATE_PERIODIC if per else oracle.EXTRAPOLATE_YES)
+        _, _, ref = oracle.interp1d_cubic(x, yy, a, b, q, mode)
+        check_equal(it.interp_array(q), ref, f"fuzz cubic seed={seed} n={n} L={L} per={per} ext={ext} bc=({lk},{rk}) path={path}")

@@ -793,3 +793,25 @@ def test_fuzz_against_oracle(pkg, seed):
         mode = oracle.EXTRAPOLATE_NO if not ext else (oracle.EXTRAPOLATE_PERIODIC if per else oracle.EXTRAPOLATE_YES)
         _, _, ref = oracle.interp1d_cubic(x, yy, a, b, q, mode)
         check_equal(it.interp_array(q), ref, f"fuzz cubic seed={seed} n={n} L={L} per={per} ext={ext} bc=({lk},{rk}) path={path}")
+
+
+def test_infinite_queries_follow_ieee_like_the_cpu(pkg):
+    """+-inf queries: out of range without extrapolation (OutOfBounds with the reference's text), and with
+    extrapolation the end interval's polynomial evaluated at +-inf -- inf / NaN exactly where the CPU gets them."""
+    rng = np.random.default_rng(3)
+    n, L = 12, 512
+    x = knots("jit", n, rng, np.float64); y = rng.uniform(-1, 1, (n, L))
+    q = rng.uniform(x[0], x[-1], 64); q[7] = np.inf; q[20] = -np.inf
+    lin = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.Linear.new().extrapolate(True)).build()
+    _, _, ref = oracle.interp1d_linear(x, y, q, True)
+    check_equal(lin.interp_array(q), ref, "linear +-inf")
+    cub = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().extrapolate(True)).build()
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q, oracle.EXTRAPOLATE_YES)
+    for path in (pkg.PATH_GATHER, pkg.PATH_BUCKETED):
+        cub.strategy.path = path
+        check_equal(cub.interp_array(q), ref, "cubic +-inf")
+    strict = pkg.Interp1DBuilder.new(y).x(x).build()
+    with pytest.raises(pkg.InterpolateError.OutOfBounds, match="x = inf is not in range") as ei:
+        strict.interp_array(q)
+    assert ei.value.index == 7

@@ -768,7 +768,6 @@ struct Interp2DImpl final : Interp2DBase {
       blocks = (nq + slice - 1) / slice;
       ws.t.reserve(nq * sizeof(uint32_t));      // keys
       ws.perm.reserve(nq * sizeof(uint4));            // grouped records {qi, xi, yi}
-      ws.qdev2.reserve(0);
       ws.stage[1].reserve(nq * 2 * sizeof(T));        // grouped {qx, qy}
       ws.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
       ws.counts.reserve((size_t)nb * sizeof(uint32_t));

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _capi
 from ._arrays import Buf, current_stream_ptr, dtype_id, is_torch, np_dtype_of
-from .errors import BuilderError, InterpolateError, Panic, raise_builder, raise_eval
+from .errors import BuilderError, Panic, raise_builder, raise_eval
 from .vector_extensions import Monotonic, get_lower_index, monotonic_prop
 
 
@@ -67,10 +67,9 @@ class _DeviceStrategy1D(Interp1DStrategy):
         xb_dt = np_dtype_of(data)
         tid = dtype_id(xb_dt)
         db = Buf(data)
-        xb = Buf(x, xb_dt) if x is not None else None
-        if xb is not None and xb.memspace != db.memspace:
-            xb = Buf(np.asarray(x.detach().cpu().numpy() if is_torch(x) else x), xb_dt) \
-                if db.memspace == _capi.MEM_HOST else Buf(_to_device(x, db.keep.device), xb_dt)
+        xb = None
+        if x is not None:   # the axis travels in the same memory space as the data
+            xb = Buf(_host(x), xb_dt) if db.memspace == _capi.MEM_HOST else Buf(_to_device(x, db.keep.device), xb_dt)
         if device is None:
             device = db.device if db.memspace == _capi.MEM_DEVICE else _default_device()
         n = db.shape[0]

@@ -28,8 +28,21 @@ def load_product_package():
     return mod
 
 
+def _ensure_native_library():
+    """A fresh checkout has no built artefacts (they are git-ignored): build the product library once,
+    exactly as __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU)."""
+    import subprocess
+    lib = os.path.join(ROOT, "ndarray-interp_amd", "libndinterp_hip.so")
+    csrc = os.path.join(ROOT, "ndarray-interp_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("ndinterp_api.hip", "kernels.hpp", "host_logic.hpp", "common.hpp")]
+    srcs.append(os.path.join(ROOT, "include", "ndinterp.h"))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.run(["make", "-C", csrc], check=True, capture_output=True)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_native_library()
 
 
 def _f(v):

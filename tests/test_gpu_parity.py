@@ -815,3 +815,27 @@ def test_infinite_queries_follow_ieee_like_the_cpu(pkg):
     with pytest.raises(pkg.InterpolateError.OutOfBounds, match="x = inf is not in range") as ei:
         strict.interp_array(q)
     assert ei.value.index == 7
+
+
+def test_empty_batches_and_size_limits(pkg):
+    rng = np.random.default_rng(1)
+    y = rng.uniform(0, 1, (5, 6))
+    interp = pkg.Interp1D.builder(y).build()
+    assert interp.interp_array(np.zeros((0,))).shape == (0, 6)
+    assert interp.interp_array(np.zeros((3, 0))).shape == (3, 0, 6)
+    cub = pkg.Interp1DBuilder.new(y).strategy(pkg.CubicSpline.new()).build()
+    for path in (pkg.PATH_GATHER, pkg.PATH_BUCKETED):
+        cub.strategy.path = path
+        assert cub.interp_array(np.zeros((0,))).shape == (0, 6)
+    it2 = pkg.Interp2D.builder(rng.uniform(0, 1, (4, 5, 3))).build()
+    assert it2.interp_array(np.zeros((0,)), np.zeros((0,))).shape == (0, 3)
+    # one query, one lane
+    s = pkg.Interp1D.builder(np.array([1.0, 3.0])).build()
+    assert s.interp_array(np.array([0.25]))[0] == 1.5
+    # the knot pyramid has three levels: 64^3 knots is the documented maximum
+    n = 64 ** 3
+    big = pkg.Interp1DBuilder.new(np.arange(n, dtype=np.float32)).build()
+    q = np.array([0.5, n - 1.5, 123456.25], dtype=np.float32)
+    assert np.array_equal(big.interp_array(q), q)            # identity data on the index axis
+    with pytest.raises(pkg.DeviceError, match="UNSUPPORTED"):
+        pkg.Interp1DBuilder.new(np.arange(n + 1, dtype=np.float32)).build()

@@ -79,8 +79,11 @@ def cpu_baseline(x, y, q_all, budget_s=20.0):
 def extra_workload(args, pkg, torch, dev, rank, world):
     """Secondary measurements (not the driver's bench line): C3 bilinear, Linear on the C2 shape."""
     rng = np.random.default_rng(42)
-    if args.workload == "c3":   # BASELINE configs[2]: 2048x2048 grid x 64 channels f32, 1e7 (x, y) queries
-        nx = ny = 2048; C = 64; nq = 10_000_000 if args.queries == 1_000_000 else args.queries
+    if args.workload in ("c3", "c5"):
+        # BASELINE configs[2]: 2048x2048 grid x 64 channels f32, 1e7 (x, y) queries;
+        # configs[4] per-GPU share: 8192x8192 grid x 16 channels f32 (4 GiB, replicated), 1.25e7 queries
+        nx, C, nq0 = (2048, 64, 10_000_000) if args.workload == "c3" else (8192, 16, 12_500_000)
+        ny = nx; nq = nq0 if args.queries == 1_000_000 else args.queries
         x = np.unique(rng.uniform(0, 1, 2 * nx).astype(np.float32))[:nx]
         y = np.unique(rng.uniform(0, 1, 2 * ny).astype(np.float32))[:ny]
         g = torch.rand((nx, ny, C), dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
@@ -91,7 +94,7 @@ def extra_workload(args, pkg, torch, dev, rank, world):
         out = torch.empty((nq, C), dtype=torch.float32, device=dev)
         step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
         points, alg = nq * C, nq * C * 20 + nq * 8
-        name = f"C3: 2D Bilinear, {nx}x{ny} grid x {C} channels f32, {nq} queries"
+        name = f"{args.workload.upper()}: 2D Bilinear, {nx}x{ny} grid x {C} channels f32, {nq} queries"
     elif args.workload == "c1":  # BASELINE configs[0]: 1D Linear, 1024 f64 knots (index axis), scalar data, 1e4 queries
         import oracle
         n, nq = 1024, 10_000
@@ -165,7 +168,7 @@ def main():
                          "streaming-store rate (physical placement of a 32.8 GB buffer varies by 15-20 %% between "
                          "allocations on MI355X, see DESIGN.md 4.3); 1 = take the first allocation")
     ap.add_argument("--sorted-queries", action="store_true", help="extra: sort the queries (cache reuse in the gather order)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c2-linear", "c2-f32", "c1"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c5", "c2-linear", "c2-f32", "c1"], default="c2",
                     help="c2 = headline (BASELINE configs[1]); c3 / c2-linear are extra measurements for DESIGN.md")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this GPU")

@@ -194,11 +194,11 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
   // software-pipelined: the next batch's queries are requested before the current batch is searched
   const uint64_t first = q_begin + (uint64_t)(tid >> 6) * 64u;
   T x_next = (first + lane < q_end) ? A.q[first + lane] : k0;
-  for (uint64_t base = first; base < q_end; base += BLOCK) {
+  for (uint64_t base = first; base < q_end; base += blockDim.x) {
     const uint64_t qi = base + lane;
     const bool active = qi < q_end;
     const T x = x_next;
-    x_next = (qi + BLOCK < q_end) ? A.q[qi + BLOCK] : k0;
+    x_next = (qi + blockDim.x < q_end) ? A.q[qi + blockDim.x] : k0;
     const bool inr = (k0 <= x) && (x <= kn);   // Interp1D::is_in_range, interp1d/mod.rs:384-386
     T xs = x;
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;
@@ -220,10 +220,11 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
   }
 }
 
-// One workgroup per contiguous slice of queries.  LDS: [pyramid | histogram].
+// One workgroup (256..1024 threads, chosen by the host so that the LDS footprint still allows a full CU of
+// waves) per contiguous slice of queries.  LDS: [pyramid | histogram].
 // STAGE: the pyramid is copied into LDS first (compile-time, so the search reads are ds_read).
 template <class T, bool STAGE>
-__global__ __launch_bounds__(BLOCK) void locate_kernel(LocateArgs<T> A) {
+__global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x;
   uint32_t* s_hist = nullptr;
@@ -233,14 +234,14 @@ __global__ __launch_bounds__(BLOCK) void locate_kernel(LocateArgs<T> A) {
     T* s0 = reinterpret_cast<T*>(smem_raw);
     T* s1 = s0 + n;
     T* s2 = s1 + n1;
-    for (uint32_t i = tid; i < n; i += BLOCK) s0[i] = A.pyr.lv0[i];
-    for (uint32_t i = tid; i < n1; i += BLOCK) s1[i] = A.pyr.lv1[i];
-    for (uint32_t i = tid; i < n2; i += BLOCK) s2[i] = A.pyr.lv2[i];
+    for (uint32_t i = tid; i < n; i += blockDim.x) s0[i] = A.pyr.lv0[i];
+    for (uint32_t i = tid; i < n1; i += blockDim.x) s1[i] = A.pyr.lv1[i];
+    for (uint32_t i = tid; i < n2; i += blockDim.x) s2[i] = A.pyr.lv2[i];
     hist_off = ((size_t)(n + n1 + n2) * sizeof(T) + 15u) & ~(size_t)15u;
   }
   if (A.hist) {
     s_hist = reinterpret_cast<uint32_t*>(smem_raw + hist_off);
-    for (uint32_t i = tid; i < A.nb; i += BLOCK) s_hist[i] = 0u;
+    for (uint32_t i = tid; i < A.nb; i += blockDim.x) s_hist[i] = 0u;
   }
   __syncthreads();
   if (STAGE) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(BLOCK) void locate_kernel(LocateArgs<T> A) {
   if (A.hist) {
     __syncthreads();
     uint32_t* dst = A.hist + (uint64_t)blockIdx.x * A.nb;
-    for (uint32_t i = tid; i < A.nb; i += BLOCK) dst[i] = s_hist[i];
+    for (uint32_t i = tid; i < A.nb; i += blockDim.x) dst[i] = s_hist[i];
   }
 }
 
@@ -276,14 +277,14 @@ struct Locate2Args {
 };
 
 template <class T>
-__global__ __launch_bounds__(BLOCK) void locate2_kernel(Locate2Args<T> A) {
+__global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x;
   const uint32_t nxa = A.px.n + A.px.n1 + A.px.n2, nya = A.py.n + A.py.n1 + A.py.n2;
   T* sx = reinterpret_cast<T*>(smem_raw);
   T* sy = sx + nxa;
-  for (uint32_t i = tid; i < nxa; i += BLOCK) sx[i] = A.px.lv0[i];   // the three levels are one allocation
-  for (uint32_t i = tid; i < nya; i += BLOCK) sy[i] = A.py.lv0[i];
+  for (uint32_t i = tid; i < nxa; i += blockDim.x) sx[i] = A.px.lv0[i];   // the three levels are one allocation
+  for (uint32_t i = tid; i < nya; i += blockDim.x) sy[i] = A.py.lv0[i];
   __syncthreads();
   PyramidLds<T> PX, PY;
   PX.lv0 = (lds_ptr<T>)(smem_raw);
@@ -302,12 +303,12 @@ __global__ __launch_bounds__(BLOCK) void locate2_kernel(Locate2Args<T> A) {
   const uint64_t first = q_begin + (uint64_t)(tid >> 6) * 64u;
   T x_next = (first + lane < q_end) ? A.qx[first + lane] : x0;
   T y_next = (first + lane < q_end) ? A.qy[first + lane] : y0;
-  for (uint64_t base = first; base < q_end; base += BLOCK) {
+  for (uint64_t base = first; base < q_end; base += blockDim.x) {
     const uint64_t qi = base + lane;
     const bool active = qi < q_end;
     const T x = x_next, y = y_next;
-    x_next = (qi + BLOCK < q_end) ? A.qx[qi + BLOCK] : x0;
-    y_next = (qi + BLOCK < q_end) ? A.qy[qi + BLOCK] : y0;
+    x_next = (qi + blockDim.x < q_end) ? A.qx[qi + blockDim.x] : x0;
+    y_next = (qi + blockDim.x < q_end) ? A.qy[qi + blockDim.x] : y0;
     const uint32_t ubx = wave_count_le<T, lds_ptr<T>>(PX, x, lane);
     const uint32_t uby = wave_count_le<T, lds_ptr<T>>(PY, y, lane);
     if (!active) continue;

@@ -180,6 +180,24 @@ static bool lds_sort_fits(const DevicePyramid<T>& pyr, uint64_t nb) {
   return nb <= GROUP_MAX_BINS && stage + nb * 4 <= LDS_STAGE_LIMIT;
 }
 
+// Workgroup size for a kernel that needs `lds` bytes per workgroup: as few threads as keep 32 waves on a CU
+// (160 KiB LDS, at most 1024 threads per workgroup).
+static unsigned threads_for_lds(size_t lds) {
+  const size_t per_cu = std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1));
+  unsigned best = 256;
+  size_t best_waves = 0;
+  for (unsigned threads : {256u, 512u, 1024u}) {
+    const size_t waves_per_wg = threads / 64;
+    const size_t wgs = std::min<size_t>(per_cu, 32 / waves_per_wg);
+    const size_t waves = wgs * waves_per_wg;
+    if (waves > best_waves) {
+      best_waves = waves;
+      best = threads;
+    }
+  }
+  return best;
+}
+
 // Launches locate_kernel.  With `hist` the grid is one workgroup per contiguous query slice and each
 // leaves its interval histogram in hist[b][nb]; *slice_out / *blocks_out describe the slicing.
 template <class T>
@@ -201,13 +219,14 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
   uint64_t blocks = hist ? std::min<uint64_t>((nq + 2047) / 2048, GROUP_MAX_BLOCKS)
                          : std::min<uint64_t>((nq + 1023) / 1024, 2048);
   blocks = std::max<uint64_t>(blocks, 1);
+  if (hist) shmem += (size_t)nb * 4;
+  const unsigned threads = threads_for_lds(shmem);
   uint64_t slice = (nq + blocks - 1) / blocks;
-  slice = (slice + BLOCK - 1) / BLOCK * BLOCK;   // whole 64-query batches per wave
+  slice = (slice + threads - 1) / threads * threads;   // whole 64-query batches per wave
   blocks = (nq + slice - 1) / slice;
   A.slice = slice;
   A.hist = hist;
   A.nb = nb;
-  if (hist) shmem += (size_t)nb * 4;
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate_kernel<T, true>),
@@ -217,8 +236,8 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
   });
   if (slice_out) *slice_out = slice;
   if (blocks_out) *blocks_out = (uint32_t)blocks;
-  if (A.stage_lds) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(BLOCK), shmem, locate_kernel<T, true>, A);
-  else launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(BLOCK), shmem, locate_kernel<T, false>, A);
+  if (A.stage_lds) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, true>, A);
+  else launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, false>, A);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -715,9 +734,10 @@ struct Interp2DImpl final : Interp2DBase {
       LA.xi = ws.idx.as<uint32_t>(); LA.yi = ws.idx2.as<uint32_t>();
       LA.first_fail = &st->first_fail[0];
       LA.mode = mode;
+      const unsigned threads = threads_for_lds(both);
       uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, 2048));
       uint64_t slice = (nq + blocks - 1) / blocks;
-      slice = (slice + BLOCK - 1) / BLOCK * BLOCK;
+      slice = (slice + threads - 1) / threads * threads;
       blocks = (nq + slice - 1) / slice;
       LA.slice = slice;
       static std::once_flag once;
@@ -725,7 +745,7 @@ struct Interp2DImpl final : Interp2DBase {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate2_kernel<T>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
       });
-      launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(BLOCK), both, locate2_kernel<T>, LA);
+      launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), both, locate2_kernel<T>, LA);
     } else {
       run_locate<T>(s, px, qx, nq, ws.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
       run_locate<T>(s, py, qy, nq, ws.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);

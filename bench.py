@@ -86,6 +86,8 @@ def extra_workload(args, pkg, torch, dev, rank, world):
         ny = nx; nq = nq0 if args.queries == 1_000_000 else args.queries
         x = np.unique(rng.uniform(0, 1, 2 * nx).astype(np.float32))[:nx]
         y = np.unique(rng.uniform(0, 1, 2 * ny).astype(np.float32))[:ny]
+        if args.even_axes:
+            x = np.arange(nx, dtype=np.float32); y = np.arange(ny, dtype=np.float32)
         g = torch.rand((nx, ny, C), dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
         interp = pkg.Interp2DBuilder.new(g).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
         interp.strategy.path = {"auto": pkg.PATH_AUTO, "gather": pkg.PATH_GATHER, "bucketed": pkg.PATH_BUCKETED}[args.path]
@@ -94,7 +96,8 @@ def extra_workload(args, pkg, torch, dev, rank, world):
         out = torch.empty((nq, C), dtype=torch.float32, device=dev)
         step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
         points, alg = nq * C, nq * C * 20 + nq * 8
-        name = f"{args.workload.upper()}: 2D Bilinear, {nx}x{ny} grid x {C} channels f32, {nq} queries"
+        name = f"{args.workload.upper()}: 2D Bilinear, {nx}x{ny} grid x {C} channels f32, {nq} queries" + \
+            (" (index axes)" if args.even_axes else " (random knots)")
     elif args.workload == "c1":  # BASELINE configs[0]: 1D Linear, 1024 f64 knots (index axis), scalar data, 1e4 queries
         import oracle
         n, nq = 1024, 10_000
@@ -167,6 +170,7 @@ def main():
                     help="allocate this many candidate output buffers and keep the one with the best measured "
                          "streaming-store rate (physical placement of a 32.8 GB buffer varies by 15-20 %% between "
                          "allocations on MI355X, see DESIGN.md 4.3); 1 = take the first allocation")
+    ap.add_argument("--even-axes", action="store_true", help="extra (c3/c5): default index axes 0..n instead of random knots")
     ap.add_argument("--sorted-queries", action="store_true", help="extra: sort the queries (cache reuse in the gather order)")
     ap.add_argument("--workload", choices=["c2", "c3", "c5", "c2-linear", "c2-f32", "c1"], default="c2",
                     help="c2 = headline (BASELINE configs[1]); c3 / c2-linear are extra measurements for DESIGN.md")

@@ -86,6 +86,7 @@ struct PyramidT {
   PTR lv2;
   uint32_t n, n1, n2;
   int levels;  // 1, 2 or 3
+  int guess;   // axis is close to evenly spaced: try the O(1) index guess first
 };
 template <class T>
 using Pyramid = PyramidT<T, const T*>;                      // global memory
@@ -163,6 +164,30 @@ __device__ __forceinline__ uint32_t wave_count_le(const PyramidT<T, PTR>& P, T x
   return base + block_last_le<T, PTR>(P.lv0 + base, len, x) + 1u;
 }
 
+// Interval index of one query per lane: the O(1) guess of the reference for evenly spaced axes
+// (vector_extensions.rs:68-90: mid = calc_frac((k0,0),(kn,n-1),x), accepted iff k[mid] <= x < k[mid+1]),
+// and the cooperative search for the whole wave as soon as one lane's guess is not accepted.  Either way the
+// result is the unique i with k[i] <= x < k[i+1], clamped to [0, n-2].  Must be called by all 64 lanes.
+template <class T, class PTR>
+__device__ __forceinline__ uint32_t locate_index(const PyramidT<T, PTR>& P, T k0, T kn, T x, uint32_t lane) {
+  uint32_t gi = 0;
+  bool need = true;
+  if (P.guess) {
+    const T m = (T(P.n - 1u) - T(0)) / (kn - k0) * (x - k0) + T(0);
+    gi = (m >= T(0)) ? (uint32_t)(m < T(P.n - 2u) ? m : T(P.n - 2u)) : 0u;   // truncation; NaN -> 0
+    const T a = P.lv0[gi], b = P.lv0[gi + 1];
+    need = !((a <= x) && (x < b));
+  }
+  uint32_t i = gi;
+  if (__any(need ? 1 : 0)) {
+    const uint32_t ub = wave_count_le<T, PTR>(P, x, lane);
+    uint32_t s = (ub == 0) ? 0u : ub - 1u;
+    if (s > P.n - 2u) s = P.n - 2u;
+    if (need) i = s;
+  }
+  return i;
+}
+
 template <class T>
 struct LocateArgs {
   Pyramid<T> pyr;          // global-memory pyramid
@@ -202,11 +227,10 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
     const bool inr = (k0 <= x) && (x <= kn);   // Interp1D::is_in_range, interp1d/mod.rs:384-386
     T xs = x;
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;
-    const uint32_t ub = wave_count_le<T, PTR>(P, xs, lane);   // all 64 lanes take part (readlane broadcast)
+    // unique i with k[i] <= x < k[i+1], clamped to [0, n-2]  (vector_extensions.rs:61-66, 100-110);
+    // all 64 lanes take part (cross-lane exchange inside)
+    const uint32_t i = locate_index<T, PTR>(P, k0, kn, xs, lane);
     if (!active) continue;
-    // unique i with k[i] <= x < k[i+1], clamped to [0, n-2]  (vector_extensions.rs:61-66, 100-110)
-    uint32_t i = (ub == 0) ? 0u : ub - 1u;
-    if (i > P.n - 2u) i = P.n - 2u;
     const bool isnan_q = !(xs == xs);
     const bool bad = (A.mode == EX_NO) ? !inr : isnan_q;
     if (bad && A.first_fail) atomicMin(A.first_fail, (unsigned long long)qi);
@@ -249,7 +273,7 @@ __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
     P.lv0 = (lds_ptr<T>)(smem_raw);
     P.lv1 = P.lv0 + n;
     P.lv2 = P.lv1 + n1;
-    P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels;
+    P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels; P.guess = A.pyr.guess;
     locate_slice<T, lds_ptr<T>>(A, P, s_hist);
   } else {
     locate_slice<T, const T*>(A, A.pyr, s_hist);
@@ -290,11 +314,11 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   PX.lv0 = (lds_ptr<T>)(smem_raw);
   PX.lv1 = PX.lv0 + A.px.n;
   PX.lv2 = PX.lv1 + A.px.n1;
-  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels;
+  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels; PX.guess = A.px.guess;
   PY.lv0 = PX.lv0 + nxa;
   PY.lv1 = PY.lv0 + A.py.n;
   PY.lv2 = PY.lv1 + A.py.n1;
-  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels;
+  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels; PY.guess = A.py.guess;
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
   const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
@@ -309,13 +333,9 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
     const T x = x_next, y = y_next;
     x_next = (qi + blockDim.x < q_end) ? A.qx[qi + blockDim.x] : x0;
     y_next = (qi + blockDim.x < q_end) ? A.qy[qi + blockDim.x] : y0;
-    const uint32_t ubx = wave_count_le<T, lds_ptr<T>>(PX, x, lane);
-    const uint32_t uby = wave_count_le<T, lds_ptr<T>>(PY, y, lane);
+    const uint32_t ix = locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
+    const uint32_t iy = locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
     if (!active) continue;
-    uint32_t ix = (ubx == 0) ? 0u : ubx - 1u;
-    if (ix > PX.n - 2u) ix = PX.n - 2u;
-    uint32_t iy = (uby == 0) ? 0u : uby - 1u;
-    if (iy > PY.n - 2u) iy = PY.n - 2u;
     // Interp2D::is_in_x_range / is_in_y_range (interp2d/mod.rs:374-379); NaN handling as in locate_slice
     const bool badx = (A.mode == EX_NO) ? !((x0 <= x) && (x <= xn)) : !(x == x);
     const bool bady = (A.mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
@@ -650,6 +670,10 @@ struct Eval2Args {
   const uint32_t* yi;
   T* out;
   uint64_t ny, lanes, out_stride, nq;
+  // addressing of the corner rows: element offset of cell (xi, yi) = (xi * row_cells + yi) * cell_elems.
+  // plain layout [nx][ny][lanes]: row_cells = ny, cell_elems = lanes; pair-packed layout (see
+  // pack_pairs_kernel): row_cells = ny - 1, cell_elems = 2 * lanes.  z12 is always z11 + lanes.
+  uint64_t row_cells, cell_elems;
   const StatusBlock* status;
   // tile-grouped order (nullptr: query order): per grouped position the query's record
   const uint4* rec_i;    // {query index, xi, yi, 0}
@@ -702,6 +726,23 @@ __global__ __launch_bounds__(BLOCK) void group_scatter2d_kernel(const uint32_t* 
   }
 }
 
+// Pair-packed grid for short trailing axes: P[xi][yi] = { z[xi][yi], z[xi][yi+1] }, yi < ny-1.  The two
+// corners a query needs from one grid row become one naturally aligned segment (128 B at 16 f32 channels), so a
+// query touches exactly two cache lines instead of three on average (a 64-B-aligned 128-B segment straddles
+// two 128-B lines half of the time).  Costs 2x the grid memory; values are copied, never recomputed.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void pack_pairs_kernel(const T* in, T* out, uint64_t nx, uint64_t ny,
+                                                           uint64_t lanes) {
+  const uint64_t total = nx * (ny - 1) * 2 * lanes;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t c = e % lanes;
+    const uint64_t h = (e / lanes) & 1u;
+    const uint64_t cell = e / (2 * lanes);
+    const uint64_t xi = cell / (ny - 1), yi = cell - xi * (ny - 1);
+    out[e] = in[(xi * ny + yi + h) * lanes + c];
+  }
+}
+
 // APPROX exists only for the tuning harness (tools/tune_eval.hip: how much of the kernel is division cost);
 // the library instantiates the exact form.
 template <class T, class V, bool APPROX = false>
@@ -748,9 +789,9 @@ __global__ __launch_bounds__(BLOCK) void eval_bilinear_kernel(Eval2Args<T> A, ui
       }
       const T x1 = A.xk[xi], x2 = A.xk[xi + 1];
       const T y1 = A.yk[yi], y2 = A.yk[yi + 1];
-      const V* z11 = reinterpret_cast<const V*>(A.data + ((uint64_t)xi * A.ny + yi) * A.lanes);
+      const V* z11 = reinterpret_cast<const V*>(A.data + ((uint64_t)xi * A.row_cells + yi) * A.cell_elems);
       const V* z12 = z11 + LV;                                    // (xi,   yi+1)
-      const V* z21 = reinterpret_cast<const V*>(A.data + ((uint64_t)(xi + 1) * A.ny + yi) * A.lanes);
+      const V* z21 = reinterpret_cast<const V*>(A.data + ((uint64_t)(xi + 1) * A.row_cells + yi) * A.cell_elems);
       const V* z22 = z21 + LV;                                    // (xi+1, yi+1)
       const V a11 = z11[v], a12 = z12[v], a21 = z21[v], a22 = z22[v];
       const V z1 = frac_v<T, V, APPROX>(x1, a11, x2, a21, x);

@@ -127,6 +127,12 @@ struct DevicePyramid {
     view.n1 = n1;
     view.n2 = n2;
     view.levels = (n <= 64) ? 1 : (n <= 4096 ? 2 : 3);
+    // evenly spaced within less than half a step everywhere -> the reference's O(1) guess will mostly be right
+    bool even = n >= 2;
+    const double step = ((double)knots[n - 1] - (double)knots[0]) / (double)(n - 1);
+    for (uint64_t i = 0; even && i < n; ++i)
+      even = std::fabs((double)knots[i] - ((double)knots[0] + step * (double)i)) < 0.45 * step;
+    view.guess = even ? 1 : 0;
     lds_bytes = all.size() * sizeof(T);
   }
 };
@@ -710,6 +716,7 @@ struct Interp2DImpl final : Interp2DBase {
   uint64_t nx = 0, ny = 0, lanes = 0;
   DevicePyramid<T> px, py;
   DevBuf data;
+  bool pair_packed = false;   // data holds the pair-packed layout (pack_pairs_kernel)
   std::mutex mu;
   std::map<SpaceKey, std::unique_ptr<Workspace>> spaces;
 
@@ -763,6 +770,8 @@ struct Interp2DImpl final : Interp2DBase {
     A.lanes = lanes;
     A.out_stride = out_stride;
     A.nq = nq;
+    A.row_cells = pair_packed ? ny - 1 : ny;
+    A.cell_elems = pair_packed ? 2 * lanes : lanes;
     A.status = st;
     A.rec_i = nullptr;
     A.rec_q = nullptr;
@@ -944,9 +953,29 @@ static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
   h->px.upload(x.data(), d.nx);
   h->py.upload(y.data(), d.ny);
   const size_t bytes = (size_t)d.nx * d.ny * d.lanes * sizeof(T);
-  h->data.reserve(bytes);
-  NDI_HIP(hipMemcpy(h->data.p, d.data, bytes,
-                    d.memspace == NDI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  const hipMemcpyKind kind = d.memspace == NDI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  // Short trailing axes (<= 64 B per grid point): keep the pair-packed layout instead of the plain one.
+  h->pair_packed = d.lanes * sizeof(T) <= 64 && d.ny >= 2;
+  if (h->pair_packed) {
+    const size_t packed = (size_t)d.nx * (d.ny - 1) * 2 * d.lanes * sizeof(T);
+    h->data.reserve(packed);
+    const void* src = d.data;
+    DevBuf tmp;
+    if (d.memspace != NDI_MEM_DEVICE) {
+      tmp.reserve(bytes);
+      NDI_HIP(hipMemcpy(tmp.p, d.data, bytes, kind));
+      src = tmp.p;
+    }
+    const uint64_t total = (uint64_t)d.nx * (d.ny - 1) * 2 * d.lanes;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((total + BLOCK - 1) / BLOCK, 65536));
+    hipLaunchKernelGGL(pack_pairs_kernel<T>, dim3(grid), dim3(BLOCK), 0, (hipStream_t) nullptr, (const T*)src,
+                       h->data.template as<T>(), (uint64_t)d.nx, (uint64_t)d.ny, (uint64_t)d.lanes);
+    NDI_HIP(hipGetLastError());
+    NDI_HIP(hipDeviceSynchronize());
+  } else {
+    h->data.reserve(bytes);
+    NDI_HIP(hipMemcpy(h->data.p, d.data, bytes, kind));
+  }
   *out = h.release();
   return NDI_OK;
 }

@@ -42,7 +42,7 @@ int main() {
   hipLaunchKernelGGL(make_queries, dim3(4096), dim3(256), 0, 0, qx, qy, xi, yi, nq, nx, ny);
   CK(hipMemset(st, 0xFF, 16)); CK(hipMemset((char*)st + 16, 0, sizeof(StatusBlock) - 16));
   Eval2Args<float> A{}; A.xk = xk; A.yk = yk; A.data = grid; A.qx = qx; A.qy = qy; A.xi = xi; A.yi = yi; A.out = out;
-  A.ny = ny; A.lanes = C; A.out_stride = C; A.nq = nq; A.status = st;
+  A.ny = ny; A.row_cells = ny; A.cell_elems = C; A.lanes = C; A.out_stride = C; A.nq = nq; A.status = st;
   const double alg = (double)nq * C * 20 + nq * 8.0;
   for (uint32_t tile_q : {16u, 64u, 256u}) for (unsigned gx : {8192u, 32768u, 131072u}) {
     double t1 = time_ms([&] { hipLaunchKernelGGL((eval_bilinear_kernel<float, 4, false>), dim3(gx), dim3(256), 0, 0, A, tile_q); });

@@ -116,7 +116,9 @@ typedef struct ndi_interp1d_desc {
 } ndi_interp1d_desc;
 
 /* Replaces Interp2DBuilder::{new,x,y,strategy,build} (src/interp2d/mod.rs:382-519)
- * + Bilinear::build (src/interp2d/strategies/bilinear.rs:45-52). */
+ * + Bilinear::build (src/interp2d/strategies/bilinear.rs:45-52).
+ * Device memory: one copy of the grid; for short trailing axes (lanes * sizeof(T) <= 64 bytes) the copy
+ * is kept pair-packed instead ({z[xi][yi], z[xi][yi+1]} per cell), which takes twice the grid size. */
 typedef struct ndi_interp2d_desc {
   int32_t dtype;
   int32_t extrapolate; /* Bilinear::extrapolate */

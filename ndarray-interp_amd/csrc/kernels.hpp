@@ -1,18 +1,22 @@
 // csrc/kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
 //
 // Everything here is HBM-bound gather/stream work (no dense contraction, so no MFMA):
-//   locate_kernel          per-query interval search, wavefront-cooperative 64-ary search
-//                          over a knot pyramid staged in LDS          (vector_extensions.rs:55-111)
-//   eval_rows_kernel       GATHER formulation, one row segment per workgroup pass, 16-byte
-//                          coalesced loads of the operand rows fused with the polynomial
-//                          (linear.rs:94-96, cubic_spline.rs:818-828)
-//   eval_flat_kernel       same arithmetic for short / unaligned rows and for Bilinear
-//                          (bilinear.rs:83-97): one 16-byte (or scalar) output vector per thread
-//   bucket_* + eval_bucketed_kernel
-//                          BUCKETED formulation: queries grouped by interval (counting sort),
-//                          operand rows held in registers across a group, output streamed
-//   spline_build_*         batched Thomas solve, one lane of the trailing axes per thread,
-//                          shared elimination factors (cubic_spline.rs:310-368, 409-721)
+//   locate_kernel / locate2_kernel
+//                          per-query interval search (one / both axes): knot pyramid staged in LDS, top level
+//                          held one entry per lane and bisected with cross-lane gathers, lower levels bisected
+//                          in LDS; O(1) guess first on evenly spaced axes         (vector_extensions.rs:55-111)
+//   eval_rows_kernel       GATHER formulation, long rows: one 256-vector row segment per workgroup pass,
+//                          16-byte coalesced loads of the operand rows fused with the polynomial,
+//                          non-temporal stores                       (linear.rs:94-96, cubic_spline.rs:818-828)
+//   eval_flat_kernel       same arithmetic for short / unaligned rows: one output vector per thread
+//   group_offsets_kernel, bucket_scan_kernel, group_scatter_kernel (+ bucket_count/_scatter fallback)
+//                          block-local counting sort of the queries by interval (LDS histograms and cursors)
+//   eval_bucketed_kernel   BUCKETED formulation: grouped order, operand rows held in registers across a
+//                          group, output streamed; XCD-aware chunk order
+//   eval_bilinear_kernel   2-D (bilinear.rs:83-97), plain or pair-packed grid (pack_pairs_kernel);
+//                          tile_hist_kernel + group_scatter2d_kernel give the optional tile-grouped order
+//   spline_build_*         batched Thomas solve, one lane of the trailing axes per thread, shared (or
+//                          per-lane selected) elimination factors          (cubic_spline.rs:310-368, 409-721)
 //
 // Arithmetic is written in the reference's operation order and the translation unit is
 // compiled with -ffp-contract=off, so results are bit-identical to a non-fused CPU evaluation.

@@ -843,6 +843,12 @@ struct BuildArgs {
 // PER_LANE: BoundaryCondition::Individual -- every lane selects its own end kinds / values and the
 // matching precomputed elimination plan (arithmetic per lane identical to a scalar solve of that column,
 // which is what solve_for_k_individual :370-403 does).
+// The recurrences are serial in i, so a lane's time is latency: rows are processed in blocks of SB --
+// all loads of a block are issued together (one memory round trip per SB rows instead of one per row) and the
+// right-hand sides, which do not depend on the recurrence, are formed before the SB dependent updates.
+// Per element the operations and their order are exactly those of the row-by-row form.
+constexpr int SB = 16;
+
 template <class T, bool PER_LANE>
 __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A) {
   const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -882,18 +888,56 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
     r_prev = ((yc - ym) / dx0) * two;
   }
   sa[0] = r_prev;
-  for (uint64_t i = 1; i + 1 < n; ++i) {
-    const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
-    T rhs;
-    if (PER_LANE && lk == 3) rhs = (((yp - yc) / dx1) * dx0 + ((yc - ym) / dx0) * dx1) * three;  // :593-594
-    else rhs = three * (dxn * (yc - ym) / dxn_1 + dxn_1 * (yp - yc) / dxn);
-    const T r = rhs - w[i] * r_prev;
-    sa[i * L] = r;
-    r_prev = r;
-    if (i + 2 < n) {
-      ym = yc;
-      yc = yp;
-      yp = y[(i + 2) * L];
+  // ---- forward sweep over the interior rows 1 .. n-2, SB rows at a time.
+  // On entry to a block starting at row i0: ym = y[i0-1], yc = y[i0]; the block needs y[i0+1 .. i0+cnt].
+  for (uint64_t i0 = 1; i0 + 1 < n; i0 += SB) {
+    const uint64_t left = n - 1 - i0;  // interior rows remaining
+    const int cnt = left < (uint64_t)SB ? (int)left : SB;
+    T yn[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b)
+      if (b < cnt) yn[b] = y[(i0 + 1 + b) * L];
+    T rhs[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+      if (b < cnt) {
+        const uint64_t i = i0 + b;
+        const T a0 = (b == 0) ? ym : ((b == 1) ? yc : yn[b >= 2 ? b - 2 : 0]);   // y[i-1]
+        const T a1 = (b == 0) ? yc : yn[b >= 1 ? b - 1 : 0];                      // y[i]
+        const T a2 = yn[b];                                                       // y[i+1]
+        const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
+        if (PER_LANE && lk == 3) rhs[b] = (((a2 - a1) / dx1) * dx0 + ((a1 - a0) / dx0) * dx1) * three;  // :593-594
+        else rhs[b] = three * (dxn * (a1 - a0) / dxn_1 + dxn_1 * (a2 - a1) / dxn);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+      if (b < cnt) {
+        const uint64_t i = i0 + b;
+        const T r = rhs[b] - w[i] * r_prev;
+        sa[i * L] = r;
+        r_prev = r;
+      }
+    }
+    // window (y[i-1], y[i], y[i+1]) of the block's last row i
+    T w0 = ym, w1 = yc, w2 = yp;
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+      if (b < cnt) {
+        if (b > 0) {
+          w0 = w1;
+          w1 = w2;
+        }
+        w2 = yn[b];
+      }
+    }
+    if (i0 + (uint64_t)cnt + 1 < n) {   // another block follows: it starts at row i0+cnt
+      ym = w1;
+      yc = w2;
+    } else {                            // done: keep the window of row n-2 for the last boundary row
+      ym = w0;
+      yc = w1;
+      yp = w2;
     }
   }
   // window is now (y[n-3], y[n-2], y[n-1])
@@ -911,16 +955,32 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
   const T r_last = rhs_last - w_last * r_prev;
   T k_next = r_last / mid_last;
   T y_hi = yp;
-  for (uint64_t i = n - 1; i-- > 0;) {
-    const T ri = sa[i * L];
-    const T y_lo = y[i * L];
-    const T k = (ri - (i == 0 ? up0 : A.up[i]) * k_next) / midp[i];
-    const T dy = y_hi - y_lo;
-    const T dxi = A.dx[i];
-    sa[i * L] = k * dxi - dy;
-    sb[i * L] = dy - k_next * dxi;
-    k_next = k;
-    y_hi = y_lo;
+  // ---- back substitution fused with a/b, rows n-2 .. 0, SB rows at a time
+  for (uint64_t hi = n - 1; hi > 0;) {   // rows hi-1, hi-2, ...
+    const int cnt = hi < (uint64_t)SB ? (int)hi : SB;
+    T ri[SB], yl[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+      if (b < cnt) {
+        const uint64_t i = hi - 1 - b;
+        ri[b] = sa[i * L];
+        yl[b] = y[i * L];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+      if (b < cnt) {
+        const uint64_t i = hi - 1 - b;
+        const T k = (ri[b] - (i == 0 ? up0 : A.up[i]) * k_next) / midp[i];
+        const T dy = y_hi - yl[b];
+        const T dxi = A.dx[i];
+        sa[i * L] = k * dxi - dy;
+        sb[i * L] = dy - k_next * dxi;
+        k_next = k;
+        y_hi = yl[b];
+      }
+    }
+    hi -= (uint64_t)cnt;
   }
 }
 

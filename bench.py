@@ -111,12 +111,39 @@ def extra_workload(args, pkg, torch, dev, rank, world):
         res = interp.interp_array(q)
         assert np.array_equal(res, oracle.interp1d_linear(x, yv, q)[2][:, 0])
         t0 = time.perf_counter()
-        for _ in range(200):
+        for _ in range(500):
             interp.interp_array(q)          # host arrays in, host array out: includes H2D / D2H and the sync
-        gpu_us = (time.perf_counter() - t0) / 200 * 1e6
+        gpu_us = (time.perf_counter() - t0) / 500 * 1e6
+        # the same batch through the bare C ABI (what a compiled host language pays; no Python mirror on top)
+        import ctypes
+        cap = pkg._capi
+        out = np.zeros(nq); opts = cap.EvalOpts(); info = cap.OobInfo()
+        fn, h = cap.lib().ndi_interp1d_eval, interp.strategy._h
+        args = (h, q.ctypes.data, nq, out.ctypes.data, 1, ctypes.byref(opts), ctypes.byref(info))
+        for _ in range(50):
+            assert fn(*args) == 0
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            fn(*args)
+        abi_us = (time.perf_counter() - t0) / 2000 * 1e6
+        assert np.array_equal(out, res)
+        cross = {}
+        for nq2 in (100, 1000, 100_000, 1_000_000):     # where the device starts to pay, host to host
+            q2 = np.random.default_rng(5).uniform(0, n - 1, nq2); o2 = np.zeros(nq2)
+            reps = max(3, int(2e6 / nq2)); t0 = time.perf_counter()
+            for _ in range(reps):
+                oracle.interp1d_linear(x, yv, q2)
+            c_us = (time.perf_counter() - t0) / reps * 1e6
+            a2 = (h, q2.ctypes.data, nq2, o2.ctypes.data, 1, ctypes.byref(opts), ctypes.byref(info))
+            fn(*a2); t0 = time.perf_counter()
+            for _ in range(reps):
+                fn(*a2)
+            cross[str(nq2)] = {"cpu_port_us": round(c_us, 1), "gpu_c_abi_us": round((time.perf_counter() - t0) / reps * 1e6, 1)}
+        print(json.dumps({"batch_size_sweep_scalar_linear": cross}))
         print(json.dumps({"workload": "C1: 1D Linear, 1024 knots, scalar f64 data, 1e4 queries (CPU-reference config)",
                           "cpu_port_us_per_batch": round(cpu_us, 1), "cpu_port_Mpoints_s": round(nq / cpu_us, 1),
-                          "gpu_host_to_host_us_per_batch": round(gpu_us, 1), "gpu_Mpoints_s": round(nq / gpu_us, 1)}))
+                          "gpu_c_abi_host_to_host_us_per_batch": round(abi_us, 1), "gpu_c_abi_Mpoints_s": round(nq / abi_us, 1),
+                          "gpu_python_mirror_us_per_batch": round(gpu_us, 1)}))
         return
     else:                        # Linear f64 / CubicSpline f32 on the C2 shape
         n = lanes = 4096; nq = args.queries

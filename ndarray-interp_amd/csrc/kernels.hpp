@@ -411,6 +411,85 @@ __device__ __forceinline__ void store_stream(V* p, V v) {
   else *p = v;
 }
 
+// Short trailing axes, latency-sensitive batches: search and evaluation fused in one launch, one query per
+// thread (lanes <= SMALL_LANES).  Because rows are written before the batch's first failing query is known,
+// the host only uses it with a staging buffer it owns (host-output mode) and copies out the rows before the
+// failure -- the caller-visible semantics stay those of the two-kernel path.
+constexpr int SMALL_LANES = 16;
+
+template <class T>
+struct EvalSmallArgs {
+  Pyramid<T> pyr;
+  const T* data;
+  const T* ca;
+  const T* cb;
+  const T* q;
+  T* out;          // [nq][lanes], row stride = lanes
+  uint64_t nq;
+  uint32_t lanes;
+  int mode;        // ExtrapMode
+  unsigned long long* first_fail;
+};
+
+template <class T, int STRAT>
+__global__ __launch_bounds__(BLOCK) void eval_small_kernel(EvalSmallArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = A.pyr.n, n1 = A.pyr.n1, n2 = A.pyr.n2;
+  {
+    T* s0 = reinterpret_cast<T*>(smem_raw);
+    const uint32_t total = n + n1 + n2;   // the three levels are one allocation
+    for (uint32_t i = tid; i < total; i += BLOCK) s0[i] = A.pyr.lv0[i];
+  }
+  __syncthreads();
+  PyramidLds<T> P;
+  P.lv0 = (lds_ptr<T>)(smem_raw);
+  P.lv1 = P.lv0 + n;
+  P.lv2 = P.lv1 + n1;
+  P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels; P.guess = A.pyr.guess;
+  const T k0 = P.lv0[0], kn = P.lv0[n - 1];
+  const uint32_t lane = tid & 63u;
+  const uint32_t L = A.lanes;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK + (tid & ~63u); base < A.nq; base += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t qi = base + lane;
+    const bool active = qi < A.nq;
+    const T x = active ? A.q[qi] : k0;
+    const bool inr = (k0 <= x) && (x <= kn);
+    T xs = x;
+    if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;
+    const uint32_t i = locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);   // all 64 lanes take part
+    if (!active) continue;
+    const bool bad = (A.mode == EX_NO) ? !inr : !(xs == xs);
+    if (bad) {
+      atomicMin(A.first_fail, (unsigned long long)qi);
+      continue;
+    }
+    const T xl = P.lv0[i], xr = P.lv0[i + 1];
+    RowCoef<T, STRAT> c;
+    if (STRAT == ST_CUBIC) {
+      const T t = (xs - xl) / (xr - xl);   // cubic_spline.rs:818
+      const T one = T(1);
+      c.c0 = one - t;
+      c.c1 = t;
+      c.c2 = t * (one - t);
+    } else {
+      c.c0 = xr - xl;
+      c.c1 = x - xl;
+      c.c2 = T(0);
+    }
+    const T* yl = A.data + (uint64_t)i * L;
+    const T* yr = yl + L;
+    const T* pa = A.ca + (uint64_t)i * L;
+    const T* pb = A.cb + (uint64_t)i * L;
+    T* o = A.out + qi * L;
+    for (uint32_t l = 0; l < L; ++l) {
+      const T a = (STRAT == ST_CUBIC) ? pa[l] : T(0);
+      const T b = (STRAT == ST_CUBIC) ? pb[l] : T(0);
+      o[l] = row_point<T, STRAT, T>(c, yl[l], yr[l], a, b);
+    }
+  }
+}
+
 // GATHER, long rows: grid.x strides over queries, grid.y over 256*U-vector segments of a row.
 template <class T, int STRAT, int U, bool NT = true>
 __global__ __launch_bounds__(BLOCK) void eval_rows_kernel(Eval1Args<T> A) {

@@ -146,6 +146,8 @@ constexpr size_t LDS_STAGE_LIMIT = 150 * 1024;          // of the CU's 160 KiB
 struct Workspace {
   DevBuf idx, idx2, t, perm, counts, cursor, hist, status, qdev, qdev2, stage[2];
   StatusBlock* host_status = nullptr;  // pinned
+  void* pin = nullptr;                 // pinned bounce buffer of the small-batch host path
+  size_t pin_bytes = 0;
   // record of the last batch (for finish())
   uint64_t last_nq = 0;
   const void* last_q = nullptr;
@@ -154,6 +156,15 @@ struct Workspace {
   bool pending = false;
   ~Workspace() {
     if (host_status) (void)hipHostFree(host_status);
+    if (pin) (void)hipHostFree(pin);
+  }
+  void ensure_pin(size_t need) {
+    if (need <= pin_bytes) return;
+    if (pin) (void)hipHostFree(pin);
+    pin = nullptr;
+    pin_bytes = 0;
+    NDI_HIP(hipHostMalloc(&pin, need, hipHostMallocDefault));
+    pin_bytes = need;
   }
   void ensure_status() {
     status.reserve(sizeof(StatusBlock));
@@ -578,6 +589,75 @@ struct Interp1DImpl final : Interp1DBase {
     return fail(st, "x = %.17g is not in range", (double)v);
   }
 
+  // Host output with short trailing axes (the reference's own bench shapes: scalar data, a few lanes):
+  // one fused search+evaluate launch per chunk into a staging buffer the library owns, results and status
+  // brought back with one synchronisation (small chunks bounce through pinned memory), and only the rows
+  // before the first failing query are copied into the caller's buffer.
+  ndi_status eval_small_host(hipStream_t s, Workspace& ws, const T* q_dev, const T* q_orig, int q_space,
+                             uint64_t nq, T* out, uint64_t out_stride, ndi_oob_info* info) {
+    const uint64_t row_bytes = lanes * sizeof(T);
+    const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (64ull << 20) / row_bytes));
+    constexpr size_t BOUNCE = 8ull << 20;
+    ws.stage[0].reserve(chunk_q * row_bytes);
+    ws.ensure_status();
+    g_last_path.store(NDI_PATH_GATHER);
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+    });
+    StatusBlock* st = ws.status.as<StatusBlock>();
+    for (uint64_t off = 0; off < nq; off += chunk_q) {
+      const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
+      const size_t bytes = cq * row_bytes;
+      NDI_HIP(hipMemsetAsync(ws.status.p, 0xFF, 2 * sizeof(unsigned long long), s));
+      EvalSmallArgs<T> A{};
+      A.pyr = pyr.view;
+      A.data = data.as<T>();
+      A.ca = ca.as<T>();
+      A.cb = cb.as<T>();
+      A.q = q_dev + off;
+      A.out = ws.stage[0].as<T>();
+      A.nq = cq;
+      A.lanes = (uint32_t)lanes;
+      A.mode = mode;
+      A.first_fail = &st->first_fail[0];
+      const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((cq + BLOCK - 1) / BLOCK, 4096));
+      const size_t shmem = (pyr.lds_bytes + 15) & ~(size_t)15;
+      if (strategy == NDI_CUBIC_SPLINE) launch1<T>(s, PC_EVAL, dim3(grid), dim3(BLOCK), shmem, eval_small_kernel<T, ST_CUBIC>, A);
+      else launch1<T>(s, PC_EVAL, dim3(grid), dim3(BLOCK), shmem, eval_small_kernel<T, ST_LINEAR>, A);
+      const bool bounce = bytes <= BOUNCE;
+      if (bounce) {
+        ws.ensure_pin(BOUNCE);
+        NDI_HIP(hipMemcpyAsync(ws.pin, ws.stage[0].p, bytes, hipMemcpyDeviceToHost, s));
+      }
+      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipStreamSynchronize(s));
+      const unsigned long long ff = ws.host_status->first_fail[0];
+      const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
+      T* dst = out + off * out_stride;
+      if (good) {
+        if (bounce) {
+          if (out_stride == lanes) std::memcpy(dst, ws.pin, good * row_bytes);
+          else
+            for (uint64_t r = 0; r < good; ++r)
+              std::memcpy(dst + r * out_stride, (const char*)ws.pin + r * row_bytes, row_bytes);
+        } else {
+          NDI_HIP(hipMemcpy2D(dst, out_stride * sizeof(T), ws.stage[0].p, row_bytes, row_bytes, good,
+                              hipMemcpyDeviceToHost));
+        }
+      }
+      if (ff != NO_FAIL) {
+        ws.last_q = q_orig + off;
+        ws.last_q_space = q_space;
+        return collect(s, ws, off, info);
+      }
+    }
+    return NDI_OK;
+  }
+
   ndi_status eval(const void* q_, uint64_t nq, void* out_, uint64_t out_stride,
                   const ndi_eval_opts* opts, ndi_oob_info* info) override {
     DeviceGuard dg(device);
@@ -606,6 +686,8 @@ struct Interp1DImpl final : Interp1DBase {
     }
     // host output: stream the batch through a device staging buffer in query chunks
     const uint64_t row_bytes = lanes * sizeof(T);
+    if (lanes <= (uint64_t)SMALL_LANES && pyr.lds_bytes <= LDS_STAGE_LIMIT)
+      return eval_small_host(s, ws, q, (const T*)q_, o.q_memspace, nq, (T*)out_, out_stride, info);
     const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / row_bytes));
     ws.stage[0].reserve(chunk_q * row_bytes);
     for (uint64_t off = 0; off < nq; off += chunk_q) {

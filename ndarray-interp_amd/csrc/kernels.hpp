@@ -9,6 +9,9 @@
 //                          16-byte coalesced loads of the operand rows fused with the polynomial,
 //                          non-temporal stores                       (linear.rs:94-96, cubic_spline.rs:818-828)
 //   eval_flat_kernel       same arithmetic for short / unaligned rows: one output vector per thread
+//   eval_small_kernel / eval_small2d_kernel
+//                          <= 16 lanes with host buffers: search + evaluation fused in one launch, one query
+//                          per thread (latency path for the reference's own bench shapes)
 //   group_offsets_kernel, bucket_scan_kernel, group_scatter_kernel (+ bucket_count/_scatter fallback)
 //                          block-local counting sort of the queries by interval (LDS histograms and cursors)
 //   eval_bucketed_kernel   BUCKETED formulation: grouped order, operand rows held in registers across a
@@ -881,6 +884,72 @@ __global__ __launch_bounds__(BLOCK) void eval_bilinear_kernel(Eval2Args<T> A, ui
       const V z2 = frac_v<T, V, APPROX>(x1, a12, x2, a22, x);
       V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
       o[v] = frac_v<T, V, APPROX>(y1, z1, y2, z2, y);
+    }
+  }
+}
+
+// 2-D counterpart of eval_small_kernel: both searches and the bilinear evaluation in one launch, one query per
+// thread (lanes <= SMALL_LANES), output into a staging buffer owned by the host side.
+template <class T>
+struct EvalSmall2Args {
+  Pyramid<T> px, py;
+  const T* data;
+  const T* qx;
+  const T* qy;
+  T* out;  // [nq][lanes]
+  uint64_t nq, row_cells, cell_elems;
+  uint32_t lanes;
+  int mode;
+  unsigned long long* first_fail;  // [2]
+};
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nxa = A.px.n + A.px.n1 + A.px.n2, nya = A.py.n + A.py.n1 + A.py.n2;
+  {
+    T* sx = reinterpret_cast<T*>(smem_raw);
+    T* sy = sx + nxa;
+    for (uint32_t i = tid; i < nxa; i += BLOCK) sx[i] = A.px.lv0[i];
+    for (uint32_t i = tid; i < nya; i += BLOCK) sy[i] = A.py.lv0[i];
+  }
+  __syncthreads();
+  PyramidLds<T> PX, PY;
+  PX.lv0 = (lds_ptr<T>)(smem_raw);
+  PX.lv1 = PX.lv0 + A.px.n;
+  PX.lv2 = PX.lv1 + A.px.n1;
+  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels; PX.guess = A.px.guess;
+  PY.lv0 = PX.lv0 + nxa;
+  PY.lv1 = PY.lv0 + A.py.n;
+  PY.lv2 = PY.lv1 + A.py.n1;
+  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels; PY.guess = A.py.guess;
+  const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
+  const uint32_t lane = tid & 63u;
+  const uint32_t L = A.lanes;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK + (tid & ~63u); base < A.nq; base += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t qi = base + lane;
+    const bool active = qi < A.nq;
+    const T x = active ? A.qx[qi] : x0;
+    const T y = active ? A.qy[qi] : y0;
+    const uint32_t xi = locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
+    const uint32_t yi = locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
+    if (!active) continue;
+    const bool badx = (A.mode == EX_NO) ? !((x0 <= x) && (x <= xn)) : !(x == x);
+    const bool bady = (A.mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
+    if (badx) atomicMin(&A.first_fail[0], (unsigned long long)qi);
+    if (bady) atomicMin(&A.first_fail[1], (unsigned long long)qi);
+    if (badx || bady) continue;
+    const T x1 = PX.lv0[xi], x2 = PX.lv0[xi + 1], y1 = PY.lv0[yi], y2 = PY.lv0[yi + 1];
+    const T* z11 = A.data + ((uint64_t)xi * A.row_cells + yi) * A.cell_elems;
+    const T* z12 = z11 + L;
+    const T* z21 = A.data + ((uint64_t)(xi + 1) * A.row_cells + yi) * A.cell_elems;
+    const T* z22 = z21 + L;
+    T* o = A.out + qi * L;
+    for (uint32_t l = 0; l < L; ++l) {
+      const T z1 = frac_v<T, T>(x1, z11[l], x2, z21[l], x);
+      const T z2 = frac_v<T, T>(x1, z12[l], x2, z22[l], x);
+      o[l] = frac_v<T, T>(y1, z1, y2, z2, y);
     }
   }
 }

@@ -947,6 +947,71 @@ struct Interp2DImpl final : Interp2DBase {
     return fail(st, "%s = %.17g is not in range", axis == 0 ? "x" : "y", (double)v);
   }
 
+  // Host output with short trailing axes: one fused launch per chunk (see Interp1DImpl::eval_small_host).
+  ndi_status eval_small_host(hipStream_t s, Workspace& ws, const T* qx_dev, const T* qy_dev, const T* qx_orig,
+                             const T* qy_orig, int q_space, uint64_t nq, T* out, uint64_t out_stride,
+                             ndi_oob_info* info) {
+    const uint64_t row_bytes = lanes * sizeof(T);
+    const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (64ull << 20) / row_bytes));
+    constexpr size_t BOUNCE = 8ull << 20;
+    ws.stage[0].reserve(chunk_q * row_bytes);
+    ws.ensure_status();
+    g_last_path.store(NDI_PATH_GATHER);
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small2d_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+    });
+    StatusBlock* st = ws.status.as<StatusBlock>();
+    const size_t shmem = (px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15;
+    for (uint64_t off = 0; off < nq; off += chunk_q) {
+      const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
+      const size_t bytes = cq * row_bytes;
+      NDI_HIP(hipMemsetAsync(ws.status.p, 0xFF, 2 * sizeof(unsigned long long), s));
+      EvalSmall2Args<T> A{};
+      A.px = px.view; A.py = py.view;
+      A.data = data.as<T>();
+      A.qx = qx_dev + off; A.qy = qy_dev + off;
+      A.out = ws.stage[0].as<T>();
+      A.nq = cq;
+      A.row_cells = pair_packed ? ny - 1 : ny;
+      A.cell_elems = pair_packed ? 2 * lanes : lanes;
+      A.lanes = (uint32_t)lanes;
+      A.mode = mode;
+      A.first_fail = &st->first_fail[0];
+      const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((cq + BLOCK - 1) / BLOCK, 4096));
+      launch1<T>(s, PC_EVAL, dim3(grid), dim3(BLOCK), shmem, eval_small2d_kernel<T>, A);
+      const bool bounce = bytes <= BOUNCE;
+      if (bounce) {
+        ws.ensure_pin(BOUNCE);
+        NDI_HIP(hipMemcpyAsync(ws.pin, ws.stage[0].p, bytes, hipMemcpyDeviceToHost, s));
+      }
+      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipStreamSynchronize(s));
+      const unsigned long long ff = std::min(ws.host_status->first_fail[0], ws.host_status->first_fail[1]);
+      const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
+      T* dst = out + off * out_stride;
+      if (good) {
+        if (bounce) {
+          if (out_stride == lanes) std::memcpy(dst, ws.pin, good * row_bytes);
+          else
+            for (uint64_t r = 0; r < good; ++r)
+              std::memcpy(dst + r * out_stride, (const char*)ws.pin + r * row_bytes, row_bytes);
+        } else {
+          NDI_HIP(hipMemcpy2D(dst, out_stride * sizeof(T), ws.stage[0].p, row_bytes, row_bytes, good,
+                              hipMemcpyDeviceToHost));
+        }
+      }
+      if (ff != NO_FAIL) {
+        ws.last_q = qx_orig + off;
+        ws.last_q2 = qy_orig + off;
+        ws.last_q_space = q_space;
+        return collect(s, ws, off, info);
+      }
+    }
+    return NDI_OK;
+  }
+
   ndi_status eval(const void* qx_, const void* qy_, uint64_t nq, void* out_, uint64_t out_stride,
                   const ndi_eval_opts* opts, ndi_oob_info* info) override {
     DeviceGuard dg(device);
@@ -979,6 +1044,8 @@ struct Interp2DImpl final : Interp2DBase {
       return collect(s, ws, 0, info);
     }
     const uint64_t row_bytes = lanes * sizeof(T);
+    if (lanes <= (uint64_t)SMALL_LANES && ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15) <= LDS_STAGE_LIMIT)
+      return eval_small_host(s, ws, qx, qy, (const T*)qx_, (const T*)qy_, o.q_memspace, nq, (T*)out_, out_stride, info);
     const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / row_bytes));
     ws.stage[0].reserve(chunk_q * row_bytes);
     for (uint64_t off = 0; off < nq; off += chunk_q) {

@@ -84,7 +84,7 @@ typedef enum ndi_monotonic {
  *  GATHER   one coalesced row gather per query (4 operand rows in, 1 row out);
  *  BUCKETED queries are grouped by interval on the device so each table row is
  *           read once per group and the kernel becomes a pure output stream;
- *  AUTO     BUCKETED when the batch has enough queries per interval to pay for
+ *  AUTO     BUCKETED when the batch has enough queries per interval (>= 5) to pay for
  *           the grouping pass, else GATHER. */
 typedef enum ndi_path { NDI_PATH_AUTO = 0, NDI_PATH_GATHER = 1, NDI_PATH_BUCKETED = 2 } ndi_path;
 

@@ -473,7 +473,7 @@ struct Interp1DImpl final : Interp1DBase {
     const bool rows_ok = vec_ok && LV >= (uint64_t)BLOCK;
     bool bucketed = false;
     if (path == NDI_PATH_BUCKETED) bucketed = rows_ok && nq < 0xffffffffull;
-    else if (path == NDI_PATH_AUTO) bucketed = rows_ok && nq < 0xffffffffull && nq >= 8 * (n - 1);
+    else if (path == NDI_PATH_AUTO) bucketed = rows_ok && nq < 0xffffffffull && nq >= 5 * (n - 1);  // measured crossover (tools/auto_threshold.py)
     g_last_path.store(bucketed ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
     T* t_out = strategy == NDI_CUBIC_SPLINE ? ws.t.as<T>() : nullptr;
 

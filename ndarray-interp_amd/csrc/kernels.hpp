@@ -427,12 +427,35 @@ struct EvalSmallArgs {
   const T* ca;
   const T* cb;
   const T* q;
-  T* out;          // [nq][lanes], row stride = lanes
-  uint64_t nq;
+  T* out;          // [nq][out_stride]
+  uint64_t nq, out_stride;
   uint32_t lanes;
   int mode;        // ExtrapMode
   unsigned long long* first_fail;
+  int prechecked;  // first_fail already holds the batch's first failing query (range_check_kernel ran):
+                   // rows at or after it are skipped, so a caller-owned output keeps them untouched
 };
+
+// Range / NaN test alone (the failure conditions of locate_slice), for the fused small-lanes kernels when
+// they write straight into a caller-owned device buffer: the first failing index must be known before any
+// row is written.  Reads 1 (2) values per query.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void range_check_kernel(const T* qx, const T* qy, uint64_t nq, T x0, T xn,
+                                                            T y0, T yn, int mode, unsigned long long* first_fail) {
+  for (uint64_t qi = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; qi < nq; qi += (uint64_t)gridDim.x * BLOCK) {
+    const T x = qx[qi];
+    const bool inr = (x0 <= x) && (x <= xn);
+    T xs = x;
+    if (mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - x0, xn - x0) + x0;   // +-inf wraps to NaN, as in locate_slice
+    const bool badx = (mode == EX_NO) ? !inr : !(xs == xs);
+    if (badx) atomicMin(&first_fail[0], (unsigned long long)qi);
+    if (qy) {
+      const T y = qy[qi];
+      const bool bady = (mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
+      if (bady) atomicMin(&first_fail[1], (unsigned long long)qi);
+    }
+  }
+}
 
 template <class T, int STRAT>
 __global__ __launch_bounds__(BLOCK) void eval_small_kernel(EvalSmallArgs<T> A) {
@@ -453,9 +476,11 @@ __global__ __launch_bounds__(BLOCK) void eval_small_kernel(EvalSmallArgs<T> A) {
   const T k0 = P.lv0[0], kn = P.lv0[n - 1];
   const uint32_t lane = tid & 63u;
   const uint32_t L = A.lanes;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK + (tid & ~63u); base < A.nq; base += (uint64_t)gridDim.x * BLOCK) {
+  unsigned long long limit = A.prechecked ? *A.first_fail : NO_FAIL;
+  if (limit > A.nq) limit = A.nq;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK + (tid & ~63u); base < limit; base += (uint64_t)gridDim.x * BLOCK) {
     const uint64_t qi = base + lane;
-    const bool active = qi < A.nq;
+    const bool active = qi < limit;
     const T x = active ? A.q[qi] : k0;
     const bool inr = (k0 <= x) && (x <= kn);
     T xs = x;
@@ -464,7 +489,7 @@ __global__ __launch_bounds__(BLOCK) void eval_small_kernel(EvalSmallArgs<T> A) {
     if (!active) continue;
     const bool bad = (A.mode == EX_NO) ? !inr : !(xs == xs);
     if (bad) {
-      atomicMin(A.first_fail, (unsigned long long)qi);
+      if (!A.prechecked) atomicMin(A.first_fail, (unsigned long long)qi);
       continue;
     }
     const T xl = P.lv0[i], xr = P.lv0[i + 1];
@@ -484,7 +509,7 @@ __global__ __launch_bounds__(BLOCK) void eval_small_kernel(EvalSmallArgs<T> A) {
     const T* yr = yl + L;
     const T* pa = A.ca + (uint64_t)i * L;
     const T* pb = A.cb + (uint64_t)i * L;
-    T* o = A.out + qi * L;
+    T* o = A.out + qi * A.out_stride;
     for (uint32_t l = 0; l < L; ++l) {
       const T a = (STRAT == ST_CUBIC) ? pa[l] : T(0);
       const T b = (STRAT == ST_CUBIC) ? pb[l] : T(0);
@@ -896,11 +921,12 @@ struct EvalSmall2Args {
   const T* data;
   const T* qx;
   const T* qy;
-  T* out;  // [nq][lanes]
-  uint64_t nq, row_cells, cell_elems;
+  T* out;  // [nq][out_stride]
+  uint64_t nq, out_stride, row_cells, cell_elems;
   uint32_t lanes;
   int mode;
   unsigned long long* first_fail;  // [2]
+  int prechecked;                  // see EvalSmallArgs
 };
 
 template <class T>
@@ -927,9 +953,12 @@ __global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
   const uint32_t L = A.lanes;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK + (tid & ~63u); base < A.nq; base += (uint64_t)gridDim.x * BLOCK) {
+  unsigned long long limit = NO_FAIL;
+  if (A.prechecked) limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
+  if (limit > A.nq) limit = A.nq;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK + (tid & ~63u); base < limit; base += (uint64_t)gridDim.x * BLOCK) {
     const uint64_t qi = base + lane;
-    const bool active = qi < A.nq;
+    const bool active = qi < limit;
     const T x = active ? A.qx[qi] : x0;
     const T y = active ? A.qy[qi] : y0;
     const uint32_t xi = locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
@@ -937,15 +966,15 @@ __global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A
     if (!active) continue;
     const bool badx = (A.mode == EX_NO) ? !((x0 <= x) && (x <= xn)) : !(x == x);
     const bool bady = (A.mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
-    if (badx) atomicMin(&A.first_fail[0], (unsigned long long)qi);
-    if (bady) atomicMin(&A.first_fail[1], (unsigned long long)qi);
+    if (badx && !A.prechecked) atomicMin(&A.first_fail[0], (unsigned long long)qi);
+    if (bady && !A.prechecked) atomicMin(&A.first_fail[1], (unsigned long long)qi);
     if (badx || bady) continue;
     const T x1 = PX.lv0[xi], x2 = PX.lv0[xi + 1], y1 = PY.lv0[yi], y2 = PY.lv0[yi + 1];
     const T* z11 = A.data + ((uint64_t)xi * A.row_cells + yi) * A.cell_elems;
     const T* z12 = z11 + L;
     const T* z21 = A.data + ((uint64_t)(xi + 1) * A.row_cells + yi) * A.cell_elems;
     const T* z22 = z21 + L;
-    T* o = A.out + qi * L;
+    T* o = A.out + qi * A.out_stride;
     for (uint32_t l = 0; l < L; ++l) {
       const T z1 = frac_v<T, T>(x1, z11[l], x2, z21[l], x);
       const T z2 = frac_v<T, T>(x1, z12[l], x2, z22[l], x);

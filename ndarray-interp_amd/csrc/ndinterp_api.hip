@@ -467,6 +467,44 @@ struct Interp1DImpl final : Interp1DBase {
     A.nq = nq;
     A.status = st;
 
+    if (lanes <= 2 && pyr.lds_bytes <= LDS_STAGE_LIMIT) {   // one thread per query only pays for 1-2 lanes
+      // short trailing axes: range pre-check (so rows after the first failing query stay untouched in the
+      // caller's buffer), then search + evaluation fused in one launch -- no index / t round trip through HBM
+      g_last_path.store(NDI_PATH_GATHER);
+      const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+      {
+        ProfScope ps(s, PC_LOCATE);
+        hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, q, (const T*)nullptr, nq, k0, kn, k0, kn,
+                           mode, &st->first_fail[0]);
+        NDI_HIP(hipGetLastError());
+        ps.done();
+      }
+      static std::once_flag once;
+      std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+      });
+      EvalSmallArgs<T> S{};
+      S.pyr = pyr.view;
+      S.data = data.as<T>();
+      S.ca = ca.as<T>();
+      S.cb = cb.as<T>();
+      S.q = q;
+      S.out = out;
+      S.nq = nq;
+      S.out_stride = out_stride;
+      S.lanes = (uint32_t)lanes;
+      S.mode = mode;
+      S.first_fail = &st->first_fail[0];
+      S.prechecked = 1;
+      const size_t shmem = (pyr.lds_bytes + 15) & ~(size_t)15;
+      if (strategy == NDI_CUBIC_SPLINE) launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), shmem, eval_small_kernel<T, ST_CUBIC>, S);
+      else launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), shmem, eval_small_kernel<T, ST_LINEAR>, S);
+      return;
+    }
     constexpr int VN = Wide<T>::N;
     const bool vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
     const uint64_t LV = vec_ok ? lanes / VN : lanes;
@@ -577,8 +615,10 @@ struct Interp1DImpl final : Interp1DBase {
       NDI_HIP(hipMemcpy(&v, (const T*)ws.last_q + ff, sizeof(T), hipMemcpyDeviceToHost));
     else
       v = ((const T*)ws.last_q)[ff];
-    const bool is_nan = !(v == v);
-    const ndi_status st = (mode != EX_NO && is_nan) ? NDI_NAN_QUERY : NDI_OUT_OF_BOUNDS;
+    // without extrapolation every failure is a range failure (NaN included: "x = NaN is not in range");
+    // with it the only failure is the search meeting a NaN -- the query itself or an infinite query that the
+    // periodic wrap turned into NaN (the reference panics: vector_extensions.rs:83-84)
+    const ndi_status st = (mode != EX_NO) ? NDI_NAN_QUERY : NDI_OUT_OF_BOUNDS;
     if (info) {
       info->index = index_offset + ff;
       info->value = (double)v;
@@ -621,9 +661,11 @@ struct Interp1DImpl final : Interp1DBase {
       A.q = q_dev + off;
       A.out = ws.stage[0].as<T>();
       A.nq = cq;
+      A.out_stride = lanes;
       A.lanes = (uint32_t)lanes;
       A.mode = mode;
       A.first_fail = &st->first_fail[0];
+      A.prechecked = 0;
       const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((cq + BLOCK - 1) / BLOCK, 4096));
       const size_t shmem = (pyr.lds_bytes + 15) & ~(size_t)15;
       if (strategy == NDI_CUBIC_SPLINE) launch1<T>(s, PC_EVAL, dim3(grid), dim3(BLOCK), shmem, eval_small_kernel<T, ST_CUBIC>, A);
@@ -816,6 +858,39 @@ struct Interp2DImpl final : Interp2DBase {
     reset_status(ws, s);
     StatusBlock* st = ws.status.as<StatusBlock>();
     const size_t both = ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15);
+    if (lanes <= 2 && both <= LDS_STAGE_LIMIT && path != NDI_PATH_BUCKETED) {
+      // short trailing axes: range pre-check, then both searches + evaluation fused in one launch
+      g_last_path.store(NDI_PATH_GATHER);
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+      {
+        ProfScope ps(s, PC_LOCATE);
+        hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
+                           px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode,
+                           &st->first_fail[0]);
+        NDI_HIP(hipGetLastError());
+        ps.done();
+      }
+      static std::once_flag once;
+      std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small2d_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
+      });
+      EvalSmall2Args<T> S{};
+      S.px = px.view; S.py = py.view;
+      S.data = data.as<T>();
+      S.qx = qx; S.qy = qy;
+      S.out = out;
+      S.nq = nq;
+      S.out_stride = out_stride;
+      S.row_cells = pair_packed ? ny - 1 : ny;
+      S.cell_elems = pair_packed ? 2 * lanes : lanes;
+      S.lanes = (uint32_t)lanes;
+      S.mode = mode;
+      S.first_fail = &st->first_fail[0];
+      S.prechecked = 1;
+      launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), both, eval_small2d_kernel<T>, S);
+      return;
+    }
     if (both <= LDS_STAGE_LIMIT) {   // both axes in one launch
       Locate2Args<T> LA{};
       LA.px = px.view; LA.py = py.view;
@@ -935,8 +1010,10 @@ struct Interp2DImpl final : Interp2DBase {
       NDI_HIP(hipMemcpy(&v, (const T*)src + ff, sizeof(T), hipMemcpyDeviceToHost));
     else
       v = ((const T*)src)[ff];
-    const bool is_nan = !(v == v);
-    const ndi_status st = (mode != EX_NO && is_nan) ? NDI_NAN_QUERY : NDI_OUT_OF_BOUNDS;
+    // without extrapolation every failure is a range failure (NaN included: "x = NaN is not in range");
+    // with it the only failure is the search meeting a NaN -- the query itself or an infinite query that the
+    // periodic wrap turned into NaN (the reference panics: vector_extensions.rs:83-84)
+    const ndi_status st = (mode != EX_NO) ? NDI_NAN_QUERY : NDI_OUT_OF_BOUNDS;
     if (info) {
       info->index = index_offset + ff;
       info->value = (double)v;
@@ -974,11 +1051,13 @@ struct Interp2DImpl final : Interp2DBase {
       A.qx = qx_dev + off; A.qy = qy_dev + off;
       A.out = ws.stage[0].as<T>();
       A.nq = cq;
+      A.out_stride = lanes;
       A.row_cells = pair_packed ? ny - 1 : ny;
       A.cell_elems = pair_packed ? 2 * lanes : lanes;
       A.lanes = (uint32_t)lanes;
       A.mode = mode;
       A.first_fail = &st->first_fail[0];
+      A.prechecked = 0;
       const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((cq + BLOCK - 1) / BLOCK, 4096));
       launch1<T>(s, PC_EVAL, dim3(grid), dim3(BLOCK), shmem, eval_small2d_kernel<T>, A);
       const bool bounce = bytes <= BOUNCE;

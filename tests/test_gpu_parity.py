@@ -862,3 +862,49 @@ def test_full_size_c5_share_bilinear(pkg):
     _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx[pick], qy[pick])
     assert np.array_equal(out[torch.as_tensor(pick, device=dev)].cpu().numpy(), ref)
     assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+
+
+def test_small_lanes_device_buffers_keep_first_error_semantics(pkg):
+    """<= 16 lanes with device-resident buffers run the fused kernel behind a range pre-check: rows at or after
+    the first failing query must stay untouched in the caller's buffer, exactly as on the two-kernel path."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(17)
+    for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        for L in (1, 2, 5):
+            n, Q = 300, 50000
+            x = knots("rand", n, rng, dt); y = rng.uniform(-1, 1, (n, L)).astype(dt)
+            q = rng.uniform(x[0], x[-1], Q).astype(dt)
+            st, a, b = oracle.cubic_build(x, y)
+            _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+            it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
+                .strategy(pkg.CubicSpline.new()).build()
+            out = it.interp_array(torch.as_tensor(q, device=dev))
+            check_equal(out.cpu().numpy().reshape(Q, L), ref, f"small lanes device L={L}")
+            q[30000] = x[-1] + 1; q[41000] = x[0] - 1
+            buf = torch.full((Q, L), -4.0, dtype=tdt, device=dev)
+            with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+                it.interp_array_into(torch.as_tensor(q, device=dev), buf)
+            assert ei.value.index == 30000
+            h = buf.cpu().numpy()
+            assert np.array_equal(h[:30000], ref[:30000]) and np.all(h[30000:] == -4.0)
+    # periodic + extrapolate: an infinite query wraps to NaN -> panic-equivalent, as on the CPU
+    x = np.arange(6.0); y = np.array([1.0, 2.0, 0.5, 3.0, 2.0, 1.0])
+    per = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).strategy(
+        pkg.CubicSpline.new().extrapolate(True).boundary(pkg.BoundaryCondition.Periodic)).build()
+    with pytest.raises(pkg.Panic):
+        per.interp_array(torch.as_tensor(np.array([0.5, np.inf, 2.0]), device=dev))
+    # 2-D
+    g = rng.uniform(0, 1, (20, 30, 2)); Q = 30000
+    qx = rng.uniform(0, 19, Q); qy = rng.uniform(0, 29, Q)
+    _, _, _, ref = oracle.interp2d_bilinear(np.arange(20.0), np.arange(30.0), g, qx, qy)
+    it2 = pkg.Interp2D.builder(torch.as_tensor(g, device=dev)).build()
+    out = it2.interp_array(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev))
+    check_equal(out.cpu().numpy(), ref, "small lanes device 2-D")
+    qy[12345] = 99.0; qx[20000] = -1.0
+    buf = torch.full((Q, 2), -4.0, dtype=torch.float64, device=dev)
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        it2.interp_array_into(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), buf)
+    assert (ei.value.index, ei.value.axis) == (12345, 1)
+    h = buf.cpu().numpy()
+    assert np.array_equal(h[:12345], ref[:12345]) and np.all(h[12345:] == -4.0)

@@ -908,3 +908,49 @@ def test_small_lanes_device_buffers_keep_first_error_semantics(pkg):
     assert (ei.value.index, ei.value.axis) == (12345, 1)
     h = buf.cpu().numpy()
     assert np.array_equal(h[:12345], ref[:12345]) and np.all(h[12345:] == -4.0)
+
+
+def test_unaligned_device_buffers_and_two_streams(pkg):
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(23)
+    n, L, Q = 80, 1024, 3000
+    x = knots("rand", n, rng, np.float64); y = rng.uniform(-1, 1, (n, L)); q = rng.uniform(x[0], x[-1], Q)
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+    it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
+        .strategy(pkg.CubicSpline.new()).build()
+    qd = torch.as_tensor(q, device=dev)
+    # output that starts 8 bytes into an allocation (not 16-byte aligned) with an odd row stride:
+    # the library must fall back to scalar accesses, for both formulations
+    big = torch.full((Q * (L + 1) + 8,), -1.0, dtype=torch.float64, device=dev)
+    view = big[1:1 + Q * (L + 1)].view(Q, L + 1)[:, :L]
+    assert view.data_ptr() % 16 == 8 and view.stride(0) == L + 1
+    for path in (pkg.PATH_GATHER, pkg.PATH_BUCKETED):
+        it.strategy.path = path
+        big.fill_(-1.0)
+        it.strategy.interp_array_into(it, qd, view)
+        h = big.cpu().numpy()
+        got = h[1:1 + Q * (L + 1)].reshape(Q, L + 1)
+        assert np.array_equal(got[:, :L], ref) and np.all(got[:, L] == -1.0) and h[0] == -1.0
+    # two streams, one handle, one host thread: each stream has its own scratch and status
+    it.strategy.path = pkg.PATH_AUTO
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    q2 = rng.uniform(x[0], x[-1], Q); q2[77] = x[-1] + 1.0
+    _, _, ref2 = oracle.interp1d_cubic(x, y, a, b, q2[:77])
+    o1 = torch.zeros((Q, L), dtype=torch.float64, device=dev); o2 = torch.full((Q, L), -9.0, dtype=torch.float64, device=dev)
+    q2d = torch.as_tensor(q2, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        it.strategy.interp_array_into(it, qd, o1, async_launch=True)
+    with torch.cuda.stream(s2):
+        it.strategy.interp_array_into(it, q2d, o2, async_launch=True)
+    with torch.cuda.stream(s1):
+        it.strategy.finish()                       # stream 1: clean batch
+    with torch.cuda.stream(s2):
+        with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+            it.strategy.finish()                   # stream 2: its own first error
+    assert ei.value.index == 77
+    assert np.array_equal(o1.cpu().numpy(), ref)
+    h2 = o2.cpu().numpy()
+    assert np.array_equal(h2[:77], ref2) and np.all(h2[77:] == -9.0)

@@ -84,7 +84,8 @@ __device__ __forceinline__ double rem_euclid_t(double a, double b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// locate: knot pyramid  lv0 = knots[n], lv1[j] = knots[64 j], lv2[j] = knots[4096 j]
+// locate: knot pyramid  lv0 = knots[n], lv1[j] = knots[j * block]  (block = power of two with 64*block >= n,
+// so the top level never has more than 64 entries: one per lane); lv2 / n2 are unused (n2 = 0)
 // ---------------------------------------------------------------------------------------------
 template <class T, class PTR>
 struct PyramidT {
@@ -92,8 +93,9 @@ struct PyramidT {
   PTR lv1;
   PTR lv2;
   uint32_t n, n1, n2;
-  int levels;  // 1, 2 or 3
+  int levels;  // 1 (n <= 64: the knots themselves are the top level) or 2
   int guess;   // axis is close to evenly spaced: try the O(1) index guess first
+  uint32_t block;  // knots per top-level entry (power of two)
 };
 template <class T>
 using Pyramid = PyramidT<T, const T*>;                      // global memory
@@ -117,15 +119,14 @@ __device__ __forceinline__ double lane_gather(double v, uint32_t src_lane) {
 //  * top pyramid level (<= 64 entries): the wave holds the level in registers, one entry per lane, and
 //    every lane bisects over it with cross-lane gathers (ds_bpermute) -- 64 queries are ranked against
 //    the whole level in 7 exchange steps with no memory access at all;
-//  * each lower level: the 64-entry block selected by the level above is searched by the lane itself
-//    with a 6-step branch-free bisection in LDS (the block's first entry is known to be <= x).
+//  * the block of `block` knots selected by the top level is searched by the lane itself with a
+//    log2(block)-step branch-free bisection in LDS (the block's first entry is known to be <= x).
 // NaN compares false everywhere -> 0.
 template <class T, class PTR>
-__device__ __forceinline__ uint32_t block_last_le(PTR blk, uint32_t len, T x) {
+__device__ __forceinline__ uint32_t block_last_le(PTR blk, uint32_t len, uint32_t block, T x) {
   uint32_t lo = 0;  // invariant: blk[lo] <= x
   const uint32_t last = len - 1u;
-#pragma unroll
-  for (uint32_t step = 32; step >= 1; step >>= 1) {
+  for (uint32_t step = block >> 1; step >= 1; step >>= 1) {   // log2(block) steps, wave-uniform trip count
     const uint32_t probe = lo + step;
     const T v = blk[probe < last ? probe : last];  // unconditional (clamped) read: no divergent branch
     lo = (probe <= last && v <= x) ? probe : lo;
@@ -139,10 +140,7 @@ __device__ __forceinline__ uint32_t wave_count_le(const PyramidT<T, PTR>& P, T x
   // struct's pointer members makes the compiler spill the struct to scratch and index it at run time.
   T mine;
   uint32_t last;
-  if (P.levels == 3) {
-    last = P.n2 - 1u;
-    mine = P.lv2[lane < last ? lane : last];
-  } else if (P.levels == 2) {
+  if (P.levels == 2) {
     last = P.n1 - 1u;
     mine = P.lv1[lane < last ? lane : last];
   } else {
@@ -160,15 +158,9 @@ __device__ __forceinline__ uint32_t wave_count_le(const PyramidT<T, PTR>& P, T x
   }
   if (!any) return 0;
   if (P.levels == 1) return lo + 1u;
-  uint32_t i = lo;  // index (within the level just searched) of the last entry <= x
-  if (P.levels == 3) {
-    const uint32_t base = i * 64u;
-    const uint32_t len = (P.n1 - base < 64u) ? P.n1 - base : 64u;
-    i = base + block_last_le<T, PTR>(P.lv1 + base, len, x);
-  }
-  const uint32_t base = i * 64u;
-  const uint32_t len = (P.n - base < 64u) ? P.n - base : 64u;
-  return base + block_last_le<T, PTR>(P.lv0 + base, len, x) + 1u;
+  const uint32_t base = lo * P.block;
+  const uint32_t len = (P.n - base < P.block) ? P.n - base : P.block;
+  return base + block_last_le<T, PTR>(P.lv0 + base, len, P.block, x) + 1u;
 }
 
 // Interval index of one query per lane: the O(1) guess of the reference for evenly spaced axes
@@ -280,7 +272,7 @@ __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
     P.lv0 = (lds_ptr<T>)(smem_raw);
     P.lv1 = P.lv0 + n;
     P.lv2 = P.lv1 + n1;
-    P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels; P.guess = A.pyr.guess;
+    P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
     locate_slice<T, lds_ptr<T>>(A, P, s_hist);
   } else {
     locate_slice<T, const T*>(A, A.pyr, s_hist);
@@ -321,11 +313,11 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   PX.lv0 = (lds_ptr<T>)(smem_raw);
   PX.lv1 = PX.lv0 + A.px.n;
   PX.lv2 = PX.lv1 + A.px.n1;
-  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels; PX.guess = A.px.guess;
+  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
   PY.lv0 = PX.lv0 + nxa;
   PY.lv1 = PY.lv0 + A.py.n;
   PY.lv2 = PY.lv1 + A.py.n1;
-  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels; PY.guess = A.py.guess;
+  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
   const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
@@ -472,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void eval_small_kernel(EvalSmallArgs<T> A) {
   P.lv0 = (lds_ptr<T>)(smem_raw);
   P.lv1 = P.lv0 + n;
   P.lv2 = P.lv1 + n1;
-  P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels; P.guess = A.pyr.guess;
+  P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
   const T k0 = P.lv0[0], kn = P.lv0[n - 1];
   const uint32_t lane = tid & 63u;
   const uint32_t L = A.lanes;
@@ -945,11 +937,11 @@ __global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A
   PX.lv0 = (lds_ptr<T>)(smem_raw);
   PX.lv1 = PX.lv0 + A.px.n;
   PX.lv2 = PX.lv1 + A.px.n1;
-  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels; PX.guess = A.px.guess;
+  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
   PY.lv0 = PX.lv0 + nxa;
   PY.lv1 = PY.lv0 + A.py.n;
   PY.lv2 = PY.lv1 + A.py.n1;
-  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels; PY.guess = A.py.guess;
+  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
   const uint32_t L = A.lanes;

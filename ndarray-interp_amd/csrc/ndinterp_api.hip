@@ -112,12 +112,12 @@ struct DevicePyramid {
 
   void upload(const T* knots, uint64_t n) {
     host_knots.assign(knots, knots + n);
-    const uint32_t n1 = (uint32_t)((n + 63) / 64);
-    const uint32_t n2 = (uint32_t)((n1 + 63) / 64);
-    std::vector<T> all(n + n1 + n2);
+    uint32_t block = 1;
+    while ((uint64_t)64 * block < n) block *= 2;          // top level <= 64 entries: one per lane
+    const uint32_t n1 = (uint32_t)((n + block - 1) / block);
+    std::vector<T> all(n + n1);
     std::copy(knots, knots + n, all.begin());
-    for (uint32_t j = 0; j < n1; ++j) all[n + j] = knots[(uint64_t)j * 64];
-    for (uint32_t j = 0; j < n2; ++j) all[n + n1 + j] = knots[(uint64_t)j * 4096];
+    for (uint32_t j = 0; j < n1; ++j) all[n + j] = knots[(uint64_t)j * block];
     buf.reserve(all.size() * sizeof(T));
     NDI_HIP(hipMemcpy(buf.p, all.data(), all.size() * sizeof(T), hipMemcpyHostToDevice));
     view.lv0 = buf.as<T>();
@@ -125,8 +125,9 @@ struct DevicePyramid {
     view.lv2 = view.lv1 + n1;
     view.n = (uint32_t)n;
     view.n1 = n1;
-    view.n2 = n2;
-    view.levels = (n <= 64) ? 1 : (n <= 4096 ? 2 : 3);
+    view.n2 = 0;
+    view.block = block;
+    view.levels = (n <= 64) ? 1 : 2;
     // evenly spaced within less than half a step everywhere -> the reference's O(1) guess will mostly be right
     bool even = n >= 2;
     const double step = ((double)knots[n - 1] - (double)knots[0]) / (double)(n - 1);
@@ -137,7 +138,7 @@ struct DevicePyramid {
   }
 };
 
-constexpr uint64_t MAX_KNOTS = 64ull * 64ull * 64ull;   // three pyramid levels
+constexpr uint64_t MAX_KNOTS = (1ull << 31) - 1;          // interval indices are 32-bit
 constexpr size_t LDS_STAGE_LIMIT = 150 * 1024;          // of the CU's 160 KiB
 
 // ---------------------------------------------------------------------------------------------

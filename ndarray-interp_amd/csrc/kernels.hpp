@@ -306,7 +306,7 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   const uint32_t nxa = A.px.n + A.px.n1 + A.px.n2, nya = A.py.n + A.py.n1 + A.py.n2;
   T* sx = reinterpret_cast<T*>(smem_raw);
   T* sy = sx + nxa;
-  for (uint32_t i = tid; i < nxa; i += blockDim.x) sx[i] = A.px.lv0[i];   // the three levels are one allocation
+  for (uint32_t i = tid; i < nxa; i += blockDim.x) sx[i] = A.px.lv0[i];   // the levels are one allocation
   for (uint32_t i = tid; i < nya; i += blockDim.x) sy[i] = A.py.lv0[i];
   __syncthreads();
   PyramidLds<T> PX, PY;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void eval_small_kernel(EvalSmallArgs<T> A) {
   const uint32_t n = A.pyr.n, n1 = A.pyr.n1, n2 = A.pyr.n2;
   {
     T* s0 = reinterpret_cast<T*>(smem_raw);
-    const uint32_t total = n + n1 + n2;   // the three levels are one allocation
+    const uint32_t total = n + n1 + n2;   // the levels are one allocation
     for (uint32_t i = tid; i < total; i += BLOCK) s0[i] = A.pyr.lv0[i];
   }
   __syncthreads();

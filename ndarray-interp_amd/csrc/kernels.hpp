@@ -85,14 +85,13 @@ __device__ __forceinline__ double rem_euclid_t(double a, double b) {
 
 // ---------------------------------------------------------------------------------------------
 // locate: knot pyramid  lv0 = knots[n], lv1[j] = knots[j * block]  (block = power of two with 64*block >= n,
-// so the top level never has more than 64 entries: one per lane); lv2 / n2 are unused (n2 = 0)
+// so the top level never has more than 64 entries: one per lane)
 // ---------------------------------------------------------------------------------------------
 template <class T, class PTR>
 struct PyramidT {
   PTR lv0;
   PTR lv1;
-  PTR lv2;
-  uint32_t n, n1, n2;
+  uint32_t n, n1;
   int levels;  // 1 (n <= 64: the knots themselves are the top level) or 2
   int guess;   // axis is close to evenly spaced: try the O(1) index guess first
   uint32_t block;  // knots per top-level entry (power of two)
@@ -252,15 +251,13 @@ __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
   const uint32_t tid = threadIdx.x;
   uint32_t* s_hist = nullptr;
   size_t hist_off = 0;
-  const uint32_t n = A.pyr.n, n1 = A.pyr.n1, n2 = A.pyr.n2;
+  const uint32_t n = A.pyr.n, n1 = A.pyr.n1;
   if (STAGE) {
     T* s0 = reinterpret_cast<T*>(smem_raw);
     T* s1 = s0 + n;
-    T* s2 = s1 + n1;
     for (uint32_t i = tid; i < n; i += blockDim.x) s0[i] = A.pyr.lv0[i];
     for (uint32_t i = tid; i < n1; i += blockDim.x) s1[i] = A.pyr.lv1[i];
-    for (uint32_t i = tid; i < n2; i += blockDim.x) s2[i] = A.pyr.lv2[i];
-    hist_off = ((size_t)(n + n1 + n2) * sizeof(T) + 15u) & ~(size_t)15u;
+    hist_off = ((size_t)(n + n1) * sizeof(T) + 15u) & ~(size_t)15u;
   }
   if (A.hist) {
     s_hist = reinterpret_cast<uint32_t*>(smem_raw + hist_off);
@@ -271,8 +268,7 @@ __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
     PyramidLds<T> P;
     P.lv0 = (lds_ptr<T>)(smem_raw);
     P.lv1 = P.lv0 + n;
-    P.lv2 = P.lv1 + n1;
-    P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
+    P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
     locate_slice<T, lds_ptr<T>>(A, P, s_hist);
   } else {
     locate_slice<T, const T*>(A, A.pyr, s_hist);
@@ -303,7 +299,7 @@ template <class T>
 __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x;
-  const uint32_t nxa = A.px.n + A.px.n1 + A.px.n2, nya = A.py.n + A.py.n1 + A.py.n2;
+  const uint32_t nxa = A.px.n + A.px.n1, nya = A.py.n + A.py.n1;
   T* sx = reinterpret_cast<T*>(smem_raw);
   T* sy = sx + nxa;
   for (uint32_t i = tid; i < nxa; i += blockDim.x) sx[i] = A.px.lv0[i];   // the levels are one allocation
@@ -312,12 +308,10 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   PyramidLds<T> PX, PY;
   PX.lv0 = (lds_ptr<T>)(smem_raw);
   PX.lv1 = PX.lv0 + A.px.n;
-  PX.lv2 = PX.lv1 + A.px.n1;
-  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
+  PX.n = A.px.n; PX.n1 = A.px.n1; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
   PY.lv0 = PX.lv0 + nxa;
   PY.lv1 = PY.lv0 + A.py.n;
-  PY.lv2 = PY.lv1 + A.py.n1;
-  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
+  PY.n = A.py.n; PY.n1 = A.py.n1; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
   const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
@@ -453,18 +447,17 @@ template <class T, int STRAT>
 __global__ __launch_bounds__(BLOCK) void eval_small_kernel(EvalSmallArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x;
-  const uint32_t n = A.pyr.n, n1 = A.pyr.n1, n2 = A.pyr.n2;
+  const uint32_t n = A.pyr.n, n1 = A.pyr.n1;
   {
     T* s0 = reinterpret_cast<T*>(smem_raw);
-    const uint32_t total = n + n1 + n2;   // the levels are one allocation
+    const uint32_t total = n + n1;   // the levels are one allocation
     for (uint32_t i = tid; i < total; i += BLOCK) s0[i] = A.pyr.lv0[i];
   }
   __syncthreads();
   PyramidLds<T> P;
   P.lv0 = (lds_ptr<T>)(smem_raw);
   P.lv1 = P.lv0 + n;
-  P.lv2 = P.lv1 + n1;
-  P.n = n; P.n1 = n1; P.n2 = n2; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
+  P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
   const T k0 = P.lv0[0], kn = P.lv0[n - 1];
   const uint32_t lane = tid & 63u;
   const uint32_t L = A.lanes;
@@ -925,7 +918,7 @@ template <class T>
 __global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x;
-  const uint32_t nxa = A.px.n + A.px.n1 + A.px.n2, nya = A.py.n + A.py.n1 + A.py.n2;
+  const uint32_t nxa = A.px.n + A.px.n1, nya = A.py.n + A.py.n1;
   {
     T* sx = reinterpret_cast<T*>(smem_raw);
     T* sy = sx + nxa;
@@ -936,12 +929,10 @@ __global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A
   PyramidLds<T> PX, PY;
   PX.lv0 = (lds_ptr<T>)(smem_raw);
   PX.lv1 = PX.lv0 + A.px.n;
-  PX.lv2 = PX.lv1 + A.px.n1;
-  PX.n = A.px.n; PX.n1 = A.px.n1; PX.n2 = A.px.n2; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
+  PX.n = A.px.n; PX.n1 = A.px.n1; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
   PY.lv0 = PX.lv0 + nxa;
   PY.lv1 = PY.lv0 + A.py.n;
-  PY.lv2 = PY.lv1 + A.py.n1;
-  PY.n = A.py.n; PY.n1 = A.py.n1; PY.n2 = A.py.n2; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
+  PY.n = A.py.n; PY.n1 = A.py.n1; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
   const uint32_t L = A.lanes;

@@ -122,10 +122,8 @@ struct DevicePyramid {
     NDI_HIP(hipMemcpy(buf.p, all.data(), all.size() * sizeof(T), hipMemcpyHostToDevice));
     view.lv0 = buf.as<T>();
     view.lv1 = view.lv0 + n;
-    view.lv2 = view.lv1 + n1;
     view.n = (uint32_t)n;
     view.n1 = n1;
-    view.n2 = 0;
     view.block = block;
     view.levels = (n <= 64) ? 1 : 2;
     // evenly spaced within less than half a step everywhere -> the reference's O(1) guess will mostly be right

@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
   }
   CK(hipMemset(d_st, 0xFF, 16)); CK(hipMemset((char*)d_st + 16, 0, sizeof(StatusBlock) - 16));
   LocateArgs<double> LA{};
-  LA.pyr = Pyramid<double>{d_pyr, d_pyr + n, d_pyr + n + n1, (uint32_t)n, n1, 0, 2, 0, 64};
+  LA.pyr = Pyramid<double>{d_pyr, d_pyr + n, (uint32_t)n, n1, 2, 0, 64};
   LA.q = d_q; LA.nq = Q; LA.idx = d_idx; LA.t = d_t; LA.first_fail = &d_st->first_fail[0]; LA.mode = EX_NO; LA.stage_lds = 1;
   const size_t lds = (pyr.size() * 8 + 15) & ~(size_t)15;
   for (unsigned blocks : {256u, 512u, 1024u, 2048u}) {

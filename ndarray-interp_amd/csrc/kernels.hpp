@@ -1003,139 +1003,189 @@ struct BuildArgs {
 // PER_LANE: BoundaryCondition::Individual -- every lane selects its own end kinds / values and the
 // matching precomputed elimination plan (arithmetic per lane identical to a scalar solve of that column,
 // which is what solve_for_k_individual :370-403 does).
-// The recurrences are serial in i, so a lane's time is latency: rows are processed in blocks of SB --
-// all loads of a block are issued together (one memory round trip per SB rows instead of one per row) and the
-// right-hand sides, which do not depend on the recurrence, are formed before the SB dependent updates.
-// Per element the operations and their order are exactly those of the row-by-row form.
+// SPLINE_GENERAL is two kernels.
+//  spline_rhs_kernel    every right-hand side of the system (rows 0 .. n-1: boundary rows :597-670, interior rows
+//                       :456-471) -- none depends on the recurrence, so this part is fully parallel, one thread per
+//                       (row, lane).  Rows 0..n-2 go to the `a` table, row n-1 to the last row of the `b` table
+//                       (both are scratch until the back substitution overwrites them).
+//  spline_build_general_kernel
+//                       the serial part, one lane per thread: thomas :678-721 (forward elimination of the
+//                       right-hand sides with the shared factors, back substitution) fused with a/b :354-365.
+//                       Rows are processed SB at a time with the next block's loads already in flight.
+// Per element the operations and their order are exactly those of the reference's row-by-row form.
+// PER_LANE: BoundaryCondition::Individual -- every lane selects its own end kinds / values and the matching
+// precomputed elimination plan (what solve_for_k_individual :370-403 does one column at a time).
 constexpr int SB = 16;
+
+template <class T, bool PER_LANE>
+__global__ __launch_bounds__(BLOCK) void spline_rhs_kernel(BuildArgs<T> A) {
+  const uint64_t n = A.n, L = A.lanes;
+  const T two = T(2), three = T(3);
+  const uint64_t total = n * L;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t i = e / L, l = e - i * L;
+    const T* y = A.data + l;
+    int lk = A.left_kind, rk = A.right_kind;
+    T lval = A.left_val, rval = A.right_val;
+    if (PER_LANE) {
+      const uint32_t cls = A.lane_cls[l];
+      lk = (int)(cls & 3u);
+      rk = (int)(cls >> 2);
+      lval = A.lane_lval[l];
+      rval = A.lane_rval[l];
+    }
+    T r;
+    if (i == 0) {
+      const T y0 = y[0], y1 = y[L], y2 = y[2 * L];
+      const T dx0 = A.dx[0], dx1 = A.dx[1];
+      if (lk == 0) r = (A.nkL_tmp1 * (y1 - y0) / dx0 + A.dx0_sq * (y2 - y1) / dx1) / A.nkL_d;
+      else if (lk == 1) r = lval;
+      else if (lk == 2) r = three * (y1 - y0) - lval * A.dx0_sq / two;
+      else r = ((y1 - y0) / dx0) * two;                                  // parabola rows (:592), n == 3 only
+    } else if (i + 1 == n) {
+      const T ym = y[(n - 3) * L], yc = y[(n - 2) * L], yp = y[(n - 1) * L];
+      const T dxl = A.dx[n - 2], dxl2 = A.dx[n - 3];
+      if (rk == 0) r = (A.dxl_sq * (yc - ym) / dxl2 + A.nkR_tmp1 * (yp - yc) / dxl) / A.nkR_d;
+      else if (rk == 1) r = rval;
+      else if (rk == 2) r = three * (yp - yc) + rval * A.dxl_sq / two;
+      else r = ((yp - yc) / dxl) * two;                                  // parabola rows (:595)
+    } else {
+      const T a0 = y[(i - 1) * L], a1 = y[i * L], a2 = y[(i + 1) * L];
+      const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
+      if (PER_LANE && lk == 3) r = (((a2 - a1) / A.dx[1]) * A.dx[0] + ((a1 - a0) / A.dx[0]) * A.dx[1]) * three;  // :593-594
+      else r = three * (dxn * (a1 - a0) / dxn_1 + dxn_1 * (a2 - a1) / dxn);
+    }
+    if (i + 1 == n) A.cb[(n - 2) * L + l] = r;
+    else A.ca[i * L + l] = r;
+  }
+}
 
 template <class T, bool PER_LANE>
 __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A) {
   const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= A.lanes) return;
   const uint64_t n = A.n, L = A.lanes;
-  const T two = T(2), three = T(3);
   const T* y = A.data + l;
   T* sa = A.ca + l;
   T* sb = A.cb + l;
-  int lk = A.left_kind, rk = A.right_kind;
-  T lval = A.left_val, rval = A.right_val;
   const T* w = A.w;
   const T* midp = A.midp;
   T up0 = A.up[0], w_last = A.w[n - 1], mid_last = A.midp[n - 1];
   if (PER_LANE) {
     const uint32_t cls = A.lane_cls[l];
-    lk = (int)(cls & 3u);
-    rk = (int)(cls >> 2);
-    lval = A.lane_lval[l];
-    rval = A.lane_rval[l];
+    const int lk = (int)(cls & 3u), rk = (int)(cls >> 2);
     w = A.w4 + (uint64_t)lk * n;
     midp = A.midp4 + (uint64_t)lk * n;
     up0 = A.up0_4[lk];
     w_last = A.wl[lk * 4 + rk];
     mid_last = A.midl[lk * 4 + rk];
   }
-  T ym = y[0], yc = y[L], yp = y[2 * L];
-  const T dx0 = A.dx[0], dx1 = A.dx[1];
-  T r_prev;
-  if (lk == 0) {
-    r_prev = (A.nkL_tmp1 * (yc - ym) / dx0 + A.dx0_sq * (yp - yc) / dx1) / A.nkL_d;
-  } else if (lk == 1) {
-    r_prev = lval;
-  } else if (lk == 2) {
-    r_prev = three * (yc - ym) - lval * A.dx0_sq / two;
-  } else {  // parabola rows (:592), n == 3 only
-    r_prev = ((yc - ym) / dx0) * two;
-  }
-  sa[0] = r_prev;
-  // ---- forward sweep over the interior rows 1 .. n-2, SB rows at a time.
-  // On entry to a block starting at row i0: ym = y[i0-1], yc = y[i0]; the block needs y[i0+1 .. i0+cnt].
-  for (uint64_t i0 = 1; i0 + 1 < n; i0 += SB) {
-    const uint64_t left = n - 1 - i0;  // interior rows remaining
-    const int cnt = left < (uint64_t)SB ? (int)left : SB;
-    T yn[SB];
-#pragma unroll
-    for (int b = 0; b < SB; ++b)
-      if (b < cnt) yn[b] = y[(i0 + 1 + b) * L];
-    T rhs[SB];
+  const T rhs_last = sb[(n - 2) * L];
+  // The per-row factors (w, up, mid', dx) are fetched per block together with the rows, *before* the block's
+  // stores: they cannot be scalar loads (the compiler cannot prove they do not alias the tables being written)
+  // and a load placed after a store waits for that store (vmcnt is in-order and counts stores on CDNA4).
+  // ---- forward elimination of the right-hand sides, rows 1 .. n-2 (row 0 stays as it is)
+  T r_prev = sa[0];
+  T rn[SB], wn[SB];
+  {
+    const uint64_t left0 = n - 2;
+    const int cnt0 = left0 < (uint64_t)SB ? (int)left0 : SB;
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
-      if (b < cnt) {
-        const uint64_t i = i0 + b;
-        const T a0 = (b == 0) ? ym : ((b == 1) ? yc : yn[b >= 2 ? b - 2 : 0]);   // y[i-1]
-        const T a1 = (b == 0) ? yc : yn[b >= 1 ? b - 1 : 0];                      // y[i]
-        const T a2 = yn[b];                                                       // y[i+1]
-        const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
-        if (PER_LANE && lk == 3) rhs[b] = (((a2 - a1) / dx1) * dx0 + ((a1 - a0) / dx0) * dx1) * three;  // :593-594
-        else rhs[b] = three * (dxn * (a1 - a0) / dxn_1 + dxn_1 * (a2 - a1) / dxn);
+      if (b < cnt0) {
+        rn[b] = sa[(1 + (uint64_t)b) * L];
+        wn[b] = w[1 + b];
+      }
+    }
+  }
+  for (uint64_t i0 = 1; i0 + 1 < n; i0 += SB) {
+    const uint64_t left = n - 1 - i0;
+    const int cnt = left < (uint64_t)SB ? (int)left : SB;
+    T rc[SB], wc[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+      rc[b] = rn[b];
+      wc[b] = wn[b];
+    }
+    {
+      const uint64_t j0 = i0 + SB;   // next block, requested before this one is processed
+      if (j0 + 1 < n) {
+        const uint64_t leftn = n - 1 - j0;
+        const int cntn = leftn < (uint64_t)SB ? (int)leftn : SB;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+          if (b < cntn) {
+            rn[b] = sa[(j0 + b) * L];
+            wn[b] = w[j0 + b];
+          }
+        }
       }
     }
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
       if (b < cnt) {
-        const uint64_t i = i0 + b;
-        const T r = rhs[b] - w[i] * r_prev;
-        sa[i * L] = r;
+        const T r = rc[b] - wc[b] * r_prev;
+        sa[(i0 + b) * L] = r;
         r_prev = r;
       }
     }
-    // window (y[i-1], y[i], y[i+1]) of the block's last row i
-    T w0 = ym, w1 = yc, w2 = yp;
-#pragma unroll
-    for (int b = 0; b < SB; ++b) {
-      if (b < cnt) {
-        if (b > 0) {
-          w0 = w1;
-          w1 = w2;
-        }
-        w2 = yn[b];
-      }
-    }
-    if (i0 + (uint64_t)cnt + 1 < n) {   // another block follows: it starts at row i0+cnt
-      ym = w1;
-      yc = w2;
-    } else {                            // done: keep the window of row n-2 for the last boundary row
-      ym = w0;
-      yc = w1;
-      yp = w2;
-    }
-  }
-  // window is now (y[n-3], y[n-2], y[n-1])
-  const T dxl = A.dx[n - 2], dxl2 = A.dx[n - 3];
-  T rhs_last;
-  if (rk == 0) {
-    rhs_last = (A.dxl_sq * (yc - ym) / dxl2 + A.nkR_tmp1 * (yp - yc) / dxl) / A.nkR_d;
-  } else if (rk == 1) {
-    rhs_last = rval;
-  } else if (rk == 2) {
-    rhs_last = three * (yp - yc) + rval * A.dxl_sq / two;
-  } else {  // parabola rows (:595)
-    rhs_last = ((yp - yc) / dxl) * two;
   }
   const T r_last = rhs_last - w_last * r_prev;
   T k_next = r_last / mid_last;
-  T y_hi = yp;
-  // ---- back substitution fused with a/b, rows n-2 .. 0, SB rows at a time
-  for (uint64_t hi = n - 1; hi > 0;) {   // rows hi-1, hi-2, ...
-    const int cnt = hi < (uint64_t)SB ? (int)hi : SB;
-    T ri[SB], yl[SB];
+  T y_hi = y[(n - 1) * L];
+  // ---- back substitution fused with a/b, rows n-2 .. 0, SB rows at a time, next block's loads in flight
+  T ri_next[SB], yl_next[SB], up_next[SB], mid_next[SB], dx_next[SB];
+  {
+    const uint64_t hi0 = n - 1;
+    const int cnt0 = hi0 < (uint64_t)SB ? (int)hi0 : SB;
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
-      if (b < cnt) {
-        const uint64_t i = hi - 1 - b;
-        ri[b] = sa[i * L];
-        yl[b] = y[i * L];
+      if (b < cnt0) {
+        const uint64_t i = hi0 - 1 - b;
+        ri_next[b] = sa[i * L];
+        yl_next[b] = y[i * L];
+        up_next[b] = (i == 0) ? up0 : A.up[i];
+        mid_next[b] = midp[i];
+        dx_next[b] = A.dx[i];
+      }
+    }
+  }
+  for (uint64_t hi = n - 1; hi > 0;) {   // rows hi-1, hi-2, ...
+    const int cnt = hi < (uint64_t)SB ? (int)hi : SB;
+    T ri[SB], yl[SB], upc[SB], midc[SB], dxc[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+      ri[b] = ri_next[b];
+      yl[b] = yl_next[b];
+      upc[b] = up_next[b];
+      midc[b] = mid_next[b];
+      dxc[b] = dx_next[b];
+    }
+    {
+      const uint64_t hn = hi - (uint64_t)cnt;   // the next block covers rows hn-1, hn-2, ...
+      if (hn > 0) {
+        const int cntn = hn < (uint64_t)SB ? (int)hn : SB;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+          if (b < cntn) {
+            const uint64_t i = hn - 1 - b;
+            ri_next[b] = sa[i * L];
+            yl_next[b] = y[i * L];
+            up_next[b] = (i == 0) ? up0 : A.up[i];
+            mid_next[b] = midp[i];
+            dx_next[b] = A.dx[i];
+          }
+        }
       }
     }
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
       if (b < cnt) {
         const uint64_t i = hi - 1 - b;
-        const T k = (ri[b] - (i == 0 ? up0 : A.up[i]) * k_next) / midp[i];
+        const T k = (ri[b] - upc[b] * k_next) / midc[b];
         const T dy = y_hi - yl[b];
-        const T dxi = A.dx[i];
-        sa[i * L] = k * dxi - dy;
-        sb[i * L] = dy - k_next * dxi;
+        sa[i * L] = k * dxc[b] - dy;
+        sb[i * L] = dy - k_next * dxc[b];
         k_next = k;
         y_hi = yl[b];
       }

@@ -345,9 +345,12 @@ struct Interp1DImpl final : Interp1DBase {
     const unsigned grid = (unsigned)((lanes + 63) / 64);
     hipStream_t s = nullptr;
     switch (P.mode) {
-      case SPLINE_GENERAL:
+      case SPLINE_GENERAL: {
+        const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * lanes + BLOCK - 1) / BLOCK, 65536));
+        hipLaunchKernelGGL((spline_rhs_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, s, A);
         hipLaunchKernelGGL((spline_build_general_kernel<T, false>), dim3(grid), dim3(64), 0, s, A);
         break;
+      }
       case SPLINE_PARABOLA3:
         hipLaunchKernelGGL(spline_build_n3_kernel<T>, dim3(grid), dim3(64), 0, s, A, 0);
         break;
@@ -437,6 +440,8 @@ struct Interp1DImpl final : Interp1DBase {
     A.lanes = lanes;
     A.nkL_tmp1 = ref.nkL_tmp1; A.nkL_d = ref.nkL_d; A.nkR_tmp1 = ref.nkR_tmp1; A.nkR_d = ref.nkR_d;
     A.dx0_sq = ref.dx0_sq; A.dxl_sq = ref.dxl_sq;
+    const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * lanes + BLOCK - 1) / BLOCK, 65536));
+    hipLaunchKernelGGL((spline_rhs_kernel<T, true>), dim3(gr), dim3(BLOCK), 0, (hipStream_t) nullptr, A);
     hipLaunchKernelGGL((spline_build_general_kernel<T, true>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0,
                        (hipStream_t) nullptr, A);
     NDI_HIP(hipGetLastError());

@@ -1194,6 +1194,15 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
   }
 }
 
+// Read-only, wave-uniform plan arrays (dx, w, up, mid', k2) read through the constant address space: the compiler
+// may then use scalar loads and need not order them against the kernel's own stores to the a / b tables (through
+// a plain global pointer it must assume they alias, which pins every factor load behind the preceding store).
+template <class T>
+__device__ __forceinline__ T const_load(const T* p, uint64_t i) {
+  typedef const __attribute__((address_space(4))) T* cptr;
+  return ((cptr)p)[i];
+}
+
 // n == 3 closed forms: parabola (:569-596) and periodic (:480-496).
 template <class T>
 __global__ __launch_bounds__(64) void spline_build_n3_kernel(BuildArgs<T> A, int periodic) {
@@ -1234,7 +1243,7 @@ __global__ __launch_bounds__(64) void spline_build_periodic_kernel(BuildArgs<T> 
   const T* y = A.data + l;
   T* sa = A.ca + l;
   T* sb = A.cb + l;
-  const T dx0 = A.dx[0], dxl = A.dx[n - 2], dxl2 = A.dx[n - 3];
+  const T dx0 = const_load(A.dx, 0), dxl = const_load(A.dx, n - 2), dxl2 = const_load(A.dx, n - 3);
   const T y0 = y[0], y1 = y[L];
   const T yn1 = y[(n - 1) * L], yn2 = y[(n - 2) * L], yn3 = y[(n - 3) * L];
   if (y0 != yn1) atomicAdd(&A.status->periodic_mismatch, 1ull);
@@ -1248,9 +1257,9 @@ __global__ __launch_bounds__(64) void spline_build_periodic_kernel(BuildArgs<T> 
   sa[0] = r_prev;
   T ym = y0, yc = y1, yp = y[2 * L];
   for (uint64_t i = 1; i < m; ++i) {
-    const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
+    const T dxn = const_load(A.dx, i), dxn_1 = const_load(A.dx, i - 1);
     const T rhs = three * (dxn * (yc - ym) / dxn_1 + dxn_1 * (yp - yc) / dxn);
-    const T r = rhs - A.w[i] * r_prev;
+    const T r = rhs - const_load(A.w, i) * r_prev;
     sa[i * L] = r;
     r_prev = r;
     ym = yc;
@@ -1258,27 +1267,27 @@ __global__ __launch_bounds__(64) void spline_build_periodic_kernel(BuildArgs<T> 
     yp = y[(i + 2) * L];
   }
   // back substitution -> k1 rows 0..m-1 parked in cb
-  T k_next = r_prev / A.midp[m - 1];
+  T k_next = r_prev / const_load(A.midp, m - 1);
   sb[(m - 1) * L] = k_next;
   for (uint64_t i = m - 1; i-- > 0;) {
-    const T k = (sa[i * L] - A.up[i] * k_next) / A.midp[i];
+    const T k = (sa[i * L] - const_load(A.up, i) * k_next) / const_load(A.midp, i);
     sb[i * L] = k;
     k_next = k;
   }
   const T k1_first = sb[0], k1_last = sb[(m - 1) * L];
   const T k_m1 = (rhs_last - k1_first * dxl2 - k1_last * dxl) / A.per_den;
-  const T k_0 = k1_first + k_m1 * A.k2[0];
+  const T k_0 = k1_first + k_m1 * const_load(A.k2, 0);
   // k[i] = k1[i] + k_m1*k2[i] (i < m), k[m] = k_m1, k[n-1] = k[0]; a/b :354-365
   T k_i = k_0;
   T y_lo = y0;
   for (uint64_t i = 0; i + 1 < n; ++i) {
     T k_r;
-    if (i + 1 < m) k_r = sb[(i + 1) * L] + k_m1 * A.k2[i + 1];
+    if (i + 1 < m) k_r = sb[(i + 1) * L] + k_m1 * const_load(A.k2, i + 1);
     else if (i + 1 == m) k_r = k_m1;
     else k_r = k_0;
     const T y_hi = y[(i + 1) * L];
     const T dy = y_hi - y_lo;
-    const T dxi = A.dx[i];
+    const T dxi = const_load(A.dx, i);
     sa[i * L] = k_i * dxi - dy;
     sb[i * L] = dy - k_r * dxi;
     k_i = k_r;

@@ -83,6 +83,19 @@ __device__ __forceinline__ double rem_euclid_t(double a, double b) {
   return (r < 0.0) ? r + fabs(b) : r;
 }
 
+// Arrays that are read-only for the duration of a kernel (the plan arrays of the build) can be read through the
+// constant address space: the compiler may
+// then use scalar loads for wave-uniform indices and need not order the loads against the kernel's own stores
+// (through a plain global pointer it must assume they alias, which pins every such load behind the preceding
+// store -- and a load behind a store waits for it: vmcnt is in-order and counts stores on CDNA4).  (Tried for the
+// per-query index / t loads of the gather kernel as well: 6 % slower on unsorted queries -- the implicit pacing
+// helps the HBM-bound stream -- so evaluation keeps plain loads.)
+template <class T>
+__device__ __forceinline__ T const_load(const T* p, uint64_t i) {
+  typedef const __attribute__((address_space(4))) T* cptr;
+  return ((cptr)p)[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // locate: knot pyramid  lv0 = knots[n], lv1[j] = knots[j * block]  (block = power of two with 64*block >= n,
 // so the top level never has more than 64 entries: one per lane)
@@ -1192,15 +1205,6 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
     }
     hi -= (uint64_t)cnt;
   }
-}
-
-// Read-only, wave-uniform plan arrays (dx, w, up, mid', k2) read through the constant address space: the compiler
-// may then use scalar loads and need not order them against the kernel's own stores to the a / b tables (through
-// a plain global pointer it must assume they alias, which pins every factor load behind the preceding store).
-template <class T>
-__device__ __forceinline__ T const_load(const T* p, uint64_t i) {
-  typedef const __attribute__((address_space(4))) T* cptr;
-  return ((cptr)p)[i];
 }
 
 // n == 3 closed forms: parabola (:569-596) and periodic (:480-496).

@@ -2,13 +2,20 @@
 """bench.py -- headline benchmark of the interp_array hot path on MI355X.
 
 Metric (BASELINE.json): interp_array Mpoints/s (points = queries x lanes), 1-D CubicSpline f64, plus the
-achieved fraction of the HBM roofline.  A "step" is one pass of the hot path (locate + evaluate) over one
-batch of synthetic queries; tables, queries and the output buffer are resident in HBM when the timed
-region starts.  Workload at N=1: BASELINE.json configs[1] (C2: 4096 knots x 4096 lanes f64, 1e6 queries).
-N>1: the same per-GPU batch on every rank (weak scaling), tables replicated, no data-path collective.
+achieved fraction of the HBM roofline.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Default workload = the north-star **Target**: 4096 knots x 4096 f64 lanes, 1e7 queries per GPU.  The whole
+output (327.7 GB) exceeds the 288 GB of HBM, so a "step" is one pass of `interp_array` over the batch through
+the library's device-output ring (ndi_interp1d_eval_ring): 10 chunks of 1e6 *distinct* queries, each located,
+grouped and evaluated into one of 2 ring slots of 32.8 GB; nothing is copied to the host.  Tables, queries and
+the ring are resident in HBM when the timed region starts.  N>1: every rank runs the same per-GPU batch on its
+own device (weak scaling; `--queries 12500000` is C4's per-GPU share), tables replicated, no collective on the
+data path.
+
+    python bench.py                                  # N=1, Target
+    python bench.py --gpus 8 --steps 20 --warmup 5   # spawns 8 ranks itself (RCCL barrier / max-reduce only)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # external launcher: same
+    python bench.py --workload c2|c3|c5|c2-linear|c2-f32|c1 ...                    # secondary measurements
 """
 import argparse
 import importlib.util
@@ -46,6 +53,16 @@ def synth_c2(n, lanes, nq, rank):
     y = rng.uniform(0.0, 1.0, (n, lanes))
     q = np.random.default_rng(123 + rank).uniform(x[0], x[-1], nq)
     return x, y, q
+
+
+def synth_target_queries(x, nq, chunk, rank):
+    """Target / C4 share: nq queries in distinct chunks -- one PRNG stream per (rank, chunk), seeds following
+    benches/bench_interp1d.rs:13-15 (123 for queries)."""
+    parts = []
+    for c, off in enumerate(range(0, nq, chunk)):
+        m = min(chunk, nq - off)
+        parts.append(np.random.default_rng([123, rank, c]).uniform(x[0], x[-1], m))
+    return np.concatenate(parts)
 
 
 def cpu_baseline(x, y, q_all, budget_s=20.0):
@@ -145,10 +162,12 @@ def extra_workload(args, pkg, torch, dev, rank, world):
                           "gpu_c_abi_host_to_host_us_per_batch": round(abi_us, 1), "gpu_c_abi_Mpoints_s": round(nq / abi_us, 1),
                           "gpu_python_mirror_us_per_batch": round(gpu_us, 1)}))
         return
-    else:                        # Linear f64 / CubicSpline f32 on the C2 shape
+    else:                        # C2 itself (one 1e6-query batch into one resident buffer), Linear f64 / CubicSpline f32 on its shape
         n = lanes = 4096; nq = args.queries
         x, yv, q = synth_c2(n, lanes, nq, rank)
-        dt, tdt, strat = (np.float64, torch.float64, None) if args.workload == "c2-linear" else (np.float32, torch.float32, pkg.CubicSpline.new())
+        dt, tdt, strat = {"c2": (np.float64, torch.float64, pkg.CubicSpline.new()),
+                          "c2-linear": (np.float64, torch.float64, None),
+                          "c2-f32": (np.float32, torch.float32, pkg.CubicSpline.new())}[args.workload]
         x = np.unique(x.astype(dt)); yv = yv[:x.size].astype(dt); n = x.size
         q = np.clip(q.astype(dt), x[0], x[-1])
         if args.sorted_queries:
@@ -183,90 +202,67 @@ def extra_workload(args, pkg, torch, dev, rank, world):
                       "stages_ms_per_step": {k: round(prof[k + "_ms"] / args.steps, 4) for k in ("locate", "group", "eval")}}))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--knots", type=int, default=4096)
-    ap.add_argument("--lanes", type=int, default=4096)
-    ap.add_argument("--queries", type=int, default=1_000_000, help="queries per GPU per step")
-    ap.add_argument("--path", choices=["auto", "gather", "bucketed"], default="auto")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--placement-probe", type=int, default=4,
-                    help="allocate this many candidate output buffers and keep the one with the best measured "
-                         "streaming-store rate (physical placement of a 32.8 GB buffer varies by 15-20 %% between "
-                         "allocations on MI355X, see DESIGN.md 4.3); 1 = take the first allocation")
-    ap.add_argument("--even-axes", action="store_true", help="extra (c3/c5): default index axes 0..n instead of random knots")
-    ap.add_argument("--sorted-queries", action="store_true", help="extra: sort the queries (cache reuse in the gather order)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c5", "c2-linear", "c2-f32", "c1"], default="c2",
-                    help="c2 = headline (BASELINE configs[1]); c3 / c2-linear are extra measurements for DESIGN.md")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this GPU")
-    args = ap.parse_args()
+def self_launch(args):
+    """`python bench.py --gpus N` without an external launcher: start N fresh rank processes -- before this
+    process has made any GPU call -- with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, wait for them and
+    return the worst exit code.  Rank 0 prints the JSON line (the children share our stdout)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(args.gpus)]
+    rc = 0
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(timeout=3000)))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = max(rc, 124)
+    return rc
 
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.device_override is not None:
-        local_rank = args.device_override
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    pkg = load_package()
-    if args.workload != "c2":
-        sys.path.insert(0, ROOT)
-        return extra_workload(args, pkg, torch, dev, rank, world)
 
-    n, lanes, nq = args.knots, args.lanes, args.queries
-    x, y, q = synth_c2(n, lanes, nq, rank)
+def check_rows_against_oracle(x, y, q_rows, got_rows):
+    """Outside the timed region: sampled output rows of the device path against the CPU oracle, bit for bit."""
+    sys.path.insert(0, ROOT)
+    import oracle
+    st, a, b = oracle.cubic_build(x, y)
+    assert st == oracle.OK
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q_rows)
+    err = float(np.max(np.abs(ref - got_rows))) if got_rows.size else 0.0
+    return {"rows": int(got_rows.shape[0]), "bit_exact": bool(np.array_equal(ref, got_rows)), "max_abs_err": err}
+
+
+def run_target(args, pkg, torch, dist, dev, rank, world):
+    n, lanes, nq, chunk = args.knots, args.lanes, args.queries, args.chunk
+    x, y, _ = synth_c2(n, lanes, 1, rank)
+    q = synth_target_queries(x, nq, chunk, rank)
     if args.sorted_queries:
         q = np.sort(q)
-    yd = torch.as_tensor(y, device=dev)
-    xd = torch.as_tensor(x, device=dev)
+    yd, xd = torch.as_tensor(y, device=dev), torch.as_tensor(x, device=dev)
     t0 = time.perf_counter()
     interp = pkg.Interp1DBuilder.new(yd).x(xd).strategy(pkg.CubicSpline.new()).build()
     torch.cuda.synchronize()
     build_ms = (time.perf_counter() - t0) * 1e3
-    interp.strategy.path = {"auto": pkg.PATH_AUTO, "gather": pkg.PATH_GATHER, "bucketed": pkg.PATH_BUCKETED}[args.path]
+    paths = {"auto": pkg.PATH_AUTO, "gather": pkg.PATH_GATHER, "bucketed": pkg.PATH_BUCKETED}
+    interp.strategy.path = paths[args.path]
     qd = torch.as_tensor(q, device=dev)
-    # Output buffer (32.8 GB at C2, stays in HBM).  Outside the timed region: among K candidate allocations keep
-    # the one the evaluation itself streams into fastest (2 timed passes each); reported in config.output_buffer.
-    out_bytes = nq * lanes * 8
-    free_b, _ = torch.cuda.mem_get_info(dev)
-    k_cand = max(1, min(args.placement_probe, int((free_b - (8 << 30)) // out_bytes)))
-    cands, probe_ms = [], []
-    for _ in range(k_cand):
-        c = torch.empty((nq, lanes), dtype=torch.float64, device=dev)
-        cands.append(c)
-        if k_cand == 1:
-            probe_ms.append(None)
-            break
-        interp.strategy.interp_array_into(interp, qd, c, async_launch=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _r in range(2):
-            interp.strategy.interp_array_into(interp, qd, c, async_launch=True)
-        e1.record(); e1.synchronize()
-        probe_ms.append(round(e0.elapsed_time(e1) / 2, 3))
-        if os.environ.get("NDI_BENCH_DEBUG"):
-            print(f"candidate @0x{c.data_ptr():x}  {probe_ms[-1]} ms", file=sys.stderr)
-    interp.strategy.finish()
-    chosen = 0 if k_cand == 1 else int(np.argmin(probe_ms))
-    out = cands[chosen]
-    del cands, c
-    torch.cuda.empty_cache()
+    # the ring: the first allocations of this process, taken as they come (no placement selection)
+    ring = [torch.empty((chunk, lanes), dtype=torch.float64, device=dev) for _ in range(args.ring_slots)]
+    nchunks = (nq + chunk - 1) // chunk
+    seen = {"chunks": 0, "rows": 0}
+
+    def consumer(c, rows):        # a real consumer would enqueue its work on c.stream here
+        seen["chunks"] += 1
+        seen["rows"] += c.q_count
+        return None
 
     def step():
-        interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
+        interp.interp_array_ring(qd, chunk, consumer, slots=ring)   # raises if any query failed (none may)
 
     def fence():
         torch.cuda.synchronize()
@@ -276,76 +272,221 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    interp.strategy.finish()
     pkg.profile_enable(True)
     pkg.profile_read(reset=True)
+    seen.update(chunks=0, rows=0)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    interp.strategy.finish()  # raises if any batch failed (none may: all queries are in range)
     prof = pkg.profile_read(reset=True)
     pkg.profile_enable(False)
+    assert seen["chunks"] == nchunks * args.steps and seen["rows"] == nq * args.steps, seen
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-
-    # sanity inside the bench: a few rows against the CPU oracle (never in the timed region)
     points_per_step = nq * lanes
     value = world * points_per_step * args.steps / elapsed / 1e6
-    if rank == 0:
-        kernel_ms = prof["eval_ms"] / max(1, prof["eval_launches"])
-        # cubic = 4 operand reads + 1 write = 5*sizeof(T) per point (+ the query value)
-        alg_bytes = points_per_step * 40 + nq * 8
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        # compulsory traffic of the batch: the output once, every table once, the queries once
-        comp_bytes = points_per_step * 8 + (n + 2 * (n - 1)) * lanes * 8 + nq * 8
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and (n, lanes, nq) == (4096, 4096, 1_000_000):  # measured on exactly this workload
-            try:
-                traffic = json.load(open(tpath)).get(f"{prof['last_path']}_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "interp_array Mpoints/s (queries x lanes), 1D cubic f64",
-            "value": round(value, 1), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"C2: 1D CubicSpline NotAKnot, {n} knots x {lanes} lanes f64, {nq} queries per GPU "
-                                   "(sorted-unique uniform knots, unsorted uniform in-range queries)",
-                       "path": prof["last_path"], "sharding": f"queries x{world}, tables replicated, no collective",
-                       "output_buffer": {"candidates": k_cand, "probe_ms_per_step": probe_ms, "chosen": chosen}},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "eval_bucketed_kernel" if prof["last_path"] == "bucketed" else "eval_rows_kernel",
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                         "compulsory_bytes_per_launch": comp_bytes,
-                         "compulsory_frac": round(comp_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "stages_ms_per_step": {"locate": round(prof["locate_ms"] / max(1, args.steps), 4),
-                                   "group": round(prof["group_ms"] / max(1, args.steps), 4),
-                                   "eval": round(prof["eval_ms"] / max(1, args.steps), 4)},
-            "build_ms": round(build_ms, 2),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            res, build_s = cpu_baseline(x, y, q)
-            v1, done1, _ = res["1t"]
-            vall, doneall, threads = res["all"]
-            line["cpu_baseline"] = {"value": round(v1, 1), "unit": "Mpoints/s", "cores": 1, "kind": "port",
-                                    "sample": f"{done1} queries x {lanes} lanes of the same workload (~10 s), oracle/ serial "
-                                              "loop in blocks of 2048 queries (the reference is single-threaded)",
-                                    "all_cores": {"value": round(vall, 1), "cores": threads,
-                                                  "sample": f"{doneall} queries (~10 s), contiguous query blocks per thread"},
-                                    "build_s": round(build_s, 2)}
-        print(json.dumps(line), flush=True)
+    if rank != 0:
+        return
+
+    # ---- everything below is outside the timed region (rank 0 only) -------------------------------------
+    kernel_ms = prof["eval_ms"] / max(1, prof["eval_launches"])          # one launch = one chunk
+    per_launch_q = nq / nchunks
+    pts = per_launch_q * lanes
+    table_bytes = (n + 2 * (n - 1)) * lanes * 8
+    bucketed = prof["last_path"] == "bucketed"
+    # bytes the kernel must move per launch: the output once + the queries' records; the bucketed formulation
+    # reads every table row once per launch, the gather formulation 4 operand rows per query
+    comp_bytes = pts * 8 + per_launch_q * 16 + (table_bytes if bucketed else pts * 32)
+    alg_bytes = pts * 40 + per_launch_q * 8                                 # SURVEY 8(d) gather model
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and (n, lanes, chunk) == (4096, 4096, 1_000_000):
+        try:
+            traffic = json.load(open(tpath)).get(f"{prof['last_path']}_bytes_per_launch")
+        except Exception:
+            traffic = None
+    phys = traffic if traffic else comp_bytes
+    achieved = phys / (kernel_ms * 1e-3) / 1e9
+    line = {
+        "metric": "interp_array Mpoints/s (queries x lanes), 1D cubic f64",
+        "value": round(value, 1), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"Target: 1D CubicSpline NotAKnot, {n} knots x {lanes} lanes f64, {nq} queries per GPU "
+                               f"in {nchunks} distinct chunks of {chunk} through a {args.ring_slots}-slot device-output "
+                               "ring (sorted-unique uniform knots, unsorted uniform in-range queries; output "
+                               f"{nq * lanes * 8 / 1e9:.1f} GB per step, never copied to the host)",
+                   "path": prof["last_path"], "sharding": f"queries x{world}, tables replicated, no collective",
+                   "output_ring": {"slots": args.ring_slots, "slot_bytes": chunk * lanes * 8,
+                                   "placement": "first allocations of the process, no selection"}},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "bytes_basis": "PMC traffic per launch (profiles/traffic.json)" if traffic else
+                                    "compulsory bytes per launch (output + tables + query records, once)",
+                     "kernel": "eval_bucketed_kernel" if bucketed else "eval_rows_kernel",
+                     "kernel_ms": round(kernel_ms, 4), "launches": prof["eval_launches"],
+                     "compulsory_bytes_per_launch": int(comp_bytes),
+                     "compulsory_frac": round(comp_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     # SURVEY 8(d)'s gather-model bytes / time / peak: > 1 on the bucketed path because that
+                     # formulation removes the per-query table re-reads the model assumes -- not a hardware fraction
+                     "gather_model_ratio": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "stages_ms_per_step": {"locate": round(prof["locate_ms"] / args.steps, 4),
+                               "group": round(prof["group_ms"] / args.steps, 4),
+                               "eval": round(prof["eval_ms"] / args.steps, 4)},
+        "build_ms": round(build_ms, 2),
+    }
+
+    # sanity: sampled rows of every chunk against the CPU oracle (one extra pass, rows gathered on the device)
+    if not args.no_check:
+        rng = np.random.default_rng(7)
+        picked_q, picked_rows = [], []
+
+        def checking_consumer(c, rows):
+            sel = np.sort(rng.choice(c.q_count, size=min(48, c.q_count), replace=False))
+            picked_q.append(q[c.q_begin + sel])
+            picked_rows.append(rows[torch.as_tensor(sel, device=dev)].cpu().numpy())
+            return None
+        interp.interp_array_ring(qd, chunk, checking_consumer, slots=ring)
+        line["check"] = check_rows_against_oracle(x, y, np.concatenate(picked_q), np.concatenate(picked_rows))
+        assert line["check"]["bit_exact"], line["check"]
+
+    # the north-star's own formulation (per-query gather of 4 operand rows) on the same batch, for the
+    # "fraction of the HBM-read roofline" it asks for: algorithmic bytes of SURVEY 8(d) / time / peak
+    if not args.no_gather_leg and bucketed:
+        interp.strategy.path = pkg.PATH_GATHER
+        interp.interp_array_ring(qd[:2 * chunk], chunk, None, slots=ring)
+        pkg.profile_enable(True); pkg.profile_read(reset=True)
+        interp.interp_array_ring(qd, chunk, None, slots=ring)
+        gp = pkg.profile_read(reset=True); pkg.profile_enable(False)
+        gms = gp["eval_ms"] / max(1, gp["eval_launches"])
+        line["gather_formulation"] = {
+            "kernel": "eval_rows_kernel", "kernel_ms": round(gms, 4),
+            "algorithmic_GBs": round(alg_bytes / (gms * 1e-3) / 1e9, 1),
+            "frac_of_peak": round(alg_bytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "read_only_frac_of_peak": round(pts * 32 / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "Mpoints_s": round(pts / (gms * 1e-3) / 1e6, 1)}
+        interp.strategy.path = paths[args.path]
+
+    # placement sensitivity of the scattered row stream: the same chunk evaluated into each ring
+    # slot and into K further allocations; reported, never used for the headline
+    if args.placement_probe > 0:
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        k_extra = max(0, min(args.placement_probe, int((free_b - (8 << 30)) // (chunk * lanes * 8))))
+        cands = list(ring) + [torch.empty((chunk, lanes), dtype=torch.float64, device=dev) for _ in range(k_extra)]
+        probe = []
+        for c in cands:
+            interp.strategy.interp_array_into(interp, qd[:chunk], c, async_launch=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _r in range(2):
+                interp.strategy.interp_array_into(interp, qd[:chunk], c, async_launch=True)
+            e1.record(); e1.synchronize()
+            probe.append(round(e0.elapsed_time(e1) / 2, 3))
+        interp.strategy.finish()
+        line["placement"] = {"ms_per_chunk_ring_slots": probe[:len(ring)], "ms_per_chunk_other_allocations": probe[len(ring):],
+                             "spread": round(max(probe) / min(probe) - 1, 4),
+                             "best_of_all_Mpoints_s": round(chunk * lanes / (min(probe) * 1e-3) / 1e6, 1),
+                             "first_allocation_Mpoints_s": round(chunk * lanes / (probe[0] * 1e-3) / 1e6, 1)}
+        del cands
+
+    if world == 1 and not args.no_cpu_baseline:
+        res, build_s = cpu_baseline(x, y, q)
+        v1, done1, _ = res["1t"]
+        vall, doneall, threads = res["all"]
+        line["cpu_baseline"] = {"value": round(v1, 1), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+                                "sample": f"{done1} queries x {lanes} lanes of the same workload (~10 s), oracle/ serial "
+                                          "loop in blocks of 2048 queries (the reference is single-threaded)",
+                                "all_cores": {"value": round(vall, 1), "cores": threads,
+                                              "sample": f"{doneall} queries (~10 s), contiguous query blocks per thread"},
+                                "build_s": round(build_s, 2)}
+    print(json.dumps(line), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--knots", type=int, default=4096)
+    ap.add_argument("--lanes", type=int, default=4096)
+    ap.add_argument("--queries", type=int, default=None,
+                    help="queries per GPU per step (target: 10000000; 12500000 = C4's per-GPU share; c2: 1000000)")
+    ap.add_argument("--chunk", type=int, default=1_000_000, help="target: queries per ring chunk")
+    ap.add_argument("--ring-slots", type=int, default=2, help="target: device-output ring slots (32.8 GB each)")
+    ap.add_argument("--path", choices=["auto", "gather", "bucketed"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the sampled-rows check against the CPU oracle")
+    ap.add_argument("--no-gather-leg", action="store_true", help="skip the extra pass with the gather formulation")
+    ap.add_argument("--placement-probe", type=int, default=3,
+                    help="after the timed region, evaluate one chunk into each ring slot and into this many further "
+                         "allocations and report the spread (0 = skip); never used for the headline value")
+    ap.add_argument("--even-axes", action="store_true", help="extra (c3/c5): default index axes 0..n instead of random knots")
+    ap.add_argument("--sorted-queries", action="store_true", help="extra: sort the queries (cache reuse in the gather order)")
+    ap.add_argument("--workload", choices=["target", "c2", "c3", "c5", "c2-linear", "c2-f32", "c1"], default="target",
+                    help="target = headline (north-star Target; BASELINE configs[1] tables, 1e7 queries through the "
+                         "ring); the others are secondary measurements for DESIGN.md")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this GPU")
+    ap.add_argument("--launch-rehearsal", action="store_true",
+                    help="no GPU work: only the launch / rendezvous / barrier / max-over-ranks skeleton (gloo), used by "
+                         "the CPU tests to cover the N>1 self-launch")
+    args = ap.parse_args()
+    if args.queries is None:
+        args.queries = 10_000_000 if args.workload == "target" else 1_000_000
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # nothing in this process has touched the GPU
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device_override is not None:
+        local_rank = args.device_override
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.launch_rehearsal:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "max_over_ranks": float(t.item()),
+                              "local_rank": local_rank}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    pkg = load_package()
+    try:
+        if args.workload == "target":
+            run_target(args, pkg, torch, dist, dev, rank, world)
+        else:
+            sys.path.insert(0, ROOT)
+            extra_workload(args, pkg, torch, dev, rank, world)
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define NDI_VERSION_MAJOR 0
-#define NDI_VERSION_MINOR 1
+#define NDI_VERSION_MINOR 2
 
 /* BuilderError / InterpolateError (src/lib.rs:127-146) + ABI-only codes. */
 typedef enum ndi_status {
@@ -194,6 +194,59 @@ ndi_status ndi_interp2d_eval(const ndi_interp2d* h, const void* qx, const void* 
 ndi_status ndi_interp1d_finish(const ndi_interp1d* h, void* stream, ndi_oob_info* info);
 ndi_status ndi_interp2d_finish(const ndi_interp2d* h, void* stream, ndi_oob_info* info);
 
+/* ---- chunked evaluation through a device-output ring ---------------------------------
+ * Replaces Interp1D::interp_array (src/interp1d/mod.rs:197-211: allocate zeros(xs.shape ++ lanes), then the
+ * query loop :326-343) for batches whose whole output does not fit, or need not stay, in device memory
+ * (4096 lanes x 1e7 queries of f64 = 327.7 GB > 288 GB HBM).  The flattened queries are evaluated in chunks of
+ * `chunk_queries` rows into a ring of `n_slots` device buffers; after a chunk's kernels are enqueued the
+ * `consume` callback is called on the calling host thread with the chunk's location, and the slot is reused
+ * n_slots chunks later.  Nothing is copied to the host.
+ *
+ * Slot hand-off is stream-ordered: a consumer that enqueues its work on chunk->stream needs nothing else and
+ * returns NULL; a consumer that works on another stream records a hipEvent_t there when it is done with the slot
+ * and returns it -- the library makes its stream wait for that event before the slot is overwritten.
+ *
+ * First-error semantics are the reference's: a range pre-pass over all queries finds the lowest failing flat
+ * index F before any chunk is produced; exactly the rows [0, F) are produced (the last chunk is cut short),
+ * then NDI_OUT_OF_BOUNDS / NDI_NAN_QUERY is returned with info filled in.  The call returns after the last
+ * chunk's kernels (and the consumer's stream-ordered work) have completed. */
+typedef struct ndi_ring_chunk {
+  uint64_t index;      /* chunk number, 0, 1, ... */
+  uint64_t q_begin;    /* flat index of the chunk's first query */
+  uint64_t q_count;    /* rows produced in this chunk */
+  void* out;           /* device pointer, T[q_count][row_stride] */
+  uint64_t row_stride; /* elements */
+  uint32_t slot;       /* ring slot the chunk lives in */
+  uint32_t reserved;
+  void* stream;        /* hipStream_t the chunk's kernels were enqueued on */
+} ndi_ring_chunk;
+
+typedef void* (*ndi_ring_consumer)(void* user, const ndi_ring_chunk* chunk);
+
+typedef struct ndi_ring_desc {
+  void* const* slots;     /* n_slots device buffers of chunk_queries * row_stride elements each, or NULL:
+                             the library owns the ring (allocated once per handle, kept until trim / destroy) */
+  uint32_t n_slots;       /* >= 1 (2-3 when the consumer runs on its own stream) */
+  uint32_t reserved;
+  uint64_t chunk_queries; /* rows per chunk */
+  uint64_t row_stride;    /* elements, >= lanes; 0 = lanes */
+} ndi_ring_desc;
+
+ndi_status ndi_interp1d_eval_ring(const ndi_interp1d* h, const void* q, uint64_t nq,
+                                  const ndi_ring_desc* ring, ndi_ring_consumer consume, void* user,
+                                  const ndi_eval_opts* opts, ndi_oob_info* info);
+/* Same for Interp2D::interp_array (src/interp2d/mod.rs:175-196, 287-307). */
+ndi_status ndi_interp2d_eval_ring(const ndi_interp2d* h, const void* qx, const void* qy, uint64_t nq,
+                                  const ndi_ring_desc* ring, ndi_ring_consumer consume, void* user,
+                                  const ndi_eval_opts* opts, ndi_oob_info* info);
+
+/* Per-(stream, host thread) scratch is cached on the handle (at most 16 idle sets are kept; the least recently
+ * used idle set is freed beyond that).  trim frees every idle set and a library-owned ring now. */
+ndi_status ndi_interp1d_trim(const ndi_interp1d* h);
+ndi_status ndi_interp2d_trim(const ndi_interp2d* h);
+/* Diagnostic: number of scratch sets currently cached on the handle. */
+uint64_t ndi_interp1d_scratch_sets(const ndi_interp1d* h);
+
 /* ---- helpers on the path ------------------------------------------------------ */
 /* VectorExtensions::get_lower_index (src/vector_extensions.rs:55-111), batched:
  * out_idx[i] = the unique j with knots[j] <= q[i] < knots[j+1], clamped to [0, n-2];
@@ -201,6 +254,16 @@ ndi_status ndi_interp2d_finish(const ndi_interp2d* h, void* stream, ndi_oob_info
 ndi_status ndi_get_lower_index_batch(int32_t dtype, int32_t device, const void* knots, uint64_t n,
                                      const void* q, uint64_t nq, int64_t* out_idx,
                                      int32_t memspace);
+
+/* The same search with the knot pyramid resident on the device (no per-call allocation or knot upload):
+ * what Interp1D::get_index_left_of (src/interp1d/mod.rs:380-382) is to a built interpolator.
+ * `stream` as in ndi_eval_opts; the call returns when out_idx is complete. */
+typedef struct ndi_locator ndi_locator;
+ndi_status ndi_locator_create(int32_t dtype, int32_t device, const void* knots, uint64_t n,
+                              int32_t memspace, ndi_locator** out);
+ndi_status ndi_locator_eval(const ndi_locator* h, const void* q, uint64_t nq, int64_t* out_idx,
+                            int32_t memspace, void* stream);
+void ndi_locator_destroy(ndi_locator* h);
 
 /* VectorExtensions::monotonic_prop (src/vector_extensions.rs:40-53, 116-198).
  * Host-side O(n) validation; returns an ndi_monotonic. */

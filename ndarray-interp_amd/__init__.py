@@ -4,7 +4,8 @@ Layout
   csrc/                 hand-written HIP kernels (gfx950) + the C ABI (include/ndinterp.h)
   libndinterp_hip.so    built in-tree by __graft_entry__.build() / csrc/Makefile
   interp1d, interp2d    host-side mirror of Interp1DBuilder / Interp2DBuilder + the Strategy traits
-  vector_extensions     monotonic_prop / batched get_lower_index
+  vector_extensions     monotonic_prop / batched get_lower_index / Locator (resident knot pyramid)
+  generic_host          the reference's generic per-query path for non-f32/f64 element types (integers)
   sharding              query sharding over the GPUs of a node (no collective on the data path)
 
 The directory name carries a hyphen (fixed by the project layout); it is imported by path as
@@ -15,7 +16,7 @@ from .errors import BuilderError, DeviceError, InterpolateError, Panic
 from .interp1d import (BoundaryCondition, CubicSpline, CubicSplineStrategy, Interp1D, Interp1DBuilder,
                        Interp1DStrategy, Interp1DStrategyBuilder, Linear, RowBoundary, SingleBoundary)
 from .interp2d import Bilinear, Interp2D, Interp2DBuilder, Interp2DStrategy, Interp2DStrategyBuilder
-from .vector_extensions import Monotonic, get_lower_index, monotonic_prop
+from .vector_extensions import Locator, Monotonic, get_lower_index, monotonic_prop
 from . import sharding
 
 PATH_AUTO, PATH_GATHER, PATH_BUCKETED = _capi.PATH_AUTO, _capi.PATH_GATHER, _capi.PATH_BUCKETED
@@ -45,6 +46,6 @@ __all__ = [
     "Interp1D", "Interp1DBuilder", "Interp1DStrategy", "Interp1DStrategyBuilder", "Linear", "CubicSpline",
     "CubicSplineStrategy", "BoundaryCondition", "RowBoundary", "SingleBoundary",
     "Interp2D", "Interp2DBuilder", "Interp2DStrategy", "Interp2DStrategyBuilder", "Bilinear",
-    "Monotonic", "monotonic_prop", "get_lower_index", "sharding", "device_count",
+    "Monotonic", "monotonic_prop", "get_lower_index", "Locator", "sharding", "device_count",
     "profile_enable", "profile_read", "PATH_AUTO", "PATH_GATHER", "PATH_BUCKETED",
 ]

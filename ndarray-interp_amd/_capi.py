@@ -64,6 +64,18 @@ class Profile(C.Structure):
                 ("last_path", C.c_int32), ("reserved", C.c_int32)]
 
 
+class RingChunk(C.Structure):
+    _fields_ = [("index", C.c_uint64), ("q_begin", C.c_uint64), ("q_count", C.c_uint64), ("out", C.c_void_p),
+                ("row_stride", C.c_uint64), ("slot", C.c_uint32), ("reserved", C.c_uint32), ("stream", C.c_void_p)]
+
+
+class RingDesc(C.Structure):
+    _fields_ = [("slots", C.POINTER(C.c_void_p)), ("n_slots", C.c_uint32), ("reserved", C.c_uint32),
+                ("chunk_queries", C.c_uint64), ("row_stride", C.c_uint64)]
+
+
+RING_CONSUMER = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(RingChunk))
+
 # every symbol include/ndinterp.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -76,6 +88,16 @@ SYMBOLS = {
     "ndi_interp2d_eval": (C.c_int, [_P, _P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(EvalOpts), C.POINTER(OobInfo)]),
     "ndi_interp1d_finish": (C.c_int, [_P, _P, C.POINTER(OobInfo)]),
     "ndi_interp2d_finish": (C.c_int, [_P, _P, C.POINTER(OobInfo)]),
+    "ndi_interp1d_eval_ring": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(RingDesc), RING_CONSUMER, _P,
+                                         C.POINTER(EvalOpts), C.POINTER(OobInfo)]),
+    "ndi_interp2d_eval_ring": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(RingDesc), RING_CONSUMER, _P,
+                                         C.POINTER(EvalOpts), C.POINTER(OobInfo)]),
+    "ndi_interp1d_trim": (C.c_int, [_P]),
+    "ndi_interp2d_trim": (C.c_int, [_P]),
+    "ndi_interp1d_scratch_sets": (C.c_uint64, [_P]),
+    "ndi_locator_create": (C.c_int, [C.c_int32, C.c_int32, _P, C.c_uint64, C.c_int32, C.POINTER(_P)]),
+    "ndi_locator_eval": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int32, _P]),
+    "ndi_locator_destroy": (None, [_P]),
     "ndi_get_lower_index_batch": (C.c_int, [C.c_int32, C.c_int32, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_int32]),
     "ndi_monotonic_prop": (C.c_int32, [C.c_int32, _P, C.c_uint64]),
     "ndi_validate1d": (C.c_int, [C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_int32]),

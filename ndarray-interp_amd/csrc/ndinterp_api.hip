@@ -4,14 +4,19 @@
 // validates like the reference's builders, sequences the kernels of kernels.hpp on a HIP stream
 // and translates the device status word into the reference's error values.
 // There is deliberately NO CPU evaluation path in this library.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -70,6 +75,49 @@ struct SpaceKey {
   }
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the function on the *current device*: one flag per
+// (function, device), and the return code is checked (a process may drive several devices, one handle each).
+static void allow_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  NDI_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({fn, dev})) return;
+  NDI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({fn, dev});
+}
+
+// roctx ranges around build / locate / group / evaluate (rocprofv3 --marker-trace).  The marker library is
+// resolved at run time and only when NDI_ROCTX=1, so the product has no link-time dependency on a profiler.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* on = std::getenv("NDI_ROCTX");
+    if (!on || on[0] == '0') return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static const Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~Range() {
+    if (on) roctx().pop();
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // per-kernel event profiling (ndi_profile_*)
 // ---------------------------------------------------------------------------------------------
@@ -81,11 +129,13 @@ static std::vector<ProfRec> g_prof_recs;
 static ndi_profile g_prof_acc{};
 static std::atomic<int> g_last_path{0};
 
+static const char* const PROF_NAMES[3] = {"ndi:evaluate", "ndi:locate", "ndi:group"};
 struct ProfScope {
   hipStream_t s;
   ProfRec r{};
   bool on;
-  ProfScope(hipStream_t stream, int cat) : s(stream), on(g_prof_on.load() != 0) {
+  Range range;   // host-side enqueue range of the stage (the kernels inside carry their own names)
+  ProfScope(hipStream_t stream, int cat) : s(stream), on(g_prof_on.load() != 0), range(PROF_NAMES[cat]) {
     if (!on) return;
     r.cat = cat;
     NDI_HIP(hipEventCreate(&r.a));
@@ -153,6 +203,9 @@ struct Workspace {
   const void* last_q2 = nullptr;
   int last_q_space = NDI_MEM_DEVICE;
   bool pending = false;
+  // SpaceSet bookkeeping (guarded by the set's mutex)
+  int users = 0;
+  uint64_t last_use = 0;
   ~Workspace() {
     if (host_status) (void)hipHostFree(host_status);
     if (pin) (void)hipHostFree(pin);
@@ -169,6 +222,73 @@ struct Workspace {
     status.reserve(sizeof(StatusBlock));
     if (!host_status) NDI_HIP(hipHostMalloc((void**)&host_status, sizeof(StatusBlock), hipHostMallocDefault));
   }
+};
+
+// The scratch sets of one handle.  A set is *idle* when no call is inside it and its last batch has been
+// collected (its stream was synchronised after the last kernel that touched the scratch).  At most MAX_IDLE idle
+// sets are kept -- thread pools and short-lived streams would otherwise grow the map without bound; the least
+// recently used idle set is freed first (hipFree / hipHostFree synchronise, so freeing is safe in any case).
+struct SpaceSet {
+  static constexpr size_t MAX_IDLE = 16;
+  std::mutex mu;
+  std::map<SpaceKey, std::unique_ptr<Workspace>> map;
+  uint64_t tick = 0;
+
+  Workspace& acquire(hipStream_t s) {
+    std::lock_guard<std::mutex> g(mu);
+    auto& slot = map[SpaceKey{s, std::this_thread::get_id()}];
+    if (!slot) slot.reset(new Workspace());
+    slot->users++;
+    slot->last_use = ++tick;
+    evict_locked(MAX_IDLE);
+    return *slot;
+  }
+  void release(Workspace& w) {
+    std::lock_guard<std::mutex> g(mu);
+    w.users--;
+  }
+  void evict_locked(size_t keep) {
+    for (;;) {
+      size_t idle = 0;
+      auto victim = map.end();
+      for (auto it = map.begin(); it != map.end(); ++it) {
+        if (it->second->users != 0 || it->second->pending) continue;
+        ++idle;
+        if (victim == map.end() || it->second->last_use < victim->second->last_use) victim = it;
+      }
+      if (idle <= keep || victim == map.end()) return;
+      map.erase(victim);
+    }
+  }
+  void trim() {
+    std::lock_guard<std::mutex> g(mu);
+    evict_locked(0);
+  }
+  size_t size() {
+    std::lock_guard<std::mutex> g(mu);
+    return map.size();
+  }
+};
+
+struct SpaceLease {
+  SpaceSet& set;
+  Workspace& ws;
+  SpaceLease(SpaceSet& st, hipStream_t s) : set(st), ws(st.acquire(s)) {}
+  ~SpaceLease() { set.release(ws); }
+  SpaceLease(const SpaceLease&) = delete;
+  SpaceLease& operator=(const SpaceLease&) = delete;
+};
+
+// A ring of device buffers owned by a handle (ndi_ring_desc::slots == NULL).
+struct OwnedRing {
+  std::mutex mu;   // one ring evaluation at a time uses the library-owned ring
+  std::vector<std::unique_ptr<DevBuf>> slots;
+  void ensure(uint32_t n, size_t bytes) {
+    if (slots.size() > n) slots.resize(n);
+    while (slots.size() < n) slots.emplace_back(new DevBuf());
+    for (auto& b : slots) b->reserve(bytes);
+  }
+  void clear() { slots.clear(); }
 };
 
 template <class T, class K, class A>
@@ -243,13 +363,8 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
   A.slice = slice;
   A.hist = hist;
   A.nb = nb;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate_kernel<T, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate_kernel<T, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-  });
+  allow_dynamic_lds(reinterpret_cast<const void*>(&locate_kernel<T, true>), (int)LDS_STAGE_LIMIT);
+  allow_dynamic_lds(reinterpret_cast<const void*>(&locate_kernel<T, false>), (int)LDS_STAGE_LIMIT);
   if (slice_out) *slice_out = slice;
   if (blocks_out) *blocks_out = (uint32_t)blocks;
   if (A.stage_lds) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, true>, A);
@@ -268,6 +383,10 @@ struct Interp1DBase {
                           const ndi_eval_opts* opts, ndi_oob_info* info) = 0;
   virtual ndi_status finish(void* stream, ndi_oob_info* info) = 0;
   virtual ndi_status coefficients(void* a_out, void* b_out, int memspace) = 0;
+  virtual ndi_status eval_ring(const void* q, uint64_t nq, const ndi_ring_desc* ring, ndi_ring_consumer consume,
+                               void* user, const ndi_eval_opts* opts, ndi_oob_info* info) = 0;
+  virtual ndi_status trim() = 0;
+  virtual uint64_t scratch_sets() = 0;
 };
 
 template <class T>
@@ -277,18 +396,12 @@ struct Interp1DImpl final : Interp1DBase {
   uint64_t n = 0, lanes = 0;
   DevicePyramid<T> pyr;
   DevBuf data, ca, cb;
-  std::mutex mu;
-  std::map<SpaceKey, std::unique_ptr<Workspace>> spaces;
-
-  Workspace& workspace(hipStream_t s) {
-    std::lock_guard<std::mutex> g(mu);
-    auto& slot = spaces[SpaceKey{s, std::this_thread::get_id()}];
-    if (!slot) slot.reset(new Workspace());
-    return *slot;
-  }
+  SpaceSet spaces;
+  OwnedRing ring_own;
 
   // ---- build (CubicSpline::build, cubic_spline.rs:754-771) --------------------------------
   ndi_status build_spline(const ndi_interp1d_desc& d) {
+    Range rg("ndi:spline_build");
     const bool per_lane = d.lane_left_kind || d.lane_left_value || d.lane_right_kind || d.lane_right_value;
     if (per_lane) {
       if (!(d.lane_left_kind && d.lane_left_value && d.lane_right_kind && d.lane_right_value))
@@ -484,13 +597,8 @@ struct Interp1DImpl final : Interp1DBase {
         NDI_HIP(hipGetLastError());
         ps.done();
       }
-      static std::once_flag once;
-      std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-      });
+      allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>), (int)LDS_STAGE_LIMIT);
+      allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>), (int)LDS_STAGE_LIMIT);
       EvalSmallArgs<T> S{};
       S.pyr = pyr.view;
       S.data = data.as<T>();
@@ -537,11 +645,7 @@ struct Interp1DImpl final : Interp1DBase {
                            ws.hist.as<uint32_t>(), blocks, nb, ws.counts.as<uint32_t>());
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
                            ws.cursor.as<uint32_t>(), st);
-        static std::once_flag once;
-        std::call_once(once, [] {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&group_scatter_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GROUP_MAX_BINS * 4));
-        });
+        allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter_kernel), (int)(GROUP_MAX_BINS * 4));
         hipLaunchKernelGGL(group_scatter_kernel, dim3(blocks), dim3(BLOCK), (size_t)nb * 4, s,
                            (const uint32_t*)ws.idx.as<uint32_t>(), nq, slice,
                            (const uint32_t*)ws.hist.as<uint32_t>(), (const uint32_t*)ws.cursor.as<uint32_t>(),
@@ -614,6 +718,11 @@ struct Interp1DImpl final : Interp1DBase {
     ws.pending = false;
     const unsigned long long ff = ws.host_status->first_fail[0];
     if (ff == NO_FAIL) return NDI_OK;
+    return report(ws, ff, index_offset, info);
+  }
+
+  // The reference's error for the batch whose lowest failing (local) query index is ff.
+  ndi_status report(Workspace& ws, unsigned long long ff, uint64_t index_offset, ndi_oob_info* info) {
     T v;
     if (ws.last_q_space == NDI_MEM_DEVICE)
       NDI_HIP(hipMemcpy(&v, (const T*)ws.last_q + ff, sizeof(T), hipMemcpyDeviceToHost));
@@ -645,13 +754,8 @@ struct Interp1DImpl final : Interp1DBase {
     ws.stage[0].reserve(chunk_q * row_bytes);
     ws.ensure_status();
     g_last_path.store(NDI_PATH_GATHER);
-    static std::once_flag once;
-    std::call_once(once, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-    });
+    allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>), (int)LDS_STAGE_LIMIT);
+    allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>), (int)LDS_STAGE_LIMIT);
     StatusBlock* st = ws.status.as<StatusBlock>();
     for (uint64_t off = 0; off < nq; off += chunk_q) {
       const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
@@ -707,6 +811,7 @@ struct Interp1DImpl final : Interp1DBase {
   ndi_status eval(const void* q_, uint64_t nq, void* out_, uint64_t out_stride,
                   const ndi_eval_opts* opts, ndi_oob_info* info) override {
     DeviceGuard dg(device);
+    Range rg("ndi_interp1d_eval");
     ndi_eval_opts o{};
     if (opts) o = *opts;
     hipStream_t s = (hipStream_t)o.stream;  // NULL = the HIP default stream
@@ -714,7 +819,8 @@ struct Interp1DImpl final : Interp1DBase {
                                         (unsigned long long)out_stride, (unsigned long long)lanes);
     if (nq == 0) return NDI_OK;
     if (!q_ || !out_) return fail(NDI_BAD_ARG, "null query / output pointer");
-    Workspace& ws = workspace(s);
+    SpaceLease lease(spaces, s);
+    Workspace& ws = lease.ws;
     const T* q = (const T*)q_;
     if (o.q_memspace == NDI_MEM_HOST) {
       ws.qdev.reserve(nq * sizeof(T));
@@ -755,13 +861,103 @@ struct Interp1DImpl final : Interp1DBase {
   ndi_status finish(void* stream, ndi_oob_info* info) override {
     DeviceGuard dg(device);
     hipStream_t s = (hipStream_t)stream;
-    Workspace& ws = workspace(s);
+    SpaceLease lease(spaces, s);
+    Workspace& ws = lease.ws;
     if (!ws.pending) {
       NDI_HIP(hipStreamSynchronize(s));
       return NDI_OK;
     }
     return collect(s, ws, 0, info);
   }
+
+  // Interp1D::interp_array for outputs that do not fit / need not stay in device memory: chunks through a ring.
+  ndi_status eval_ring(const void* q_, uint64_t nq, const ndi_ring_desc* ring, ndi_ring_consumer consume,
+                       void* user, const ndi_eval_opts* opts, ndi_oob_info* info) override {
+    DeviceGuard dg(device);
+    ndi_eval_opts o{};
+    if (opts) o = *opts;
+    hipStream_t s = (hipStream_t)o.stream;
+    if (!ring || ring->n_slots == 0 || ring->chunk_queries == 0)
+      return fail(NDI_BAD_ARG, "ring needs n_slots >= 1 and chunk_queries >= 1");
+    const uint64_t stride = ring->row_stride ? ring->row_stride : lanes;
+    if (stride < lanes) return fail(NDI_BAD_ARG, "ring row_stride (%llu) < lanes (%llu)",
+                                    (unsigned long long)stride, (unsigned long long)lanes);
+    if (nq == 0) return NDI_OK;
+    if (!q_) return fail(NDI_BAD_ARG, "null query pointer");
+    Range rg("ndi_interp1d_eval_ring");
+    SpaceLease lease(spaces, s);
+    Workspace& ws = lease.ws;
+    const T* q = (const T*)q_;
+    if (o.q_memspace == NDI_MEM_HOST) {
+      ws.qdev.reserve(nq * sizeof(T));
+      NDI_HIP(hipMemcpyAsync(ws.qdev.p, q_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+      q = ws.qdev.as<T>();
+    }
+    // range pre-pass over the whole batch: the first failing index is known before any chunk is produced
+    reset_status(ws, s);
+    StatusBlock* st = ws.status.as<StatusBlock>();
+    {
+      const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+      ProfScope ps(s, PC_LOCATE);
+      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, q, (const T*)nullptr, nq, k0, kn, k0, kn,
+                         mode, &st->first_fail[0]);
+      NDI_HIP(hipGetLastError());
+      ps.done();
+    }
+    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    NDI_HIP(hipStreamSynchronize(s));
+    const unsigned long long ff = ws.host_status->first_fail[0];
+    const uint64_t limit = ff == NO_FAIL ? nq : std::min<uint64_t>(nq, ff);
+
+    std::unique_lock<std::mutex> own(ring_own.mu, std::defer_lock);
+    std::vector<void*> slots(ring->n_slots);
+    if (ring->slots) {
+      for (uint32_t i = 0; i < ring->n_slots; ++i) {
+        if (!ring->slots[i]) return fail(NDI_BAD_ARG, "ring slot %u is null", i);
+        slots[i] = ring->slots[i];
+      }
+    } else {
+      own.lock();
+      ring_own.ensure(ring->n_slots, (size_t)ring->chunk_queries * stride * sizeof(T));
+      for (uint32_t i = 0; i < ring->n_slots; ++i) slots[i] = ring_own.slots[i]->p;
+    }
+    std::vector<hipEvent_t> busy(ring->n_slots, nullptr);
+    uint64_t k = 0;
+    for (uint64_t off = 0; off < limit; off += ring->chunk_queries, ++k) {
+      const uint64_t cq = std::min<uint64_t>(ring->chunk_queries, limit - off);
+      const uint32_t slot = (uint32_t)(k % ring->n_slots);
+      if (busy[slot]) {   // the consumer reads this slot on another stream: wait for it there
+        NDI_HIP(hipStreamWaitEvent(s, busy[slot], 0));
+        busy[slot] = nullptr;
+      }
+      enqueue(s, ws, q + off, cq, (T*)slots[slot], stride, o.path);
+      if (consume) {
+        ndi_ring_chunk c{};
+        c.index = k; c.q_begin = off; c.q_count = cq; c.out = slots[slot]; c.row_stride = stride;
+        c.slot = slot; c.stream = (void*)s;
+        busy[slot] = (hipEvent_t)consume(user, &c);
+      }
+    }
+    NDI_HIP(hipStreamSynchronize(s));
+    for (hipEvent_t e : busy)
+      if (e) NDI_HIP(hipEventSynchronize(e));
+    ws.pending = false;
+    if (ff == NO_FAIL) return NDI_OK;
+    ws.last_q = q_;
+    ws.last_q_space = o.q_memspace;
+    return report(ws, ff, 0, info);
+  }
+
+  ndi_status trim() override {
+    DeviceGuard dg(device);
+    spaces.trim();
+    std::lock_guard<std::mutex> g(ring_own.mu);
+    ring_own.clear();
+    return NDI_OK;
+  }
+
+  uint64_t scratch_sets() override { return spaces.size(); }
 
   ndi_status coefficients(void* a_out, void* b_out, int memspace) override {
     DeviceGuard dg(device);
@@ -795,6 +991,7 @@ static std::vector<T> fetch_axis(const void* p, uint64_t len, int memspace) {
 template <class T>
 static ndi_status create1d(const ndi_interp1d_desc& d, Interp1DBase** out) {
   DeviceGuard dg(d.device);
+  Range rg("ndi_interp1d_create");
   std::unique_ptr<Interp1DImpl<T>> h(new Interp1DImpl<T>());
   h->dtype = d.dtype;
   h->device = d.device;
@@ -836,6 +1033,10 @@ struct Interp2DBase {
   virtual ndi_status eval(const void* qx, const void* qy, uint64_t nq, void* out, uint64_t out_stride,
                           const ndi_eval_opts* opts, ndi_oob_info* info) = 0;
   virtual ndi_status finish(void* stream, ndi_oob_info* info) = 0;
+  virtual ndi_status eval_ring(const void* qx, const void* qy, uint64_t nq, const ndi_ring_desc* ring,
+                               ndi_ring_consumer consume, void* user, const ndi_eval_opts* opts,
+                               ndi_oob_info* info) = 0;
+  virtual ndi_status trim() = 0;
 };
 
 template <class T>
@@ -845,15 +1046,8 @@ struct Interp2DImpl final : Interp2DBase {
   DevicePyramid<T> px, py;
   DevBuf data;
   bool pair_packed = false;   // data holds the pair-packed layout (pack_pairs_kernel)
-  std::mutex mu;
-  std::map<SpaceKey, std::unique_ptr<Workspace>> spaces;
-
-  Workspace& workspace(hipStream_t s) {
-    std::lock_guard<std::mutex> g(mu);
-    auto& slot = spaces[SpaceKey{s, std::this_thread::get_id()}];
-    if (!slot) slot.reset(new Workspace());
-    return *slot;
-  }
+  SpaceSet spaces;
+  OwnedRing ring_own;
 
   void enqueue(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t nq, T* out,
                uint64_t out_stride, int path) {
@@ -874,11 +1068,7 @@ struct Interp2DImpl final : Interp2DBase {
         NDI_HIP(hipGetLastError());
         ps.done();
       }
-      static std::once_flag once;
-      std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small2d_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-      });
+      allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small2d_kernel<T>), (int)LDS_STAGE_LIMIT);
       EvalSmall2Args<T> S{};
       S.px = px.view; S.py = py.view;
       S.data = data.as<T>();
@@ -908,11 +1098,7 @@ struct Interp2DImpl final : Interp2DBase {
       slice = (slice + threads - 1) / threads * threads;
       blocks = (nq + slice - 1) / slice;
       LA.slice = slice;
-      static std::once_flag once;
-      std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locate2_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-      });
+      allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T>), (int)LDS_STAGE_LIMIT);
       launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), both, locate2_kernel<T>, LA);
     } else {
       run_locate<T>(s, px, qx, nq, ws.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
@@ -962,13 +1148,8 @@ struct Interp2DImpl final : Interp2DBase {
       ws.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
       ws.counts.reserve((size_t)nb * sizeof(uint32_t));
       ws.cursor.reserve((size_t)nb * sizeof(uint32_t));
-      static std::once_flag once;
-      std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&group_scatter2d_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GROUP_MAX_BINS * 4));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_hist_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GROUP_MAX_BINS * 4));
-      });
+      allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T>), (int)(GROUP_MAX_BINS * 4));
+      allow_dynamic_lds(reinterpret_cast<const void*>(&tile_hist_kernel), (int)(GROUP_MAX_BINS * 4));
       ProfScope ps(s, PC_GROUP);
       hipLaunchKernelGGL(tile_hist_kernel, dim3((unsigned)blocks), dim3(BLOCK), (size_t)nb * 4, s,
                          (const uint32_t*)A.xi, (const uint32_t*)A.yi, nq, slice, sx, sy, nty, nb,
@@ -1005,6 +1186,11 @@ struct Interp2DImpl final : Interp2DBase {
     ws.pending = false;
     const unsigned long long fx = ws.host_status->first_fail[0], fy = ws.host_status->first_fail[1];
     if (fx == NO_FAIL && fy == NO_FAIL) return NDI_OK;
+    return report(ws, fx, fy, index_offset, info);
+  }
+
+  ndi_status report(Workspace& ws, unsigned long long fx, unsigned long long fy, uint64_t index_offset,
+                    ndi_oob_info* info) {
     // x is tested before y for the same query (bilinear.rs:71-80)
     const int axis = (fx <= fy) ? 0 : 1;
     const unsigned long long ff = axis == 0 ? fx : fy;
@@ -1038,11 +1224,7 @@ struct Interp2DImpl final : Interp2DBase {
     ws.stage[0].reserve(chunk_q * row_bytes);
     ws.ensure_status();
     g_last_path.store(NDI_PATH_GATHER);
-    static std::once_flag once;
-    std::call_once(once, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_small2d_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_STAGE_LIMIT);
-    });
+    allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small2d_kernel<T>), (int)LDS_STAGE_LIMIT);
     StatusBlock* st = ws.status.as<StatusBlock>();
     const size_t shmem = (px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15;
     for (uint64_t off = 0; off < nq; off += chunk_q) {
@@ -1098,6 +1280,7 @@ struct Interp2DImpl final : Interp2DBase {
   ndi_status eval(const void* qx_, const void* qy_, uint64_t nq, void* out_, uint64_t out_stride,
                   const ndi_eval_opts* opts, ndi_oob_info* info) override {
     DeviceGuard dg(device);
+    Range rg("ndi_interp2d_eval");
     ndi_eval_opts o{};
     if (opts) o = *opts;
     hipStream_t s = (hipStream_t)o.stream;  // NULL = the HIP default stream
@@ -1105,7 +1288,8 @@ struct Interp2DImpl final : Interp2DBase {
                                         (unsigned long long)out_stride, (unsigned long long)lanes);
     if (nq == 0) return NDI_OK;
     if (!qx_ || !qy_ || !out_) return fail(NDI_BAD_ARG, "null query / output pointer");
-    Workspace& ws = workspace(s);
+    SpaceLease lease(spaces, s);
+    Workspace& ws = lease.ws;
     const T* qx = (const T*)qx_;
     const T* qy = (const T*)qy_;
     if (o.q_memspace == NDI_MEM_HOST) {
@@ -1151,18 +1335,113 @@ struct Interp2DImpl final : Interp2DBase {
   ndi_status finish(void* stream, ndi_oob_info* info) override {
     DeviceGuard dg(device);
     hipStream_t s = (hipStream_t)stream;
-    Workspace& ws = workspace(s);
+    SpaceLease lease(spaces, s);
+    Workspace& ws = lease.ws;
     if (!ws.pending) {
       NDI_HIP(hipStreamSynchronize(s));
       return NDI_OK;
     }
     return collect(s, ws, 0, info);
   }
+
+  // Interp2D::interp_array through a device-output ring (see Interp1DImpl::eval_ring).
+  ndi_status eval_ring(const void* qx_, const void* qy_, uint64_t nq, const ndi_ring_desc* ring,
+                       ndi_ring_consumer consume, void* user, const ndi_eval_opts* opts,
+                       ndi_oob_info* info) override {
+    DeviceGuard dg(device);
+    ndi_eval_opts o{};
+    if (opts) o = *opts;
+    hipStream_t s = (hipStream_t)o.stream;
+    if (!ring || ring->n_slots == 0 || ring->chunk_queries == 0)
+      return fail(NDI_BAD_ARG, "ring needs n_slots >= 1 and chunk_queries >= 1");
+    const uint64_t stride = ring->row_stride ? ring->row_stride : lanes;
+    if (stride < lanes) return fail(NDI_BAD_ARG, "ring row_stride (%llu) < lanes (%llu)",
+                                    (unsigned long long)stride, (unsigned long long)lanes);
+    if (nq == 0) return NDI_OK;
+    if (!qx_ || !qy_) return fail(NDI_BAD_ARG, "null query pointer");
+    Range rg("ndi_interp2d_eval_ring");
+    SpaceLease lease(spaces, s);
+    Workspace& ws = lease.ws;
+    const T* qx = (const T*)qx_;
+    const T* qy = (const T*)qy_;
+    if (o.q_memspace == NDI_MEM_HOST) {
+      ws.qdev.reserve(nq * sizeof(T));
+      ws.qdev2.reserve(nq * sizeof(T));
+      NDI_HIP(hipMemcpyAsync(ws.qdev.p, qx_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+      NDI_HIP(hipMemcpyAsync(ws.qdev2.p, qy_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+      qx = ws.qdev.as<T>();
+      qy = ws.qdev2.as<T>();
+    }
+    reset_status(ws, s);
+    StatusBlock* st = ws.status.as<StatusBlock>();
+    {
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+      ProfScope ps(s, PC_LOCATE);
+      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
+                         px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode,
+                         &st->first_fail[0]);
+      NDI_HIP(hipGetLastError());
+      ps.done();
+    }
+    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    NDI_HIP(hipStreamSynchronize(s));
+    const unsigned long long fx = ws.host_status->first_fail[0], fy = ws.host_status->first_fail[1];
+    const unsigned long long ff = std::min(fx, fy);
+    const uint64_t limit = ff == NO_FAIL ? nq : std::min<uint64_t>(nq, ff);
+
+    std::unique_lock<std::mutex> own(ring_own.mu, std::defer_lock);
+    std::vector<void*> slots(ring->n_slots);
+    if (ring->slots) {
+      for (uint32_t i = 0; i < ring->n_slots; ++i) {
+        if (!ring->slots[i]) return fail(NDI_BAD_ARG, "ring slot %u is null", i);
+        slots[i] = ring->slots[i];
+      }
+    } else {
+      own.lock();
+      ring_own.ensure(ring->n_slots, (size_t)ring->chunk_queries * stride * sizeof(T));
+      for (uint32_t i = 0; i < ring->n_slots; ++i) slots[i] = ring_own.slots[i]->p;
+    }
+    std::vector<hipEvent_t> busy(ring->n_slots, nullptr);
+    uint64_t k = 0;
+    for (uint64_t off = 0; off < limit; off += ring->chunk_queries, ++k) {
+      const uint64_t cq = std::min<uint64_t>(ring->chunk_queries, limit - off);
+      const uint32_t slot = (uint32_t)(k % ring->n_slots);
+      if (busy[slot]) {
+        NDI_HIP(hipStreamWaitEvent(s, busy[slot], 0));
+        busy[slot] = nullptr;
+      }
+      enqueue(s, ws, qx + off, qy + off, cq, (T*)slots[slot], stride, o.path);
+      if (consume) {
+        ndi_ring_chunk c{};
+        c.index = k; c.q_begin = off; c.q_count = cq; c.out = slots[slot]; c.row_stride = stride;
+        c.slot = slot; c.stream = (void*)s;
+        busy[slot] = (hipEvent_t)consume(user, &c);
+      }
+    }
+    NDI_HIP(hipStreamSynchronize(s));
+    for (hipEvent_t e : busy)
+      if (e) NDI_HIP(hipEventSynchronize(e));
+    ws.pending = false;
+    if (ff == NO_FAIL) return NDI_OK;
+    ws.last_q = qx_;
+    ws.last_q2 = qy_;
+    ws.last_q_space = o.q_memspace;
+    return report(ws, fx, fy, 0, info);
+  }
+
+  ndi_status trim() override {
+    DeviceGuard dg(device);
+    spaces.trim();
+    std::lock_guard<std::mutex> g(ring_own.mu);
+    ring_own.clear();
+    return NDI_OK;
+  }
 };
 
 template <class T>
 static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
   DeviceGuard dg(d.device);
+  Range rg("ndi_interp2d_create");
   std::unique_ptr<Interp2DImpl<T>> h(new Interp2DImpl<T>());
   h->dtype = d.dtype;
   h->device = d.device;
@@ -1212,31 +1491,57 @@ static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
   return NDI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Locator: VectorExtensions::get_lower_index with the knot pyramid resident on the device
+// ---------------------------------------------------------------------------------------------
+struct LocatorBase {
+  virtual ~LocatorBase() = default;
+  int dtype = 0, device = 0;
+  virtual ndi_status eval(const void* q, uint64_t nq, int64_t* out_idx, int memspace, void* stream) = 0;
+};
+
 template <class T>
-static ndi_status lower_index_batch(int device, const void* knots, uint64_t n, const void* q, uint64_t nq,
-                                    int64_t* out_idx, int memspace) {
+struct LocatorImpl final : LocatorBase {
+  DevicePyramid<T> pyr;
+  SpaceSet spaces;
+
+  ndi_status eval(const void* q, uint64_t nq, int64_t* out_idx, int memspace, void* stream) override {
+    DeviceGuard dg(device);
+    if (nq == 0) return NDI_OK;
+    Range rg("ndi_locator_eval");
+    hipStream_t s = (hipStream_t)stream;
+    const T* qdev = (const T*)q;
+    int64_t* odev = out_idx;
+    if (memspace == NDI_MEM_HOST) {
+      SpaceLease lease(spaces, s);
+      Workspace& ws = lease.ws;
+      ws.qdev.reserve(nq * sizeof(T));
+      ws.stage[0].reserve(nq * sizeof(int64_t));
+      NDI_HIP(hipMemcpyAsync(ws.qdev.p, q, nq * sizeof(T), hipMemcpyHostToDevice, s));
+      qdev = ws.qdev.as<T>();
+      odev = ws.stage[0].as<int64_t>();
+      run_locate<T>(s, pyr, qdev, nq, nullptr, odev, nullptr, nullptr, EX_YES);
+      NDI_HIP(hipMemcpyAsync(out_idx, odev, nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipStreamSynchronize(s));
+      return NDI_OK;
+    }
+    run_locate<T>(s, pyr, qdev, nq, nullptr, odev, nullptr, nullptr, EX_YES);
+    NDI_HIP(hipStreamSynchronize(s));
+    return NDI_OK;
+  }
+};
+
+template <class T>
+static ndi_status create_locator(int device, const void* knots, uint64_t n, int memspace, LocatorBase** out) {
   DeviceGuard dg(device);
   if (n < 2) return fail(NDI_BAD_ARG, "get_lower_index needs at least 2 knots");
   if (n > MAX_KNOTS) return fail(NDI_UNSUPPORTED, "too many knots");
-  if (nq == 0) return NDI_OK;
+  std::unique_ptr<LocatorImpl<T>> h(new LocatorImpl<T>());
+  h->dtype = DType<T>::id;
+  h->device = device;
   std::vector<T> x = fetch_axis<T>(knots, n, memspace);
-  DevicePyramid<T> pyr;
-  pyr.upload(x.data(), n);
-  hipStream_t s = nullptr;
-  DevBuf qd, od;
-  const T* qdev = (const T*)q;
-  int64_t* odev = out_idx;
-  if (memspace == NDI_MEM_HOST) {
-    qd.reserve(nq * sizeof(T));
-    od.reserve(nq * sizeof(int64_t));
-    NDI_HIP(hipMemcpyAsync(qd.p, q, nq * sizeof(T), hipMemcpyHostToDevice, s));
-    qdev = qd.as<T>();
-    odev = od.as<int64_t>();
-  }
-  run_locate<T>(s, pyr, qdev, nq, nullptr, odev, nullptr, nullptr, EX_YES);
-  if (memspace == NDI_MEM_HOST)
-    NDI_HIP(hipMemcpyAsync(out_idx, od.p, nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  NDI_HIP(hipStreamSynchronize(s));
+  h->pyr.upload(x.data(), n);
+  *out = h.release();
   return NDI_OK;
 }
 
@@ -1247,6 +1552,7 @@ static ndi_status lower_index_batch(int device, const void* knots, uint64_t n, c
 // =============================================================================================
 struct ndi_interp1d { ndi::Interp1DBase* impl; };
 struct ndi_interp2d { ndi::Interp2DBase* impl; };
+struct ndi_locator { ndi::LocatorBase* impl; };
 
 #define NDI_TRY try {
 #define NDI_CATCH                                                                  \
@@ -1370,16 +1676,86 @@ NDI_API ndi_status ndi_interp2d_finish(const ndi_interp2d* h, void* stream, ndi_
   NDI_CATCH
 }
 
-NDI_API ndi_status ndi_get_lower_index_batch(int32_t dtype, int32_t device, const void* knots, uint64_t n,
-                                             const void* q, uint64_t nq, int64_t* out_idx, int32_t memspace) {
-  if (!knots || (!q && nq) || (!out_idx && nq)) return ndi::fail(NDI_BAD_ARG, "null argument");
+NDI_API ndi_status ndi_interp1d_eval_ring(const ndi_interp1d* h, const void* q, uint64_t nq,
+                                          const ndi_ring_desc* ring, ndi_ring_consumer consume, void* user,
+                                          const ndi_eval_opts* opts, ndi_oob_info* info) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->eval_ring(q, nq, ring, consume, user, opts, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp2d_eval_ring(const ndi_interp2d* h, const void* qx, const void* qy, uint64_t nq,
+                                          const ndi_ring_desc* ring, ndi_ring_consumer consume, void* user,
+                                          const ndi_eval_opts* opts, ndi_oob_info* info) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->eval_ring(qx, qy, nq, ring, consume, user, opts, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp1d_trim(const ndi_interp1d* h) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->trim();
+  NDI_CATCH
+}
+
+NDI_API uint64_t ndi_interp1d_scratch_sets(const ndi_interp1d* h) { return h ? h->impl->scratch_sets() : 0; }
+
+NDI_API ndi_status ndi_interp2d_trim(const ndi_interp2d* h) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->trim();
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_locator_create(int32_t dtype, int32_t device, const void* knots, uint64_t n,
+                                      int32_t memspace, ndi_locator** out) {
+  if (!knots || !out) return ndi::fail(NDI_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (dtype != NDI_F32 && dtype != NDI_F64) return ndi::fail(NDI_BAD_ARG, "unknown dtype");
   ndi_status ds = need_device(device);
   if (ds != NDI_OK) return ds;
   NDI_TRY
-  if (dtype == NDI_F32) return ndi::lower_index_batch<float>(device, knots, n, q, nq, out_idx, memspace);
-  if (dtype == NDI_F64) return ndi::lower_index_batch<double>(device, knots, n, q, nq, out_idx, memspace);
-  return ndi::fail(NDI_BAD_ARG, "unknown dtype");
+  ndi::LocatorBase* impl = nullptr;
+  ndi_status st = dtype == NDI_F32 ? ndi::create_locator<float>(device, knots, n, memspace, &impl)
+                                   : ndi::create_locator<double>(device, knots, n, memspace, &impl);
+  if (st != NDI_OK) return st;
+  *out = new ndi_locator{impl};
+  return NDI_OK;
   NDI_CATCH
+}
+
+NDI_API ndi_status ndi_locator_eval(const ndi_locator* h, const void* q, uint64_t nq, int64_t* out_idx,
+                                    int32_t memspace, void* stream) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  if ((!q || !out_idx) && nq) return ndi::fail(NDI_BAD_ARG, "null argument");
+  NDI_TRY
+  return h->impl->eval(q, nq, out_idx, memspace, stream);
+  NDI_CATCH
+}
+
+NDI_API void ndi_locator_destroy(ndi_locator* h) {
+  if (!h) return;
+  try {
+    ndi::DeviceGuard dg(h->impl->device);
+    delete h->impl;
+  } catch (...) {
+  }
+  delete h;
+}
+
+// One-shot form: builds a locator, searches, drops it (allocation + knot upload per call).
+NDI_API ndi_status ndi_get_lower_index_batch(int32_t dtype, int32_t device, const void* knots, uint64_t n,
+                                             const void* q, uint64_t nq, int64_t* out_idx, int32_t memspace) {
+  if (!knots || (!q && nq) || (!out_idx && nq)) return ndi::fail(NDI_BAD_ARG, "null argument");
+  ndi_locator* loc = nullptr;
+  ndi_status st = ndi_locator_create(dtype, device, knots, n, memspace, &loc);
+  if (st != NDI_OK) return st;
+  st = ndi_locator_eval(loc, q, nq, out_idx, memspace, nullptr);
+  ndi_locator_destroy(loc);
+  return st;
 }
 
 NDI_API int32_t ndi_monotonic_prop(int32_t dtype, const void* host_v, uint64_t n) {

@@ -55,7 +55,12 @@ InterpolateError.OutOfBounds = _OutOfBounds
 
 
 class Panic(RuntimeError):
-    """A condition on which the reference panics instead of returning Err."""
+    """A condition on which the reference panics instead of returning Err.  `index` is the flat query index
+    the serial loop would have panicked at, when the batch path knows it (NaN query while extrapolating)."""
+
+    def __init__(self, msg, index=None):
+        super().__init__(msg)
+        self.index = index
 
 
 class DeviceError(RuntimeError):
@@ -92,5 +97,5 @@ def raise_eval(status: int, info: "_capi.OobInfo"):
                                            index=int(info.index), value=float(info.value), axis=int(info.axis))
     if status == _capi.NAN_QUERY:
         # vector_extensions.rs:83-84 (unimplemented! -> panic)
-        raise Panic("not implemented: failed to convert NaN to usize")
+        raise Panic("not implemented: failed to convert NaN to usize", index=int(info.index))
     raise DeviceError(f"{_capi.STATUS_NAMES[status] if 0 <= status < 10 else status}: {_capi.last_error()}")

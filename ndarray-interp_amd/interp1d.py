@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _capi
 from ._arrays import Buf, current_stream_ptr, dtype_id, is_torch, np_dtype_of
-from .errors import BuilderError, Panic, raise_builder, raise_eval
+from .errors import BuilderError, InterpolateError, Panic, raise_builder, raise_eval
 from .vector_extensions import Monotonic, get_lower_index, monotonic_prop
 
 
@@ -116,10 +116,13 @@ class _DeviceStrategy1D(Interp1DStrategy):
     def interp_array_into(self, interpolator, xs_flat, out2d, *, async_launch=False):
         """Replaces the reference's query loop (interp1d/mod.rs:326-343) by one C-ABI call."""
         qb = Buf(xs_flat, self._np_dtype)
+        _check_out_dtype(out2d, self._np_dtype)
         opts = _capi.EvalOpts()
         opts.q_memspace = qb.memspace
         opts.path = self.path
         opts.async_launch = int(bool(async_launch))
+        # an async batch reads the query array until finish(): keep our (possibly converted) copy alive
+        self._inflight = qb if async_launch else None
         if is_torch(out2d):
             if not out2d.is_cuda:
                 raise TypeError("torch output buffers must live on the device; use numpy for host buffers")
@@ -143,6 +146,57 @@ class _DeviceStrategy1D(Interp1DStrategy):
         """Completes `async_launch` evaluations on the current stream and raises their error, if any."""
         info = _capi.OobInfo()
         st = _capi.lib().ndi_interp1d_finish(self._h, current_stream_ptr(self._device), C.byref(info))
+        self._inflight = None
+        if st != _capi.OK:
+            raise_eval(st, info)
+
+    def trim(self):
+        """Frees the handle's idle scratch sets and a library-owned ring (ndi_interp1d_trim)."""
+        _capi.lib().ndi_interp1d_trim(self._h)
+
+    def interp_array_ring(self, xs_flat, chunk_queries, consumer=None, *, slots=None, n_slots=2):
+        """Chunked evaluation through a device-output ring (ndi_interp1d_eval_ring): `interp_array` for batches
+        whose whole output does not fit (or need not stay) in device memory.  `slots`: list of contiguous device
+        tensors of shape (chunk_queries, lanes) -- the ring; None lets the library own `n_slots` buffers.
+        `consumer(chunk, view)` is called once per chunk, in order, after the chunk's kernels are enqueued on the
+        current stream; `view` is the slot tensor cut to the chunk's rows (None with a library-owned ring) and
+        `chunk` the ndi_ring_chunk fields (index, q_begin, q_count, out, row_stride, slot, stream).  Work the
+        consumer enqueues on the current stream is ordered before the slot's reuse; if it uses another stream it
+        returns a `torch.cuda.Event` recorded there."""
+        qb = Buf(xs_flat, self._np_dtype)
+        ring = _capi.RingDesc()
+        ring.chunk_queries = int(chunk_queries)
+        keep_events = []
+        if slots is not None:
+            for t in slots:
+                _check_out_dtype(t, self._np_dtype)
+                if not (is_torch(t) and t.is_cuda and t.is_contiguous()) or t.numel() < chunk_queries * self._lanes:
+                    raise TypeError("ring slots must be contiguous device tensors of chunk_queries x lanes elements")
+            arr = (C.c_void_p * len(slots))(*[t.data_ptr() for t in slots])
+            ring.slots = C.cast(arr, C.POINTER(C.c_void_p))
+            ring.n_slots = len(slots)
+        else:
+            ring.n_slots = int(n_slots)
+        ring.row_stride = self._lanes
+
+        def _cb(_user, cptr):
+            c = cptr.contents
+            view = slots[c.slot].view(-1, self._lanes)[:c.q_count] if slots is not None else None
+            ev = consumer(c, view)
+            if ev is None:
+                return None
+            keep_events.append(ev)
+            return ev.cuda_event
+        cb = _capi.RING_CONSUMER(_cb) if consumer is not None else C.cast(None, _capi.RING_CONSUMER)
+        opts = _capi.EvalOpts()
+        opts.q_memspace = qb.memspace
+        opts.out_memspace = _capi.MEM_DEVICE
+        opts.path = self.path
+        opts.stream = current_stream_ptr(self._device)
+        info = _capi.OobInfo()
+        st = _capi.lib().ndi_interp1d_eval_ring(self._h, qb.ptr, qb.size, C.byref(ring), cb, None,
+                                                C.byref(opts), C.byref(info))
+        del keep_events
         if st != _capi.OK:
             raise_eval(st, info)
 
@@ -151,6 +205,14 @@ class _DeviceStrategy1D(Interp1DStrategy):
         out = np.empty((1, self._lanes), dtype=self._np_dtype)
         self.interp_array_into(interpolator, np.array([x], dtype=self._np_dtype), out)
         target[...] = out.reshape(target.shape)
+
+
+def _check_out_dtype(out, dt):
+    """The kernels write sizeof(data element) per output element: the buffer must have the data's element type
+    (the reference enforces this at compile time)."""
+    got = np_dtype_of(out)
+    if got != np.dtype(dt):
+        raise TypeError(f"output buffer has element type {got}, the interpolator's data is {np.dtype(dt)}")
 
 
 def _default_device() -> int:
@@ -183,6 +245,10 @@ class Linear(Interp1DStrategyBuilder, _DeviceStrategy1D):
         return self
 
     def build(self, x, data):
+        if np_dtype_of(data) not in (np.dtype(np.float32), np.dtype(np.float64)):
+            # integer (and other non-f32/f64) element types: the reference's generic per-query path
+            from .generic_host import HostLinear
+            return HostLinear(_host(x), _host(data), self._extrapolate)
         return self._create(x, data, extrapolate=self._extrapolate)
 
 
@@ -411,8 +477,12 @@ class Interp1D:
         shape = self.get_buffer_shape(tuple(xs.shape))
         if is_torch(xs) and xs.is_cuda:
             import torch
-            ys = torch.empty(shape, dtype=xs.dtype if xs.dtype in (torch.float32, torch.float64) else None,
-                             device=xs.device)
+            # element type of the *data* (the kernels write that; queries are converted to it)
+            tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}.get(
+                np_dtype_of(self.data))
+            if tdt is None:
+                raise TypeError("device query tensors need f32 / f64 data; other element types use host arrays")
+            ys = torch.empty(shape, dtype=tdt, device=xs.device)
             # the reference hands back zeros for rows it never reached only on Err, where the buffer
             # is dropped anyway (:210); no memset of the output is needed
         else:
@@ -427,6 +497,8 @@ class Interp1D:
         if tuple(buffer.shape) != expect:
             raise Panic(f"ShapeError/IncompatibleShape: incompatible shapes expected: {list(expect)}, "
                         f"got: {list(buffer.shape)}")
+        if np_dtype_of(buffer) != np_dtype_of(self.data):
+            raise TypeError(f"buffer has element type {np_dtype_of(buffer)}, the data is {np_dtype_of(self.data)}")
         nq = int(np.prod(xs.shape, dtype=np.int64))
         lanes = int(np.prod(self._lanes_shape(), dtype=np.int64))
         xs_flat = xs.reshape(-1)
@@ -441,11 +513,27 @@ class Interp1D:
                                             buffer.reshape(nq, lanes), **kw)
             return
         # strided ArrayViewMut: bounce through a contiguous temporary
-        tmp = np.zeros((nq, lanes), dtype=buffer.dtype)
+        tmp = np.zeros((nq, lanes), dtype=np_dtype_of(self.data))
+        done = nq
         try:
             self.strategy.interp_array_into(self, _host(xs_flat), tmp, **kw)
+        except InterpolateError.OutOfBounds as e:
+            done = e.index if e.index is not None else 0   # rows before the failing query are written,
+            raise                                          # later rows stay untouched (interp1d/mod.rs:334-342)
         finally:
-            buffer[...] = tmp.reshape(buffer.shape)
+            if done and len(xs.shape) == 0:
+                buffer[...] = tmp[0].reshape(buffer.shape)
+            elif done:
+                where = np.unravel_index(np.arange(done), tuple(xs.shape))     # works for any strides
+                buffer[where] = tmp[:done].reshape((done,) + self._lanes_shape())
+
+    def interp_array_ring(self, xs, chunk_queries, consumer=None, *, slots=None, n_slots=2):
+        """`interp_array` (interp1d/mod.rs:197-211) for outputs larger than device memory: the flattened
+        queries are evaluated `chunk_queries` rows at a time into a ring of device buffers and handed to
+        `consumer(chunk, rows)`; see `_DeviceStrategy1D.interp_array_ring` / ndi_interp1d_eval_ring."""
+        if not hasattr(self.strategy, "interp_array_ring"):
+            raise TypeError("the ring evaluation needs a built-in device strategy (f32 / f64 data)")
+        self.strategy.interp_array_ring(xs.reshape(-1), chunk_queries, consumer, slots=slots, n_slots=n_slots)
 
 
 class Interp1DBuilder:

@@ -8,8 +8,8 @@ import numpy as np
 
 from . import _capi
 from ._arrays import Buf, current_stream_ptr, dtype_id, is_torch, np_dtype_of
-from .errors import BuilderError, Panic, raise_builder, raise_eval
-from .interp1d import _default_device, _host, _to_device
+from .errors import BuilderError, InterpolateError, Panic, raise_builder, raise_eval
+from .interp1d import _check_out_dtype, _default_device, _host, _to_device
 from .vector_extensions import Monotonic, get_lower_index, monotonic_prop
 
 
@@ -63,6 +63,10 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
 
     def build(self, x, y, data, device=None):
         dt = np_dtype_of(data)
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+            # integer (and other non-f32/f64) element types: the reference's generic per-query path
+            from .generic_host import HostBilinear
+            return HostBilinear(_host(x), _host(y), _host(data), self._extrapolate)
         tid = dtype_id(dt)
         db = Buf(data)
 
@@ -111,6 +115,8 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
         qy = Buf(ys_flat, self._np_dtype)
         if qx.memspace != qy.memspace:
             raise TypeError("xs and ys must live in the same memory space")
+        _check_out_dtype(out2d, self._np_dtype)
+        self._inflight = (qx, qy) if async_launch else None   # read until finish()
         opts = _capi.EvalOpts()
         opts.q_memspace = qx.memspace
         opts.path = self.path
@@ -137,6 +143,51 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
     def finish(self):
         info = _capi.OobInfo()
         st = _capi.lib().ndi_interp2d_finish(self._h, current_stream_ptr(self._device), C.byref(info))
+        self._inflight = None
+        if st != _capi.OK:
+            raise_eval(st, info)
+
+    def trim(self):
+        _capi.lib().ndi_interp2d_trim(self._h)
+
+    def interp_array_ring(self, xs_flat, ys_flat, chunk_queries, consumer=None, *, slots=None, n_slots=2):
+        """ndi_interp2d_eval_ring; see `_DeviceStrategy1D.interp_array_ring`."""
+        qx, qy = Buf(xs_flat, self._np_dtype), Buf(ys_flat, self._np_dtype)
+        if qx.memspace != qy.memspace:
+            raise TypeError("xs and ys must live in the same memory space")
+        ring = _capi.RingDesc()
+        ring.chunk_queries = int(chunk_queries)
+        keep_events = []
+        if slots is not None:
+            for t in slots:
+                _check_out_dtype(t, self._np_dtype)
+                if not (is_torch(t) and t.is_cuda and t.is_contiguous()) or t.numel() < chunk_queries * self._lanes:
+                    raise TypeError("ring slots must be contiguous device tensors of chunk_queries x lanes elements")
+            arr = (C.c_void_p * len(slots))(*[t.data_ptr() for t in slots])
+            ring.slots = C.cast(arr, C.POINTER(C.c_void_p))
+            ring.n_slots = len(slots)
+        else:
+            ring.n_slots = int(n_slots)
+        ring.row_stride = self._lanes
+
+        def _cb(_user, cptr):
+            c = cptr.contents
+            view = slots[c.slot].view(-1, self._lanes)[:c.q_count] if slots is not None else None
+            ev = consumer(c, view)
+            if ev is None:
+                return None
+            keep_events.append(ev)
+            return ev.cuda_event
+        cb = _capi.RING_CONSUMER(_cb) if consumer is not None else C.cast(None, _capi.RING_CONSUMER)
+        opts = _capi.EvalOpts()
+        opts.q_memspace = qx.memspace
+        opts.out_memspace = _capi.MEM_DEVICE
+        opts.path = self.path
+        opts.stream = current_stream_ptr(self._device)
+        info = _capi.OobInfo()
+        st = _capi.lib().ndi_interp2d_eval_ring(self._h, qx.ptr, qy.ptr, qx.size, C.byref(ring), cb, None,
+                                                C.byref(opts), C.byref(info))
+        del keep_events
         if st != _capi.OK:
             raise_eval(st, info)
 
@@ -214,7 +265,11 @@ class Interp2D:
         shape = self.get_buffer_shape(tuple(xs.shape))
         if is_torch(xs) and xs.is_cuda:
             import torch
-            zs = torch.empty(shape, dtype=xs.dtype, device=xs.device)
+            tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}.get(
+                np_dtype_of(self.data))
+            if tdt is None:
+                raise TypeError("device query tensors need f32 / f64 data; other element types use host arrays")
+            zs = torch.empty(shape, dtype=tdt, device=xs.device)
         else:
             zs = np.zeros(shape, dtype=np_dtype_of(self.data))
         self.interp_array_into(xs, ys, zs)
@@ -228,6 +283,8 @@ class Interp2D:
         if tuple(buffer.shape) != expect:
             raise Panic(f"ShapeError/IncompatibleShape: incompatible shapes expected: {list(expect)}, "
                         f"got: {list(buffer.shape)}")
+        if np_dtype_of(buffer) != np_dtype_of(self.data):
+            raise TypeError(f"buffer has element type {np_dtype_of(buffer)}, the data is {np_dtype_of(self.data)}")
         nq = int(np.prod(xs.shape, dtype=np.int64))
         lanes = int(np.prod(self._lanes_shape(), dtype=np.int64))
         xf, yf = xs.reshape(-1), ys.reshape(-1)
@@ -241,11 +298,28 @@ class Interp2D:
         if buffer.flags.c_contiguous:
             self.strategy.interp_array_into(self, xf, yf, buffer.reshape(nq, lanes), **kw)
             return
-        tmp = np.zeros((nq, lanes), dtype=buffer.dtype)
+        tmp = np.zeros((nq, lanes), dtype=np_dtype_of(self.data))
+        done = nq
         try:
             self.strategy.interp_array_into(self, xf, yf, tmp, **kw)
+        except InterpolateError.OutOfBounds as e:
+            done = e.index if e.index is not None else 0   # rows before the failing query are written,
+            raise                                          # later rows stay untouched (interp2d/mod.rs:297-306)
         finally:
-            buffer[...] = tmp.reshape(buffer.shape)
+            if done and len(xs.shape) == 0:
+                buffer[...] = tmp[0].reshape(buffer.shape)
+            elif done:
+                where = np.unravel_index(np.arange(done), tuple(xs.shape))
+                buffer[where] = tmp[:done].reshape((done,) + self._lanes_shape())
+
+    def interp_array_ring(self, xs, ys, chunk_queries, consumer=None, *, slots=None, n_slots=2):
+        """`interp_array` (interp2d/mod.rs:175-196) through a device-output ring (ndi_interp2d_eval_ring)."""
+        if tuple(xs.shape) != tuple(ys.shape):
+            raise Panic("`xs.shape()` and `ys.shape()` do not match")
+        if not hasattr(self.strategy, "interp_array_ring"):
+            raise TypeError("the ring evaluation needs the built-in device strategy (f32 / f64 data)")
+        self.strategy.interp_array_ring(xs.reshape(-1), ys.reshape(-1), chunk_queries, consumer, slots=slots,
+                                        n_slots=n_slots)
 
 
 class Interp2DBuilder:

@@ -9,7 +9,7 @@ and the minimum over ranks wins (MIN all-reduce of one int64 -- RCCL on the GPUs
 """
 from __future__ import annotations
 
-from .errors import InterpolateError
+from .errors import InterpolateError, Panic
 
 NO_FAIL = (1 << 62)
 
@@ -27,9 +27,34 @@ def eval_shard(evaluate, nq: int, rank: int, world: int):
     lo, hi = shard_bounds(nq, rank, world)
     try:
         evaluate(lo, hi)
-    except InterpolateError.OutOfBounds as e:  # local index -> global index
-        return lo + (e.index if e.index is not None else 0), e
+    except (InterpolateError.OutOfBounds, Panic) as e:  # local index -> global index
+        # a panic (NaN query while extrapolating) ends the reference's loop at that query just like an Err
+        return lo + (e.index if getattr(e, "index", None) is not None else 0), e
+    except Exception as e:  # noqa: BLE001 -- device failure: this rank must still reach the all-reduce
+        return lo, e        # (otherwise the other ranks block in it until the process-group timeout)
     return NO_FAIL, None
+
+
+def eval_sharded(evaluate, nq: int, rank: int, world: int, group=None, device=None):
+    """The whole protocol: evaluate this rank's block, MIN all-reduce the first failing global index (every
+    rank always enters the collective), then the rank that owns the winning index re-raises its exception and
+    the others raise `ShardFailed` naming it -- the reference's first-error result (interp1d/mod.rs:334-342)
+    reproduced across ranks.  Returns normally when no rank failed."""
+    local, exc = eval_shard(evaluate, nq, rank, world)
+    first = first_error_across_ranks(local, group=group, device=device)
+    if first == NO_FAIL:
+        return
+    if exc is not None and local == first:
+        raise exc
+    raise ShardFailed(first)
+
+
+class ShardFailed(RuntimeError):
+    """Another rank's shard holds the batch's first failing query."""
+
+    def __init__(self, index: int):
+        super().__init__(f"query {index} failed on another rank's shard")
+        self.index = index
 
 
 def first_error_across_ranks(local_fail: int, group=None, device=None) -> int:

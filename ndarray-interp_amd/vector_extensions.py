@@ -84,3 +84,50 @@ def get_lower_index(knots, xs, device: int = 0):
     if st != _capi.OK:
         raise DeviceError(f"{_capi.STATUS_NAMES[st]}: {_capi.last_error()}")
     return out.reshape(qb.shape)
+
+
+class Locator:
+    """`get_lower_index` with the knot pyramid resident on the device (ndi_locator_*): what
+    `Interp1D::get_index_left_of` (src/interp1d/mod.rs:380-382) is to a built interpolator -- no allocation or
+    knot upload per call."""
+
+    def __init__(self, knots, device: int | None = None):
+        import ctypes as C
+        kb = Buf(knots)
+        self._np_dtype = kb.np_dtype
+        self._memspace = kb.memspace
+        self._device = kb.device if kb.memspace == _capi.MEM_DEVICE else (device or 0)
+        h = C.c_void_p()
+        st = _capi.lib().ndi_locator_create(dtype_id(kb.np_dtype), self._device, kb.ptr, kb.size, kb.memspace,
+                                            C.byref(h))
+        if st != _capi.OK:
+            raise DeviceError(f"{_capi.STATUS_NAMES[st]}: {_capi.last_error()}")
+        self._h = h
+
+    def get_lower_index(self, xs):
+        """int64 indices (the shape of `xs`); -1 marks a NaN query.  numpy in -> numpy out, device tensor in ->
+        device tensor out (on the current stream)."""
+        from ._arrays import current_stream_ptr
+        qb = Buf(xs, self._np_dtype)
+        if qb.memspace == _capi.MEM_DEVICE:
+            import torch
+            out = torch.empty(qb.size, dtype=torch.int64, device=qb.keep.device)
+            optr, stream = out.data_ptr(), current_stream_ptr(self._device)
+        else:
+            out = np.empty(qb.size, dtype=np.int64)
+            optr, stream = out.ctypes.data, None
+        st = _capi.lib().ndi_locator_eval(self._h, qb.ptr, qb.size, optr, qb.memspace, stream)
+        if st != _capi.OK:
+            raise DeviceError(f"{_capi.STATUS_NAMES[st]}: {_capi.last_error()}")
+        return out.reshape(qb.shape)
+
+    def release(self):
+        if self._h is not None:
+            _capi.lib().ndi_locator_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

@@ -80,9 +80,91 @@ def test_individual_boundary_shape_error(pkg):
             pkg.BoundaryCondition.Individual([[R.Natural, R.NotAKnot], [R.Natural, R.NotAKnot]]))).build()
 
 
-def test_non_float_dtype_is_refused_by_device_strategies(pkg):
+def _intvec():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_integer_vectors.json")) as f:
+        return json.load(f)
+
+
+def test_integer_element_types_take_the_generic_per_query_path(pkg):
+    """i32 data on i32 axes (tests/interp2d.rs:29-47, 63-82) runs the default per-query loop with
+    the element type's own arithmetic -- no device, no float conversion."""
+    v = _intvec()
+    for case in v["interp2d_scalar"]:
+        b = pkg.Interp2DBuilder.new(np.array(case["data"], dtype=np.int32))
+        if case["x"] is not None:
+            b = b.x(np.array(case["x"], dtype=np.int32))
+        interp = b.build()
+        for (qx, qy), want in zip(case["queries"], case["expect"]):
+            got = interp.interp_scalar(qx, qy)
+            assert got == want and got.dtype == np.int32, (case["src"], qx, qy, got)
+        # the batched entry: the trait's default loop
+        q = np.array(case["queries"], dtype=np.int32)
+        res = interp.interp_array(q[:, 0], q[:, 1])
+        assert res.dtype == np.int32 and res.tolist() == case["expect"]
+    oob = v["interp2d_out_of_bounds"]
+    interp = pkg.Interp2DBuilder.new(np.array(oob["data"], dtype=np.int32)).build()
+    for (qx, qy), axis in zip(oob["queries"], oob["axis"]):
+        with pytest.raises(pkg.InterpolateError.OutOfBounds, match=rf"^{axis} = {qx if axis == 'x' else qy} is not in range"):
+            interp.interp(qx, qy)
+    # first-error semantics of the loop: rows before the failing query are written, later ones untouched
+    buf = np.full(3, -7, dtype=np.int32)
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        interp.interp_array_into(np.array([0, 5, 1], dtype=np.int32), np.array([0, 0, 1], dtype=np.int32), buf)
+    assert ei.value.index == 1 and buf.tolist() == [1, -7, -7]
+
+
+def test_integer_linear_truncating_division(pkg):
+    """Linear::calc_frac on i32 (linear.rs:29-36): `(y2 - y1) / (x2 - x1)` is Rust integer division."""
+    for case in _intvec()["derived_linear_i32"]:
+        data = np.array(case["data"], dtype=np.int32)
+        interp = pkg.Interp1DBuilder.new(data).x(np.array(case["x"], dtype=np.int32)).build()
+        res = interp.interp_array(np.array(case["queries"], dtype=np.int32))
+        assert res.dtype == np.int32 and res.tolist() == case["expect"], case["why"]
+        for q, want in zip(case["queries"], case["expect"]):
+            assert np.array_equal(interp.interp(q), np.array(want, dtype=np.int32))
+    # 1-D data: interp_scalar; extrapolation with the end interval
+    interp = pkg.Interp1DBuilder.new(np.array([0, 10], dtype=np.int64)).x(np.array([0, 4])).strategy(
+        pkg.Linear.new().extrapolate(True)).build()
+    assert interp.interp_scalar(6) == 12 and interp.interp_scalar(-1) == -2
+    with pytest.raises(pkg.InterpolateError.OutOfBounds, match="^x = 5 is not in range"):
+        pkg.Interp1DBuilder.new(np.array([0, 10])).x(np.array([0, 4])).build().interp_scalar(5)
+    # the spline needs a float element type (the reference's trait bounds: Pow / Euclid on T)
     with pytest.raises(TypeError, match="float32/float64"):
-        pkg.Interp1DBuilder.new(np.array([1, 2, 3])).build()
+        pkg.Interp1DBuilder.new(np.array([1, 2, 3])).strategy(pkg.CubicSpline.new()).build()
+
+
+def test_integer_builder_errors(pkg):
+    """tests/interp1d.rs:122-140, tests/interp2d.rs:281-329 with their i32 arrays."""
+    v = _intvec()
+    for c in v["interp1d_builder_errors"]["cases"]:
+        b = pkg.Interp1DBuilder.new(np.array(c["data"], dtype=np.int32))
+        if c["x"] is not None:
+            b = b.x(np.array(c["x"], dtype=np.int32))
+        with pytest.raises(getattr(pkg.BuilderError, c["error"])):
+            b.build()
+    for c in v["interp2d_builder_errors"]["cases"]:
+        b = pkg.Interp2DBuilder.new(np.array(c["data"], dtype=np.int32))
+        if c["x"] is not None:
+            b = b.x(np.array(c["x"], dtype=np.int32))
+        if c["y"] is not None:
+            b = b.y(np.array(c["y"], dtype=np.int32))
+        with pytest.raises(getattr(pkg.BuilderError, c["error"])):
+            b.build()
+
+
+def test_output_buffers_must_have_the_data_element_type(pkg):
+    """the kernels write sizeof(data element) per output element; a buffer of another element type
+    is refused on the host before anything reaches the device (the reference rejects it at compile time)."""
+    class FakeStrategy:
+        def interp_array_into(self, *a, **k):
+            raise AssertionError("must not be reached")
+    i1 = pkg.Interp1D.new_unchecked(np.arange(3.0), np.zeros((3, 2)), FakeStrategy())
+    with pytest.raises(TypeError, match="element type float32"):
+        i1.interp_array_into(np.zeros(4), np.zeros((4, 2), dtype=np.float32))
+    i2 = pkg.Interp2D.new_unchecked(np.arange(3.0), np.arange(3.0), np.zeros((3, 3, 2), dtype=np.float32), FakeStrategy())
+    with pytest.raises(TypeError, match="element type float64"):
+        i2.interp_array_into(np.zeros(4), np.zeros(4), np.zeros((4, 2)))
 
 
 def test_shard_bounds(pkg):

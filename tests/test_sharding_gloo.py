@@ -27,18 +27,33 @@ x = np.sort(rng.uniform(0, 1, n)); y = rng.uniform(0, 1, (n, L)); q = rng.unifor
 mode = os.environ["NDI_CASE"]
 if mode == "err":
     q[7001] = 5.0; q[9000] = -3.0; q[200 + 5003] = 9.0      # failures in both shards; lowest is 5203
+if mode == "nan":
+    q[8000] = np.nan                                        # in rank 1's shard; the other rank has no failure
 st, a, b = oracle.cubic_build(x, y)
 out = np.full((Q, L), -1.0)
 def evaluate(lo, hi):
-    s, fail, _ = oracle.interp1d_cubic(x, y, a, b, q[lo:hi], out=out[lo:hi])
+    if mode == "boom" and rank == 1:
+        raise RuntimeError("HIP_ERROR: device lost")         # a device failure on one rank only
+    ex = oracle.EXTRAPOLATE_YES if mode == "nan" else oracle.EXTRAPOLATE_NO
+    s, fail, _ = oracle.interp1d_cubic(x, y, a, b, q[lo:hi], extrapolate=ex, out=out[lo:hi])
     if s == oracle.OUT_OF_BOUNDS:
         raise pkg.InterpolateError.OutOfBounds("x = ? is not in range", index=fail, value=float(q[lo + fail]))
+    if s == oracle.NAN_QUERY:
+        raise pkg.Panic("not implemented: failed to convert NaN to usize", index=fail)
 local, exc = pkg.sharding.eval_shard(evaluate, Q, rank, world)
 first = pkg.sharding.first_error_across_ranks(local)
 lo, hi = pkg.sharding.shard_bounds(Q, rank, world)
+# the packaged protocol on the same inputs: every rank enters the all-reduce, the owner re-raises
+outcome = "ok"
+try:
+    pkg.sharding.eval_sharded(evaluate, Q, rank, world)
+except Exception as e:
+    outcome = f"{type(e).__name__}:{getattr(e, 'index', None)}"
 np.save(os.path.join(os.environ["NDI_OUT"], f"out{rank}.npy"), out[lo:hi])
 with open(os.path.join(os.environ["NDI_OUT"], f"first{rank}.txt"), "w") as f:
     f.write(f"{first} {lo} {hi}")
+with open(os.path.join(os.environ["NDI_OUT"], f"outcome{rank}.txt"), "w") as f:
+    f.write(outcome)
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -56,11 +71,18 @@ def _run(case):
         for p in procs:
             assert p.wait(timeout=240) == 0
         firsts, parts = [], []
+        global LAST_OUTCOMES
+        LAST_OUTCOMES = []
         for r in range(2):
             first, lo, hi = map(int, open(os.path.join(tmp, f"first{r}.txt")).read().split())
             firsts.append(first)
             parts.append((lo, hi, np.load(os.path.join(tmp, f"out{r}.npy"))))
+            op = os.path.join(tmp, f"outcome{r}.txt")
+            LAST_OUTCOMES.append(open(op).read() if os.path.exists(op) else None)
         return firsts, parts
+
+
+LAST_OUTCOMES = []
 
 
 def _inputs():
@@ -84,6 +106,20 @@ def test_two_rank_shards_equal_single_process(pkg):
 def test_two_rank_first_error_is_global_minimum(pkg):
     firsts, parts = _run("err")
     assert firsts == [5203, 5203]          # both ranks learn the reference's first failing index
+    # rank 1 owns query 5203 and re-raises its OutOfBounds (local index 199); rank 0 is told which query failed
+    assert LAST_OUTCOMES == ["ShardFailed:5203", "OutOfBounds:199"]
+
+
+def test_two_rank_panic_and_device_failure_do_not_hang(pkg):
+    """a NaN query while extrapolating (a panic in the reference) or a device failure on ONE rank must
+    not leave the other rank blocked in the MIN all-reduce; the panic's index is the global first failure."""
+    firsts, _ = _run("nan")
+    assert firsts == [8000, 8000]
+    assert LAST_OUTCOMES[0] == "ShardFailed:8000" and LAST_OUTCOMES[1].startswith("Panic:")
+    firsts, _ = _run("boom")
+    lo1 = pkg.sharding.shard_bounds(10007, 1, 2)[0]
+    assert firsts == [lo1, lo1]            # the failing rank reports its shard start
+    assert LAST_OUTCOMES == [f"ShardFailed:{lo1}", "RuntimeError:None"]
 
 
 GPU_WORKER = r'''

@@ -251,8 +251,13 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
     paths = {"auto": pkg.PATH_AUTO, "gather": pkg.PATH_GATHER, "bucketed": pkg.PATH_BUCKETED}
     interp.strategy.path = paths[args.path]
     qd = torch.as_tensor(q, device=dev)
-    # the ring: the first allocations of this process, taken as they come (no placement selection)
-    ring = [torch.empty((chunk, lanes), dtype=torch.float64, device=dev) for _ in range(args.ring_slots)]
+    # the ring: ONE allocation (the first of this process, taken as it comes) with the slots interleaved row by
+    # row -- the layout ndarray-interp_amd recommends and a library-owned ring uses;
+    # --ring-layout separate = one buffer per slot, rows contiguous (round 1's layout, for comparison)
+    if args.ring_layout == "striped":
+        ring = pkg.striped_ring(chunk, lanes, args.ring_slots, np.float64, dev.index)
+    else:
+        ring = [torch.empty((chunk, lanes), dtype=torch.float64, device=dev) for _ in range(args.ring_slots)]
     nchunks = (nq + chunk - 1) // chunk
     seen = {"chunks": 0, "rows": 0}
 
@@ -325,7 +330,9 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
                                f"{nq * lanes * 8 / 1e9:.1f} GB per step, never copied to the host)",
                    "path": prof["last_path"], "sharding": f"queries x{world}, tables replicated, no collective",
                    "output_ring": {"slots": args.ring_slots, "slot_bytes": chunk * lanes * 8,
-                                   "placement": "first allocations of the process, no selection"}},
+                                   "layout": "one allocation, slots interleaved row by row (striped_ring)"
+                                             if args.ring_layout == "striped" else "one buffer per slot",
+                                   "placement": "first allocation of the process, no selection"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "bytes_basis": "PMC traffic per launch (profiles/traffic.json)" if traffic else
@@ -375,27 +382,34 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
             "Mpoints_s": round(pts / (gms * 1e-3) / 1e6, 1)}
         interp.strategy.path = paths[args.path]
 
-    # placement sensitivity of the scattered row stream: the same chunk evaluated into each ring
-    # slot and into K further allocations; reported, never used for the headline
+    # placement sensitivity of the output stream: the same chunk evaluated into every slot of the
+    # ring in use, and into the slots of a second ring of the other layout; reported, never used for the headline
     if args.placement_probe > 0:
-        free_b, _ = torch.cuda.mem_get_info(dev)
-        k_extra = max(0, min(args.placement_probe, int((free_b - (8 << 30)) // (chunk * lanes * 8))))
-        cands = list(ring) + [torch.empty((chunk, lanes), dtype=torch.float64, device=dev) for _ in range(k_extra)]
-        probe = []
-        for c in cands:
+        def probe_ms(c):
             interp.strategy.interp_array_into(interp, qd[:chunk], c, async_launch=True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _r in range(2):
                 interp.strategy.interp_array_into(interp, qd[:chunk], c, async_launch=True)
             e1.record(); e1.synchronize()
-            probe.append(round(e0.elapsed_time(e1) / 2, 3))
+            return round(e0.elapsed_time(e1) / 2, 3)
+        ring_ms = [probe_ms(c) for c in ring]
+        other_ms = []
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        k = max(0, min(args.placement_probe, int((free_b - (8 << 30)) // (chunk * lanes * 8))))
+        if k:
+            other = pkg.striped_ring(chunk, lanes, k, np.float64, dev.index) if args.ring_layout != "striped" else \
+                [torch.empty((chunk, lanes), dtype=torch.float64, device=dev) for _ in range(k)]
+            other_ms = [probe_ms(c) for c in other]
+            del other
         interp.strategy.finish()
-        line["placement"] = {"ms_per_chunk_ring_slots": probe[:len(ring)], "ms_per_chunk_other_allocations": probe[len(ring):],
-                             "spread": round(max(probe) / min(probe) - 1, 4),
-                             "best_of_all_Mpoints_s": round(chunk * lanes / (min(probe) * 1e-3) / 1e6, 1),
-                             "first_allocation_Mpoints_s": round(chunk * lanes / (probe[0] * 1e-3) / 1e6, 1)}
-        del cands
+        striped_ms, separate_ms = (ring_ms, other_ms) if args.ring_layout == "striped" else (other_ms, ring_ms)
+        line["placement"] = {"ms_per_chunk_striped_slots": striped_ms, "ms_per_chunk_separate_buffers": separate_ms,
+                             "spread_striped": round(max(striped_ms) / min(striped_ms) - 1, 4) if striped_ms else None,
+                             "spread_separate": round(max(separate_ms) / min(separate_ms) - 1, 4) if separate_ms else None,
+                             "ring_in_use": args.ring_layout,
+                             "best_of_all_Mpoints_s": round(chunk * lanes / (min(ring_ms + other_ms) * 1e-3) / 1e6, 1)}
+        torch.cuda.empty_cache()
 
     if world == 1 and not args.no_cpu_baseline:
         res, build_s = cpu_baseline(x, y, q)
@@ -420,11 +434,14 @@ def main():
     ap.add_argument("--queries", type=int, default=None,
                     help="queries per GPU per step (target: 10000000; 12500000 = C4's per-GPU share; c2: 1000000)")
     ap.add_argument("--chunk", type=int, default=1_000_000, help="target: queries per ring chunk")
-    ap.add_argument("--ring-slots", type=int, default=2, help="target: device-output ring slots (32.8 GB each)")
+    ap.add_argument("--ring-slots", type=int, default=4, help="target: device-output ring slots (32.8 GB each)")
     ap.add_argument("--path", choices=["auto", "gather", "bucketed"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the sampled-rows check against the CPU oracle")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the extra pass with the gather formulation")
+    ap.add_argument("--ring-layout", choices=["striped", "separate"], default="striped",
+                    help="target: striped = one allocation, slots interleaved row by row (recommended); separate = one "
+                         "buffer per slot")
     ap.add_argument("--placement-probe", type=int, default=3,
                     help="after the timed region, evaluate one chunk into each ring slot and into this many further "
                          "allocations and report the spread (0 = skip); never used for the headline value")

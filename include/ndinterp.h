@@ -223,13 +223,19 @@ typedef struct ndi_ring_chunk {
 
 typedef void* (*ndi_ring_consumer)(void* user, const ndi_ring_chunk* chunk);
 
+/* Ring layout.  slots[i] points at row 0 of slot i; row r of a chunk is at slots[i] + r * row_stride elements.
+ * Slots may be separate buffers (row_stride >= lanes), but on MI355X the recommended layout is ONE allocation with
+ * the slots interleaved row by row: slots[i] = base + i * lanes, row_stride = n_slots * lanes.  The rate at which
+ * a kernel streams into a 32.8 GB extent depends on where that extent lies in physical memory (up to 27 %
+ * between the slots of one allocation); striping every chunk over the whole ring removes the dependence
+ * (DESIGN.md 4.3).  With slots == NULL the library owns the ring (allocated once per handle, kept until trim /
+ * destroy) and uses exactly that layout: chunk->row_stride is then n_slots * max(row_stride, lanes). */
 typedef struct ndi_ring_desc {
-  void* const* slots;     /* n_slots device buffers of chunk_queries * row_stride elements each, or NULL:
-                             the library owns the ring (allocated once per handle, kept until trim / destroy) */
-  uint32_t n_slots;       /* >= 1 (2-3 when the consumer runs on its own stream) */
+  void* const* slots;     /* n_slots device pointers, or NULL for a library-owned ring */
+  uint32_t n_slots;       /* >= 1 */
   uint32_t reserved;
   uint64_t chunk_queries; /* rows per chunk */
-  uint64_t row_stride;    /* elements, >= lanes; 0 = lanes */
+  uint64_t row_stride;    /* elements between consecutive rows of a slot (>= lanes; 0 = lanes) */
 } ndi_ring_desc;
 
 ndi_status ndi_interp1d_eval_ring(const ndi_interp1d* h, const void* q, uint64_t nq,

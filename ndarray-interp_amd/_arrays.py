@@ -68,3 +68,14 @@ def current_stream_ptr(device: int):
     if torch is None or not torch.cuda.is_available():
         return None
     return torch.cuda.current_stream(device).cuda_stream
+
+
+
+def striped_ring(chunk_queries: int, lanes: int, n_slots: int, dtype=np.float64, device: int = 0):
+    """The recommended ring layout on MI355X (include/ndinterp.h): ONE device allocation with the
+    slots interleaved row by row.  Returns `n_slots` views of shape (chunk_queries, lanes) whose rows are
+    contiguous and `n_slots * lanes` elements apart -- every chunk's output stream then covers the whole ring's
+    physical extent instead of one 1/n_slots part of it."""
+    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[np.dtype(dtype)]
+    base = torch.empty((chunk_queries, n_slots, lanes), dtype=tdt, device=f"cuda:{device}")
+    return [base[:, s, :] for s in range(n_slots)]

@@ -693,7 +693,13 @@ __global__ __launch_bounds__(BLOCK) void group_scatter_kernel(const uint32_t* id
 // One workgroup streams CQ grouped queries x one 256*U-vector row segment.  The four operand
 // row segments stay in registers while the interval does not change, so table traffic is
 // ~ (1/CQ + 1/queries-per-interval) of the gather formulation and the kernel is an output stream.
-template <class T, int STRAT, int U, int CQ, bool NT = true>
+// FULL: the row length is a whole number of 256*U-vector segments, so no per-vector bounds test is needed and
+// the loop body is straight-line code.  That matters for more than the branches: with control flow between the
+// (conditional) table loads and their first use the compiler cannot count outstanding memory operations and
+// drains them all (`s_waitcnt vmcnt(0)`, which on CDNA4 includes the wave's own stores) before every one of the
+// U store groups -- one 1 KiB store in flight per wave.  Straight-line, it waits for exactly the loads a segment
+// needs and the stores of several queries stay in flight.
+template <class T, int STRAT, int U, int CQ, bool NT = true, bool FULL = false>
 __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
   constexpr int VN = Wide<T>::N;
   using V = typename VecT<T, VN>::type;
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const uint64_t v = v0 + (uint64_t)u * BLOCK;
-            if (v < LV) {
+            if (FULL || v < LV) {
               ryl[u] = yl[v];
               ryr[u] = yr[v];
               if (STRAT == ST_CUBIC) {
@@ -758,7 +764,7 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint64_t v = v0 + (uint64_t)u * BLOCK;
-          if (v < LV) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
+          if (FULL || v < LV) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
         }
       }
     }

@@ -279,16 +279,18 @@ struct SpaceLease {
   SpaceLease& operator=(const SpaceLease&) = delete;
 };
 
-// A ring of device buffers owned by a handle (ndi_ring_desc::slots == NULL).
+// A ring of device buffers owned by a handle (ndi_ring_desc::slots == NULL): ONE allocation in which the slots
+// are interleaved row by row -- row r of slot s lives at (r * n_slots + s) * row_stride, i.e. the chunk's rows have
+// the pitch n_slots * row_stride.  Measured on MI355X (profiles/r02_placement_*.jsonl): the rate at
+// which a kernel streams into a 32.8 GB extent depends on where the extent lies in physical memory (slots laid
+// out one after the other in one allocation ran 6.1 / 5.9 / 5.6 / 4.7 ms for the same chunk, stable, and the same
+// for sequential fills); with the rows of every slot striped over the whole ring each chunk's stream covers the
+// ring's full extent and runs at the fast end (4.57-4.77 ms in 8 of 9 processes, < 1 % apart within a ring).
 struct OwnedRing {
   std::mutex mu;   // one ring evaluation at a time uses the library-owned ring
-  std::vector<std::unique_ptr<DevBuf>> slots;
-  void ensure(uint32_t n, size_t bytes) {
-    if (slots.size() > n) slots.resize(n);
-    while (slots.size() < n) slots.emplace_back(new DevBuf());
-    for (auto& b : slots) b->reserve(bytes);
-  }
-  void clear() { slots.clear(); }
+  DevBuf buf;
+  void ensure(uint32_t n, size_t chunk_rows, size_t stride_bytes) { buf.reserve((size_t)n * chunk_rows * stride_bytes); }
+  void clear() { buf.release(); }
 };
 
 template <class T, class K, class A>
@@ -674,7 +676,12 @@ struct Interp1DImpl final : Interp1DBase {
       const uint64_t per_xcd = ((nq + CQ - 1) / CQ + 7) / 8;
       const unsigned gx = (unsigned)std::max<uint64_t>(8, std::min<uint64_t>(per_xcd * 8, 65528));
       dim3 grid(gx, (unsigned)std::min<uint64_t>(segs, 64));
-#define NDI_BK(ST, UU) launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_bucketed_kernel<T, ST, UU, CQ>, A)
+      const bool full = LV % ((uint64_t)BLOCK * U) == 0;   // whole segments only: straight-line kernel variant
+#define NDI_BK(ST, UU)                                                                                      \
+  do {                                                                                                      \
+    if (full) launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_bucketed_kernel<T, ST, UU, CQ, true, true>, A); \
+    else launch1<T>(s, PC_EVAL, grid, dim3(BLOCK), 0, eval_bucketed_kernel<T, ST, UU, CQ, true, false>, A);   \
+  } while (0)
       if (strategy == NDI_CUBIC_SPLINE) {
         if (U == 8) NDI_BK(ST_CUBIC, 8); else if (U == 4) NDI_BK(ST_CUBIC, 4);
         else if (U == 2) NDI_BK(ST_CUBIC, 2); else NDI_BK(ST_CUBIC, 1);
@@ -912,15 +919,17 @@ struct Interp1DImpl final : Interp1DBase {
 
     std::unique_lock<std::mutex> own(ring_own.mu, std::defer_lock);
     std::vector<void*> slots(ring->n_slots);
+    uint64_t pitch = stride;          // row pitch of a chunk, in elements
     if (ring->slots) {
       for (uint32_t i = 0; i < ring->n_slots; ++i) {
         if (!ring->slots[i]) return fail(NDI_BAD_ARG, "ring slot %u is null", i);
         slots[i] = ring->slots[i];
       }
     } else {
-      own.lock();
-      ring_own.ensure(ring->n_slots, (size_t)ring->chunk_queries * stride * sizeof(T));
-      for (uint32_t i = 0; i < ring->n_slots; ++i) slots[i] = ring_own.slots[i]->p;
+      own.lock();    // library-owned ring: one allocation, slots interleaved row by row (see OwnedRing)
+      ring_own.ensure(ring->n_slots, ring->chunk_queries, stride * sizeof(T));
+      for (uint32_t i = 0; i < ring->n_slots; ++i) slots[i] = (char*)ring_own.buf.p + (size_t)i * stride * sizeof(T);
+      pitch = (uint64_t)ring->n_slots * stride;
     }
     std::vector<hipEvent_t> busy(ring->n_slots, nullptr);
     uint64_t k = 0;
@@ -931,10 +940,10 @@ struct Interp1DImpl final : Interp1DBase {
         NDI_HIP(hipStreamWaitEvent(s, busy[slot], 0));
         busy[slot] = nullptr;
       }
-      enqueue(s, ws, q + off, cq, (T*)slots[slot], stride, o.path);
+      enqueue(s, ws, q + off, cq, (T*)slots[slot], pitch, o.path);
       if (consume) {
         ndi_ring_chunk c{};
-        c.index = k; c.q_begin = off; c.q_count = cq; c.out = slots[slot]; c.row_stride = stride;
+        c.index = k; c.q_begin = off; c.q_count = cq; c.out = slots[slot]; c.row_stride = pitch;
         c.slot = slot; c.stream = (void*)s;
         busy[slot] = (hipEvent_t)consume(user, &c);
       }
@@ -1391,15 +1400,17 @@ struct Interp2DImpl final : Interp2DBase {
 
     std::unique_lock<std::mutex> own(ring_own.mu, std::defer_lock);
     std::vector<void*> slots(ring->n_slots);
+    uint64_t pitch = stride;          // row pitch of a chunk, in elements
     if (ring->slots) {
       for (uint32_t i = 0; i < ring->n_slots; ++i) {
         if (!ring->slots[i]) return fail(NDI_BAD_ARG, "ring slot %u is null", i);
         slots[i] = ring->slots[i];
       }
     } else {
-      own.lock();
-      ring_own.ensure(ring->n_slots, (size_t)ring->chunk_queries * stride * sizeof(T));
-      for (uint32_t i = 0; i < ring->n_slots; ++i) slots[i] = ring_own.slots[i]->p;
+      own.lock();    // library-owned ring: one allocation, slots interleaved row by row (see OwnedRing)
+      ring_own.ensure(ring->n_slots, ring->chunk_queries, stride * sizeof(T));
+      for (uint32_t i = 0; i < ring->n_slots; ++i) slots[i] = (char*)ring_own.buf.p + (size_t)i * stride * sizeof(T);
+      pitch = (uint64_t)ring->n_slots * stride;
     }
     std::vector<hipEvent_t> busy(ring->n_slots, nullptr);
     uint64_t k = 0;
@@ -1410,10 +1421,10 @@ struct Interp2DImpl final : Interp2DBase {
         NDI_HIP(hipStreamWaitEvent(s, busy[slot], 0));
         busy[slot] = nullptr;
       }
-      enqueue(s, ws, qx + off, qy + off, cq, (T*)slots[slot], stride, o.path);
+      enqueue(s, ws, qx + off, qy + off, cq, (T*)slots[slot], pitch, o.path);
       if (consume) {
         ndi_ring_chunk c{};
-        c.index = k; c.q_begin = off; c.q_count = cq; c.out = slots[slot]; c.row_stride = stride;
+        c.index = k; c.q_begin = off; c.q_count = cq; c.out = slots[slot]; c.row_stride = pitch;
         c.slot = slot; c.stream = (void*)s;
         busy[slot] = (hipEvent_t)consume(user, &c);
       }

@@ -170,18 +170,22 @@ class _DeviceStrategy1D(Interp1DStrategy):
         if slots is not None:
             for t in slots:
                 _check_out_dtype(t, self._np_dtype)
-                if not (is_torch(t) and t.is_cuda and t.is_contiguous()) or t.numel() < chunk_queries * self._lanes:
-                    raise TypeError("ring slots must be contiguous device tensors of chunk_queries x lanes elements")
+                if not (is_torch(t) and t.is_cuda and t.dim() == 2 and t.shape[1] == self._lanes
+                        and t.shape[0] >= chunk_queries and (t.stride(1) == 1 or self._lanes == 1)
+                        and t.stride(0) == slots[0].stride(0)):
+                    raise TypeError("ring slots must be device tensors of shape (>= chunk_queries, lanes) with "
+                                    "contiguous rows and one common row pitch (see striped_ring)")
             arr = (C.c_void_p * len(slots))(*[t.data_ptr() for t in slots])
             ring.slots = C.cast(arr, C.POINTER(C.c_void_p))
             ring.n_slots = len(slots)
+            ring.row_stride = max(slots[0].stride(0), self._lanes)
         else:
             ring.n_slots = int(n_slots)
-        ring.row_stride = self._lanes
+            ring.row_stride = self._lanes
 
         def _cb(_user, cptr):
             c = cptr.contents
-            view = slots[c.slot].view(-1, self._lanes)[:c.q_count] if slots is not None else None
+            view = slots[c.slot][:c.q_count] if slots is not None else None
             ev = consumer(c, view)
             if ev is None:
                 return None

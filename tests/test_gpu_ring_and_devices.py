@@ -49,10 +49,15 @@ def test_ring_chunks_equal_one_batch(pkg, dt, own_ring):
         def consumer(c, rows):
             assert rows is None
             # wrap the raw device pointer: copy the chunk out on the chunk's stream (stream-ordered before reuse)
+            # the library-owned ring is one allocation with the slots interleaved row by row
+            assert c.row_stride == 3 * 1024
             host = np.empty((c.q_count, 1024), dtype=dt)
             hip = C.CDLL("libamdhip64.so")
-            hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-            assert hip.hipMemcpyAsync(host.ctypes.data, c.out, host.nbytes, 2, c.stream) == 0
+            hip.hipMemcpy2DAsync.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                             C.c_int, C.c_void_p]
+            isz = host.itemsize
+            assert hip.hipMemcpy2DAsync(host.ctypes.data, 1024 * isz, c.out, c.row_stride * isz, 1024 * isz,
+                                        c.q_count, 2, c.stream) == 0
             assert hip.hipStreamSynchronize(C.c_void_p(c.stream)) == 0
             got[c.q_begin:c.q_begin + c.q_count] = host
             seen.append((c.index, c.q_begin, c.q_count, c.slot))
@@ -69,6 +74,16 @@ def test_ring_chunks_equal_one_batch(pkg, dt, own_ring):
     assert [s[0] for s in seen] == list(range(5)) and [s[1] for s in seen] == [0, 2048, 4096, 6144, 8192]
     assert seen[-1][2] == Q - 4 * chunk
     assert np.array_equal(got, ref)
+    # the recommended caller-owned layout: striped_ring (rows of a slot n_slots * lanes apart)
+    sring = pkg.striped_ring(chunk, 1024, 3, dt, 0)
+    assert sring[1].data_ptr() - sring[0].data_ptr() == 1024 * np.dtype(dt).itemsize and sring[0].stride(0) == 3 * 1024
+    got3 = np.zeros_like(ref)
+
+    def consumer3(c, rows):
+        assert c.row_stride == 3 * 1024 and rows.data_ptr() == c.out and tuple(rows.shape) == (c.q_count, 1024)
+        got3[c.q_begin:c.q_begin + c.q_count] = rows.cpu().numpy()
+    interp.interp_array_ring(qd, chunk, consumer3, slots=sring)
+    assert np.array_equal(got3, ref)
     # host queries are accepted as well (uploaded once), and both formulations agree
     interp.strategy.path = pkg.PATH_GATHER
     got2 = np.zeros_like(ref)
@@ -369,3 +384,4 @@ def test_one_process_drives_every_device(pkg):
     assert not errors, errors
     for d in range(ndev):
         assert np.array_equal(results[d][0], ref), d
+

@@ -369,6 +369,7 @@ struct Eval1Args {
   const StatusBlock* status;
   // bucketed
   const uint32_t* perm;
+  uint32_t run;   // consecutive chunks per workgroup (0 = 1)
 };
 
 // Per-query scalars shared by all lanes of a row.
@@ -716,55 +717,72 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
   // XCD-aware chunk order: workgroups b and b+8 share an XCD (and its L2), so XCD k walks the contiguous
   // chunk range [k*per, (k+1)*per): neighbouring chunks belong to the same or adjacent intervals and
   // re-use each other's operand rows from that L2 instead of fetching them once per XCD.
+  // A workgroup takes a RUN of A.run consecutive chunks and keeps the operand rows in registers across the
+  // chunk boundaries, so a table row is fetched about once per interval instead of once per chunk it appears in:
+  // table reads interleaved into the write stream cost more than their share of the bytes (tools/tune_bucketed.hip:
+  // 4 operand rows per chunk 4.90 ms, 1 row 4.68 ms, none 4.68 ms = the store-only ceiling).
   // (Placement is a speed heuristic only -- any mapping gives the same result.)
   const uint64_t per = (nchunks + 7) / 8;
-  for (uint64_t vb = blockIdx.x; vb < per * 8; vb += gridDim.x) {
-    const uint64_t chunk = (vb & 7u) * per + (vb >> 3);
-    if ((vb >> 3) >= per || chunk >= nchunks) continue;
-    const uint64_t p0 = chunk * CQ;
-    const uint32_t cnt = (n_valid - p0 < (uint64_t)CQ) ? (uint32_t)(n_valid - p0) : (uint32_t)CQ;
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) {
-      const uint32_t qi = A.perm[p0 + j];
-      s_q[j] = qi;
-      s_i[j] = A.idx[qi];
-      s_s[j] = (STRAT == ST_CUBIC) ? A.t[qi] : A.q[qi];
-    }
-    __syncthreads();
-    for (uint32_t seg = blockIdx.y; seg < segs; seg += gridDim.y) {
-      const uint64_t v0 = (uint64_t)seg * seg_vecs + threadIdx.x;
+  const uint64_t run = A.run ? A.run : 1;
+  const uint64_t runs_per_xcd = (per + run - 1) / run;
+  for (uint32_t seg = blockIdx.y; seg < segs; seg += gridDim.y) {
+    const uint64_t v0 = (uint64_t)seg * seg_vecs + threadIdx.x;
+    for (uint64_t vb = blockIdx.x; vb < runs_per_xcd * 8; vb += gridDim.x) {
+      const uint64_t xcd = vb & 7u;
+      const uint64_t c_begin = xcd * per + (vb >> 3) * run;
+      uint64_t c_end = c_begin + run;
+      if (c_end > (xcd + 1) * per) c_end = (xcd + 1) * per;
+      if (c_end > nchunks) c_end = nchunks;
       V ryl[U], ryr[U], ra[U], rb[U];
       uint32_t cur = 0xffffffffu;
-      for (uint32_t j = 0; j < cnt; ++j) {
-        const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_i[j]);
-        const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_q[j]);
-        if (qi >= limit) continue;
-        const T sj = s_s[j];
-        if (i != cur) {
-          cur = i;
-          const V* yl = reinterpret_cast<const V*>(A.data + (uint64_t)i * A.lanes);
-          const V* yr = yl + LV;
-          const V* pa = reinterpret_cast<const V*>(A.ca + (uint64_t)i * A.lanes);
-          const V* pb = reinterpret_cast<const V*>(A.cb + (uint64_t)i * A.lanes);
+      for (uint64_t chunk = c_begin; chunk < c_end; ++chunk) {
+        const uint64_t p0 = chunk * CQ;
+        const uint32_t cnt = (n_valid - p0 < (uint64_t)CQ) ? (uint32_t)(n_valid - p0) : (uint32_t)CQ;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) {
+          const uint32_t qi = A.perm[p0 + j];
+          s_q[j] = qi;
+          s_i[j] = A.idx[qi];
+          s_s[j] = (STRAT == ST_CUBIC) ? A.t[qi] : A.q[qi];
+        }
+        __syncthreads();
+        for (uint32_t j = 0; j < cnt; ++j) {
+          const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_i[j]);
+          const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_q[j]);
+          if (qi >= limit) continue;
+          const T sj = s_s[j];
+          if (i != cur) {
+            cur = i;
+            const V* yl = reinterpret_cast<const V*>(A.data + (uint64_t)i * A.lanes);
+            const V* yr = yl + LV;
+            const V* pa = reinterpret_cast<const V*>(A.ca + (uint64_t)i * A.lanes);
+            const V* pb = reinterpret_cast<const V*>(A.cb + (uint64_t)i * A.lanes);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const uint64_t v = v0 + (uint64_t)u * BLOCK;
+              if (FULL || v < LV) {
+                ryl[u] = yl[v];
+                ryr[u] = yr[v];
+                if (STRAT == ST_CUBIC) {
+                  ra[u] = pa[v];
+                  rb[u] = pb[v];
+                }
+              }
+            }
+            // NOTE (measured, tools/_run7 / profiles/r02_tuning.md): draining the loads here with an explicit
+            // s_waitcnt vmcnt(0), so that the compute/store section below carries no waits at all and the stores run
+            // ahead without limit, is SLOWER (5.10-5.37 ms vs 4.93): the waits the compiler places below for the
+            // reload path (vmcnt(28) ... vmcnt(7)) act on the wave's own stores on the common path -- vmcnt counts
+            // stores on CDNA4 -- and keep about one query's stores in flight per wave, which is the pacing the
+            // memory system runs best at together with the polynomial's VALU work.
+          }
+          const RowCoef<T, STRAT> c = row_coef<T, STRAT>(A.knots, i, sj, sj);
+          V* o = reinterpret_cast<V*>(A.out + (uint64_t)qi * A.out_stride);
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const uint64_t v = v0 + (uint64_t)u * BLOCK;
-            if (FULL || v < LV) {
-              ryl[u] = yl[v];
-              ryr[u] = yr[v];
-              if (STRAT == ST_CUBIC) {
-                ra[u] = pa[v];
-                rb[u] = pb[v];
-              }
-            }
+            if (FULL || v < LV) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
           }
-        }
-        const RowCoef<T, STRAT> c = row_coef<T, STRAT>(A.knots, i, sj, sj);
-        V* o = reinterpret_cast<V*>(A.out + (uint64_t)qi * A.out_stride);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint64_t v = v0 + (uint64_t)u * BLOCK;
-          if (FULL || v < LV) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
         }
       }
     }

@@ -309,6 +309,7 @@ static void reset_status(Workspace& ws, hipStream_t s) {
                          sizeof(StatusBlock) - 2 * sizeof(unsigned long long), s));
 }
 
+constexpr uint32_t BUCKETED_RUN = 4;         // consecutive 128-query chunks per workgroup of eval_bucketed_kernel
 constexpr uint32_t GROUP_MAX_BLOCKS = 256;   // query slices of the block-local counting sort
 constexpr uint32_t GROUP_MAX_BINS = 16384;   // histogram must fit LDS next to the pyramid
 
@@ -672,9 +673,13 @@ struct Interp1DImpl final : Interp1DBase {
       constexpr int CQ = 128;
       const int U = LV >= 2048 ? 8 : (LV >= 1024 ? 4 : (LV >= 512 ? 2 : 1));
       const uint64_t segs = (LV + (uint64_t)BLOCK * U - 1) / ((uint64_t)BLOCK * U);
-      // a multiple of 8 so that a workgroup keeps its XCD residue when it strides (XCD-aware chunk order)
+      // a multiple of 8 so that a workgroup keeps its XCD residue when it strides (XCD-aware chunk order);
+      // every workgroup takes a run of consecutive chunks (operand rows stay in registers across them)
+      static const uint32_t run_env = [] { const char* e = std::getenv("NDI_BUCKETED_RUN"); return e ? (uint32_t)std::atoi(e) : 0u; }();
       const uint64_t per_xcd = ((nq + CQ - 1) / CQ + 7) / 8;
-      const unsigned gx = (unsigned)std::max<uint64_t>(8, std::min<uint64_t>(per_xcd * 8, 65528));
+      A.run = run_env ? run_env : BUCKETED_RUN;
+      const uint64_t runs_per_xcd = (per_xcd + A.run - 1) / A.run;
+      const unsigned gx = (unsigned)std::max<uint64_t>(8, std::min<uint64_t>(runs_per_xcd * 8, 65528));
       dim3 grid(gx, (unsigned)std::min<uint64_t>(segs, 64));
       const bool full = LV % ((uint64_t)BLOCK * U) == 0;   // whole segments only: straight-line kernel variant
 #define NDI_BK(ST, UU)                                                                                      \

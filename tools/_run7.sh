@@ -1,0 +1,6 @@
+set -x
+mkdir -p gpurun_out/r02
+python -m pytest tests -m gpu -x -q > gpurun_out/r02/pytest7.log 2>&1; echo rc=$?; tail -3 gpurun_out/r02/pytest7.log
+for run in 1 4; do
+NDI_BUCKETED_RUN=$run python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-gather-leg --placement-probe 0 > gpurun_out/r02/bench7_run$run.json 2> gpurun_out/r02/bench7.err; echo bench rc=$?
+done

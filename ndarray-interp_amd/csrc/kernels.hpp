@@ -802,7 +802,7 @@ struct Eval2Args {
   const uint32_t* xi;
   const uint32_t* yi;
   T* out;
-  uint64_t ny, lanes, out_stride, nq;
+  uint64_t nx, ny, lanes, out_stride, nq;
   // addressing of the corner rows: element offset of cell (xi, yi) = (xi * row_cells + yi) * cell_elems.
   // plain layout [nx][ny][lanes]: row_cells = ny, cell_elems = lanes; pair-packed layout (see
   // pack_pairs_kernel): row_cells = ny - 1, cell_elems = 2 * lanes.  z12 is always z11 + lanes.
@@ -812,6 +812,11 @@ struct Eval2Args {
   const uint4* rec_i;    // {query index, xi, yi, 0}
   const T* rec_q;        // {qx, qy} pairs
 };
+
+template <class T, bool LDS>
+struct KnotPtr { using type = const T*; };
+template <class T>
+struct KnotPtr<T, true> { using type = const __attribute__((address_space(3))) T*; };
 
 // 2-D grouping key: the tile (2^sx x 2^sy cells) a query's cell falls in.  One workgroup per contiguous
 // query slice; leaves the keys and the slice's tile histogram (same layout as locate_kernel's).
@@ -863,16 +868,21 @@ __global__ __launch_bounds__(BLOCK) void group_scatter2d_kernel(const uint32_t* 
 // corners a query needs from one grid row become one naturally aligned segment (128 B at 16 f32 channels), so a
 // query touches exactly two cache lines instead of three on average (a 64-B-aligned 128-B segment straddles
 // two 128-B lines half of the time).  Costs 2x the grid memory; values are copied, never recomputed.
-template <class T>
-__global__ __launch_bounds__(BLOCK) void pack_pairs_kernel(const T* in, T* out, uint64_t nx, uint64_t ny,
-                                                           uint64_t lanes) {
-  const uint64_t total = nx * (ny - 1) * 2 * lanes;
-  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
-    const uint64_t c = e % lanes;
-    const uint64_t h = (e / lanes) & 1u;
-    const uint64_t cell = e / (2 * lanes);
-    const uint64_t xi = cell / (ny - 1), yi = cell - xi * (ny - 1);
-    out[e] = in[(xi * ny + yi + h) * lanes + c];
+// E = copy unit (a 16-byte vector when the cell size allows, else one element); units = copy units per grid
+// point.  grid.y walks the grid rows, so the only per-unit index arithmetic is the split of the in-row position
+// into (pair, unit): a shift when `units` is a power of two (unit_shift >= 0), one division otherwise.
+template <class E>
+__global__ __launch_bounds__(BLOCK) void pack_pairs_kernel(const E* in, E* out, uint64_t nx, uint64_t ny,
+                                                           uint32_t units, int unit_shift) {
+  const uint64_t row_out = (ny - 1) * 2 * units;   // copy units per packed grid row
+  for (uint64_t xi = blockIdx.y; xi < nx; xi += gridDim.y) {
+    const E* src = in + xi * ny * units;
+    E* dst = out + xi * row_out;
+    for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < row_out; e += (uint64_t)gridDim.x * BLOCK) {
+      const uint64_t pair = unit_shift >= 0 ? e >> unit_shift : e / units;   // = 2 * yi + h
+      const uint64_t c = e - pair * units;
+      dst[e] = src[((pair >> 1) + (pair & 1u)) * units + c];                // z[xi][yi + h][c]
+    }
   }
 }
 
@@ -886,9 +896,28 @@ __device__ __forceinline__ V frac_v(T x1, V y1, T x2, V y2, T x) {
   return m * (x - x1) + y1;
 }
 
-template <class T, int VEC, bool APPROX = false>
-__global__ __launch_bounds__(BLOCK) void eval_bilinear_kernel(Eval2Args<T> A, uint32_t tile_q) {
+// UNR items (one output vector each) per thread and loop trip, processed in three phases -- indices and query
+// values, then knots and the four corner vectors, then arithmetic and store -- so that the two dependent memory
+// latencies of an item (index -> corner) are paid once per UNR items: the kernel is a random gather whose only
+// lever is memory-level parallelism (C5, 8192 x 8192 x 16 f32: UNR 1 -> 2: 0.88 -> see DESIGN.md 4.4).
+// KLDS: both knot vectors are staged in LDS once per workgroup (TB = 1024 threads, a grid of about two workgroups
+// per CU) and the four knot values of an item come from there instead of four scattered global loads.
+template <class T, int VEC, bool APPROX = false, int UNR = 2, int TB = BLOCK, bool KLDS = false>
+__global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint32_t tile_q) {
   using V = typename VecT<T, VEC>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typename KnotPtr<T, KLDS>::type xk, yk;
+  if constexpr (KLDS) {
+    T* s0 = reinterpret_cast<T*>(smem_raw);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)A.nx; i += TB) s0[i] = A.xk[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)A.ny; i += TB) s0[A.nx + i] = A.yk[i];
+    __syncthreads();
+    xk = (lds_ptr<T>)(smem_raw);
+    yk = xk + A.nx;
+  } else {
+    xk = A.xk;
+    yk = A.yk;
+  }
   const uint32_t LV = (uint32_t)(A.lanes / VEC);
   unsigned long long limit = A.status->first_fail[0];
   if (A.status->first_fail[1] < limit) limit = A.status->first_fail[1];
@@ -900,37 +929,53 @@ __global__ __launch_bounds__(BLOCK) void eval_bilinear_kernel(Eval2Args<T> A, ui
     const uint64_t q0 = tile * tile_q;
     const uint32_t nq_here = (span - q0 < tile_q) ? (uint32_t)(span - q0) : tile_q;
     const uint32_t items = nq_here * LV;
-    for (uint32_t it = threadIdx.x; it < items; it += BLOCK) {
-      const uint32_t ql = it / LV;
-      const uint32_t v = it - ql * LV;
-      uint64_t qi = q0 + ql;
-      uint32_t xi, yi;
-      T x, y;
-      if (A.rec_i) {
-        const uint4 r = A.rec_i[qi];
-        x = A.rec_q[2 * qi];
-        y = A.rec_q[2 * qi + 1];
-        qi = r.x;
-        xi = r.y;
-        yi = r.z;
-        if (qi >= limit) continue;
-      } else {
-        xi = A.xi[qi];
-        yi = A.yi[qi];
-        x = A.qx[qi];
-        y = A.qy[qi];
+    for (uint32_t it0 = threadIdx.x; it0 < items; it0 += TB * UNR) {
+      bool live[UNR];
+      uint32_t v[UNR], xi[UNR], yi[UNR];
+      uint64_t qi[UNR];
+      T x[UNR], y[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {          // phase 1: indices and query values
+        const uint32_t it = it0 + (uint32_t)k * TB;
+        live[k] = it < items;
+        const uint32_t ql = live[k] ? it / LV : 0u;
+        v[k] = live[k] ? it - ql * LV : 0u;
+        qi[k] = q0 + ql;
+        if (A.rec_i) {
+          const uint4 r = A.rec_i[qi[k]];
+          x[k] = A.rec_q[2 * qi[k]];
+          y[k] = A.rec_q[2 * qi[k] + 1];
+          qi[k] = r.x;
+          xi[k] = r.y;
+          yi[k] = r.z;
+          if (qi[k] >= limit) live[k] = false;
+        } else {
+          xi[k] = A.xi[qi[k]];
+          yi[k] = A.yi[qi[k]];
+          x[k] = A.qx[qi[k]];
+          y[k] = A.qy[qi[k]];
+        }
       }
-      const T x1 = A.xk[xi], x2 = A.xk[xi + 1];
-      const T y1 = A.yk[yi], y2 = A.yk[yi + 1];
-      const V* z11 = reinterpret_cast<const V*>(A.data + ((uint64_t)xi * A.row_cells + yi) * A.cell_elems);
-      const V* z12 = z11 + LV;                                    // (xi,   yi+1)
-      const V* z21 = reinterpret_cast<const V*>(A.data + ((uint64_t)(xi + 1) * A.row_cells + yi) * A.cell_elems);
-      const V* z22 = z21 + LV;                                    // (xi+1, yi+1)
-      const V a11 = z11[v], a12 = z12[v], a21 = z21[v], a22 = z22[v];
-      const V z1 = frac_v<T, V, APPROX>(x1, a11, x2, a21, x);
-      const V z2 = frac_v<T, V, APPROX>(x1, a12, x2, a22, x);
-      V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
-      o[v] = frac_v<T, V, APPROX>(y1, z1, y2, z2, y);
+      T x1[UNR], x2[UNR], y1[UNR], y2[UNR];
+      V a11[UNR], a12[UNR], a21[UNR], a22[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {          // phase 2: knots and the four corner vectors
+        x1[k] = xk[xi[k]]; x2[k] = xk[xi[k] + 1];
+        y1[k] = yk[yi[k]]; y2[k] = yk[yi[k] + 1];
+        const V* z11 = reinterpret_cast<const V*>(A.data + ((uint64_t)xi[k] * A.row_cells + yi[k]) * A.cell_elems);
+        const V* z21 = reinterpret_cast<const V*>(A.data + ((uint64_t)(xi[k] + 1) * A.row_cells + yi[k]) * A.cell_elems);
+        a11[k] = z11[v[k]];
+        a12[k] = z11[LV + v[k]];                 // (xi,   yi+1)
+        a21[k] = z21[v[k]];
+        a22[k] = z21[LV + v[k]];                 // (xi+1, yi+1)
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {          // phase 3: bilinear.rs:88-97, store
+        const V z1 = frac_v<T, V, APPROX>(x1[k], a11[k], x2[k], a21[k], x[k]);
+        const V z2 = frac_v<T, V, APPROX>(x1[k], a12[k], x2[k], a22[k], x[k]);
+        V* o = reinterpret_cast<V*>(A.out + qi[k] * A.out_stride);
+        if (live[k]) o[v[k]] = frac_v<T, V, APPROX>(y1[k], z1, y2[k], z2, y[k]);
+      }
     }
   }
 }

@@ -1127,6 +1127,7 @@ struct Interp2DImpl final : Interp2DBase {
     A.xi = ws.idx.as<uint32_t>();
     A.yi = ws.idx2.as<uint32_t>();
     A.out = out;
+    A.nx = nx;
     A.ny = ny;
     A.lanes = lanes;
     A.out_stride = out_stride;
@@ -1184,12 +1185,27 @@ struct Interp2DImpl final : Interp2DBase {
     constexpr int VN = Wide<T>::N;
     const bool vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
     const uint64_t LV = vec_ok ? lanes / VN : lanes;
-    const uint32_t tile_q = (uint32_t)std::max<uint64_t>(1, 1024 / std::max<uint64_t>(LV, 1));
-    const uint64_t ntiles = (nq + tile_q - 1) / tile_q;
-    const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 32768));
+    // knots in LDS: both axes must fit next to each other with two 1024-thread workgroups per CU, and the batch
+    // must be large enough to amortise the staging
+    static const int klds_env = [] { const char* e = std::getenv("NDI_BILINEAR_KLDS"); return e ? std::atoi(e) : -1; }();
+    const size_t knot_bytes = (size_t)(nx + ny) * sizeof(T);
+    bool klds = vec_ok && knot_bytes <= 72 * 1024 && nq >= (1u << 20);
+    if (klds_env >= 0) klds = klds_env != 0 && vec_ok && knot_bytes <= LDS_STAGE_LIMIT;
     ProfScope ps(s, PC_EVAL);
-    if (vec_ok) hipLaunchKernelGGL((eval_bilinear_kernel<T, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
-    else hipLaunchKernelGGL((eval_bilinear_kernel<T, 1>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+    if (klds) {
+      constexpr int TB = 1024;
+      const uint32_t tile_q = (uint32_t)std::max<uint64_t>(1, (uint64_t)TB * 2 / std::max<uint64_t>(LV, 1));
+      const uint64_t ntiles = (nq + tile_q - 1) / tile_q;
+      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 512));
+      allow_dynamic_lds(reinterpret_cast<const void*>(&eval_bilinear_kernel<T, VN, false, 2, TB, true>), (int)LDS_STAGE_LIMIT);
+      hipLaunchKernelGGL((eval_bilinear_kernel<T, VN, false, 2, TB, true>), dim3(gx), dim3(TB), (knot_bytes + 15) & ~(size_t)15, s, A, tile_q);
+    } else {
+      const uint32_t tile_q = (uint32_t)std::max<uint64_t>(1, 1024 / std::max<uint64_t>(LV, 1));
+      const uint64_t ntiles = (nq + tile_q - 1) / tile_q;
+      const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 32768));
+      if (vec_ok) hipLaunchKernelGGL((eval_bilinear_kernel<T, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+      else hipLaunchKernelGGL((eval_bilinear_kernel<T, 1>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+    }
     NDI_HIP(hipGetLastError());
     ps.done();
   }
@@ -1493,10 +1509,22 @@ static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
       NDI_HIP(hipMemcpy(tmp.p, d.data, bytes, kind));
       src = tmp.p;
     }
-    const uint64_t total = (uint64_t)d.nx * (d.ny - 1) * 2 * d.lanes;
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((total + BLOCK - 1) / BLOCK, 65536));
-    hipLaunchKernelGGL(pack_pairs_kernel<T>, dim3(grid), dim3(BLOCK), 0, (hipStream_t) nullptr, (const T*)src,
-                       h->data.template as<T>(), (uint64_t)d.nx, (uint64_t)d.ny, (uint64_t)d.lanes);
+    // copy in 16-byte vectors when a grid point is a whole number of them (and both buffers are aligned)
+    const size_t cell_bytes = (size_t)d.lanes * sizeof(T);
+    const bool vec = cell_bytes % 16 == 0 && aligned16(src) && aligned16(h->data.p);
+    const uint32_t units = vec ? (uint32_t)(cell_bytes / 16) : (uint32_t)d.lanes;
+    int shift = -1;
+    for (int b = 0; b < 31; ++b)
+      if ((1u << b) == units) shift = b;
+    const uint64_t row_out = (uint64_t)(d.ny - 1) * 2 * units;
+    dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((row_out + BLOCK - 1) / BLOCK, 1024)),
+              (unsigned)std::min<uint64_t>(d.nx, 16384));
+    if (vec)
+      hipLaunchKernelGGL(pack_pairs_kernel<uint4>, grid, dim3(BLOCK), 0, (hipStream_t) nullptr, (const uint4*)src,
+                         (uint4*)h->data.p, (uint64_t)d.nx, (uint64_t)d.ny, units, shift);
+    else
+      hipLaunchKernelGGL(pack_pairs_kernel<T>, grid, dim3(BLOCK), 0, (hipStream_t) nullptr, (const T*)src,
+                         h->data.template as<T>(), (uint64_t)d.nx, (uint64_t)d.ny, units, shift);
     NDI_HIP(hipGetLastError());
     NDI_HIP(hipDeviceSynchronize());
   } else {

@@ -962,3 +962,29 @@ def test_full_size_c5_share_bilinear(pkg):
     interp.strategy.path = pkg.PATH_BUCKETED
     out_t = interp.interp_array(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev))
     assert torch.equal(out, out_t)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_bilinear_large_batch_knots_in_lds(pkg, dt):
+    """Batches of >= 2^20 queries run the evaluation with both knot vectors staged in LDS (1024-thread workgroups,
+    two items per thread): same bits as the oracle, incl. the first-error cut and the tile-grouped order."""
+    import torch
+    rng = np.random.default_rng(77)
+    nx, ny, C, Q = 301, 200, 8, (1 << 20) + 12_345
+    x = knots("rand", nx, rng, dt); y = knots("log", ny, rng, dt)
+    g = rng.random((nx, ny, C)).astype(dt)
+    interp = pkg.Interp2DBuilder.new(g).x(x).y(y).build()
+    qx = rng.uniform(x[0], x[-1], Q).astype(dt); qy = rng.uniform(y[0], y[-1], Q).astype(dt)
+    _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy)
+    out = interp.interp_array(torch.as_tensor(qx, device="cuda:0"), torch.as_tensor(qy, device="cuda:0"))
+    assert np.array_equal(out.cpu().numpy(), ref)
+    interp.strategy.path = pkg.PATH_BUCKETED
+    out_t = interp.interp_array(torch.as_tensor(qx, device="cuda:0"), torch.as_tensor(qy, device="cuda:0"))
+    assert torch.equal(out, out_t)
+    interp.strategy.path = pkg.PATH_AUTO
+    qy[1_000_000] = np.nan
+    buf = torch.full((Q, C), -2.0, dtype=out.dtype, device="cuda:0")
+    with pytest.raises(pkg.InterpolateError.OutOfBounds, match="^y = NaN") as ei:
+        interp.interp_array_into(torch.as_tensor(qx, device="cuda:0"), torch.as_tensor(qy, device="cuda:0"), buf)
+    assert ei.value.index == 1_000_000
+    assert np.array_equal(buf[:1_000_000].cpu().numpy(), ref[:1_000_000]) and bool((buf[1_000_000:] == -2.0).all())

@@ -108,8 +108,45 @@ static float time_it(F&& launch) {
   return ts[2];
 }
 
-int main() {
+// seg128 reads with the 128-B cells placed `spread` cells apart: the same number of cells and requests over a
+// `spread` times larger physical extent (does the random-read rate depend on the extent, like the store rate?)
+__global__ __launch_bounds__(256) void spread_read_kernel(const flt4* tab, const uint32_t* cell, uint64_t nq,
+                                                          uint64_t spread, uint64_t pitch_vecs, int nseg, float* sink) {
+  const uint32_t sub = threadIdx.x & 7u;
+  flt4 acc = {0, 0, 0, 0};
+  for (uint64_t q = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3); q < nq; q += (uint64_t)gridDim.x * 32) {
+    const uint64_t base = (uint64_t)cell[q] * 8 * spread;
+    acc += tab[base + sub];
+    if (nseg > 1) acc += tab[base + pitch_vecs * spread + sub];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
+}
+
+int main(int argc, char** argv) {
   const uint64_t NQ = 12500000;
+  if (argc > 1) {
+    const uint64_t nx = 8192, ny = 8192, pitch_vecs = (ny - 1) * 8;
+    const uint32_t ncells = (uint32_t)((nx - 1) * (ny - 1));
+    uint32_t* cell;
+    CK(hipMalloc(&cell, NQ * 4));
+    hipLaunchKernelGGL(gen_kernel, dim3(4096), dim3(256), 0, 0, cell, NQ, ncells, 12345ull);
+    float* sink;
+    CK(hipMalloc(&sink, 64));
+    for (uint64_t spread : {1ull, 2ull, 4ull, 8ull, 16ull}) {
+      const uint64_t bytes = nx * (ny - 1) * 128 * spread + (1 << 20);
+      flt4* tab;
+      if (hipMalloc(&tab, bytes) != hipSuccess) break;
+      CK(hipMemset(tab, 0, bytes));
+      for (int nseg = 1; nseg <= 2; ++nseg) {
+        float t = time_it([&] { hipLaunchKernelGGL(spread_read_kernel, dim3(8192), dim3(256), 0, 0, tab, cell, NQ, spread, pitch_vecs, nseg, sink); });
+        printf("{\"kernel\": \"seg128 spread\", \"spread\": %llu, \"extent_GiB\": %.1f, \"segments_per_query\": %d, \"ms\": %.4f, \"read_TBs\": %.3f}\n",
+               (unsigned long long)spread, bytes / 1073741824.0, nseg, t, NQ * 128.0 * nseg / t / 1e9);
+      }
+      fflush(stdout);
+      CK(hipFree(tab));
+    }
+    return 0;
+  }
   const uint64_t nx = 8192, ny = 8192;
   const uint64_t pitch_vecs = (ny - 1) * 8;              // pair-packed row pitch in 16-B vectors (128 B per cell)
   const uint64_t tab_bytes = nx * (ny - 1) * 128;        // 8 GiB

@@ -70,6 +70,7 @@ def cpu_baseline(x, y, q_all, budget_s=20.0):
     same workload: blocks of 2048 queries into a reused output block until ~budget_s of CPU work."""
     sys.path.insert(0, ROOT)
     import oracle
+    flags = oracle.use_native()      # BASELINE.md 2: -O3 -march=native, compiled on this host
     n, lanes = y.shape
     t0 = time.perf_counter()
     st, a, b = oracle.cubic_build(x, y)
@@ -90,6 +91,7 @@ def cpu_baseline(x, y, q_all, budget_s=20.0):
             done += blk
             pos += blk
         res[label] = (done * lanes / t_used / 1e6, done, threads)
+    res["flags"] = flags
     return res, build_s
 
 
@@ -420,7 +422,7 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
                                           "loop in blocks of 2048 queries (the reference is single-threaded)",
                                 "all_cores": {"value": round(vall, 1), "cores": threads,
                                               "sample": f"{doneall} queries (~10 s), contiguous query blocks per thread"},
-                                "build_s": round(build_s, 2)}
+                                "build_s": round(build_s, 2), "compiler_flags": res["flags"]}
     print(json.dumps(line), flush=True)
 
 

@@ -21,6 +21,7 @@
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -120,24 +121,97 @@ struct Array {
 
 // ---- VectorExtensions (src/vector_extensions.rs) -----------------------------------------------------
 enum class Monotonic { NotMonotonic, RisingStrict, Rising, FallingStrict, Falling };
+
+namespace detail {
+// The state machine of src/vector_extensions.rs:116-198 for element types outside f32 / f64 (the i32 axes of
+// tests/interp1d.rs:123-140): the library's ndi_monotonic_prop covers the float types.
+template <class T>
+Monotonic monotonic_generic(const std::vector<T>& v) {
+  if (v.size() <= 1) return Monotonic::NotMonotonic;
+  bool strict = true, rising = false, falling = false;
+  for (size_t i = 0; i + 1 < v.size(); ++i) {
+    if (v[i] < v[i + 1]) rising = true;
+    else if (v[i] > v[i + 1]) falling = true;
+    else strict = false;
+    if (rising && falling) return Monotonic::NotMonotonic;
+  }
+  if (rising) return strict ? Monotonic::RisingStrict : Monotonic::Rising;
+  if (falling) return strict ? Monotonic::FallingStrict : Monotonic::Falling;
+  return Monotonic::NotMonotonic;
+}
+// VectorExtensions::get_lower_index for one query, generic element type (vector_extensions.rs:55-111): the unique
+// i with k[i] <= x < k[i+1], clamped to [0, n-2]
+template <class T>
+size_t lower_index_generic(const std::vector<T>& k, T x) {
+  const size_t n = k.size();
+  if (x <= k[0]) return 0;
+  if (x >= k[n - 1]) return n - 2;
+  size_t lo = 0, hi = n - 1;   // invariant k[lo] <= x < k[hi]
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) / 2;
+    if (k[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// Linear::calc_frac (linear.rs:29-36) with the element type's own arithmetic (integer division truncates)
+template <class T>
+T calc_frac(T x1, T y1, T x2, T y2, T x) {
+  const T m = (y2 - y1) / (x2 - x1);
+  return m * (x - x1) + y1;
+}
+template <class T>
+std::string debug_value(T v) {
+  if constexpr (std::is_floating_point_v<T>) return rust_float((double)v);
+  else return std::to_string(v);
+}
+}  // namespace detail
+
 template <class T>
 Monotonic monotonic_prop(const std::vector<T>& v) {
-  switch (ndi_monotonic_prop(detail::DType<T>::id, v.data(), v.size())) {
-    case NDI_MONO_RISING_STRICT: return Monotonic::RisingStrict;
-    case NDI_MONO_RISING: return Monotonic::Rising;
-    case NDI_MONO_FALLING_STRICT: return Monotonic::FallingStrict;
-    case NDI_MONO_FALLING: return Monotonic::Falling;
-    default: return Monotonic::NotMonotonic;
+  if constexpr (!std::is_same_v<T, float> && !std::is_same_v<T, double>) {
+    return detail::monotonic_generic(v);
+  } else {
+    switch (ndi_monotonic_prop(detail::DType<T>::id, v.data(), v.size())) {
+      case NDI_MONO_RISING_STRICT: return Monotonic::RisingStrict;
+      case NDI_MONO_RISING: return Monotonic::Rising;
+      case NDI_MONO_FALLING_STRICT: return Monotonic::FallingStrict;
+      case NDI_MONO_FALLING: return Monotonic::Falling;
+      default: return Monotonic::NotMonotonic;
+    }
   }
 }
 template <class T>
 std::vector<int64_t> get_lower_index(const std::vector<T>& knots, const std::vector<T>& xs, int device = 0) {
   std::vector<int64_t> out(xs.size());
-  int st = ndi_get_lower_index_batch(detail::DType<T>::id, device, knots.data(), knots.size(), xs.data(),
-                                     xs.size(), out.data(), NDI_MEM_HOST);
-  if (st != NDI_OK) throw DeviceError(ndi_last_error_string());
+  if constexpr (!std::is_same_v<T, float> && !std::is_same_v<T, double>) {
+    for (size_t i = 0; i < xs.size(); ++i) out[i] = (int64_t)detail::lower_index_generic(knots, xs[i]);
+  } else {
+    int st = ndi_get_lower_index_batch(detail::DType<T>::id, device, knots.data(), knots.size(), xs.data(),
+                                       xs.size(), out.data(), NDI_MEM_HOST);
+    if (st != NDI_OK) throw DeviceError(ndi_last_error_string());
+  }
   return out;
 }
+
+// get_lower_index with the knot pyramid resident on the device (ndi_locator_*): no allocation / knot upload per call
+template <class T>
+class Locator {
+  ndi_locator* h_ = nullptr;
+ public:
+  explicit Locator(const std::vector<T>& knots, int device = 0) {
+    int st = ndi_locator_create(detail::DType<T>::id, device, knots.data(), knots.size(), NDI_MEM_HOST, &h_);
+    if (st != NDI_OK) throw DeviceError(ndi_last_error_string());
+  }
+  Locator(const Locator&) = delete;
+  Locator& operator=(const Locator&) = delete;
+  ~Locator() { ndi_locator_destroy(h_); }
+  std::vector<int64_t> get_lower_index(const std::vector<T>& xs) const {
+    std::vector<int64_t> out(xs.size());
+    int st = ndi_locator_eval(h_, xs.data(), xs.size(), out.data(), NDI_MEM_HOST, nullptr);
+    if (st != NDI_OK) throw DeviceError(ndi_last_error_string());
+    return out;
+  }
+};
 
 // =================================================================================================
 // 1-D
@@ -196,7 +270,19 @@ struct Device1D : Interp1DStrategy<T> {  // owns an ndi_interp1d*
   }
   void interp_into(const Interp1D<T>& i, T* target, T x) const override { interp_array_into(i, &x, 1, target, lanes); }
 };
+
+// Linear::interp_into (linear.rs:73-98) for element types the device path does not cover (integers ...): the
+// reference's generic per-query body; batches take the trait's default loop.
+template <class T>
+struct HostLinear : Interp1DStrategy<T> {
+  bool extrapolate = false;
+  void interp_into(const Interp1D<T>& ip, T* target, T x) const override;
+};
 }  // namespace detail
+
+// One chunk of a ring evaluation as the consumer sees it (ndi_ring_chunk): rows [q_begin, q_begin + q_count) of
+// the batch, T[q_count][row_stride] in device memory at `out`, produced on `stream`.
+using RingChunk = ndi_ring_chunk;
 
 // Linear (src/interp1d/strategies/linear.rs): builder and finished strategy in one, as in the reference
 template <class T>
@@ -208,9 +294,15 @@ class Linear : public Interp1DStrategyBuilder<T> {
   Linear& extrapolate(bool e) & { extrapolate_ = e; return *this; }
   size_t MINIMUM_DATA_LENGHT() const override { return 2; }  // linear.rs:52
   std::shared_ptr<Interp1DStrategy<T>> build(const std::vector<T>& x, const Array<T>& data) override {
-    auto s = std::make_shared<detail::Device1D<T>>();
-    s->create(x, data, NDI_LINEAR, extrapolate_, false, {0, 0.0}, {0, 0.0}, 0);
-    return s;
+    if constexpr (!std::is_same_v<T, float> && !std::is_same_v<T, double>) {
+      auto s = std::make_shared<detail::HostLinear<T>>();   // integers: the reference's generic per-query path
+      s->extrapolate = extrapolate_;
+      return s;
+    } else {
+      auto s = std::make_shared<detail::Device1D<T>>();
+      s->create(x, data, NDI_LINEAR, extrapolate_, false, {0, 0.0}, {0, 0.0}, 0);
+      return s;
+    }
   }
 };
 
@@ -245,6 +337,8 @@ class CubicSpline : public Interp1DStrategyBuilder<T> {  // cubic_spline.rs:85-8
   CubicSpline boundary(BoundaryCondition b) && { boundary_ = b; return std::move(*this); }
   size_t MINIMUM_DATA_LENGHT() const override { return 3; }  // cubic_spline.rs:751
   std::shared_ptr<Interp1DStrategy<T>> build(const std::vector<T>& x, const Array<T>& data) override {
+    static_assert(std::is_same_v<T, float> || std::is_same_v<T, double>,
+                  "CubicSpline needs a float element type (the reference's trait bounds: Pow / Euclid on T)");
     auto s = std::make_shared<detail::Device1D<T>>();
     s->create(x, data, NDI_CUBIC_SPLINE, extrapolate_, boundary_.periodic,
               {boundary_.left.kind, boundary_.left.value}, {boundary_.right.kind, boundary_.right.value}, 0);
@@ -272,6 +366,28 @@ class Interp1D {  // interp1d/mod.rs:39-51
     return (size_t)r[0];
   }
   bool is_in_range(T v) const { return x.front() <= v && v <= x.back(); }
+
+  // interp_array (interp1d/mod.rs:197-211) for outputs larger than device memory: chunks of `chunk_queries` rows
+  // through a library-owned device ring of `n_slots` slots (ndi_interp1d_eval_ring); `consume` sees every chunk
+  // once, in order, after its kernels are enqueued on chunk.stream (return a hipEvent_t recorded on another
+  // stream if the chunk is drained there, else nullptr).  Needs a built-in device strategy.
+  void interp_array_ring(const Array<T>& xs, size_t chunk_queries, unsigned n_slots,
+                         const std::function<void*(const RingChunk&)>& consume) const {
+    auto dev = std::dynamic_pointer_cast<detail::Device1D<T>>(strategy);
+    if (!dev) throw Panic("interp_array_ring needs a built-in device strategy (f32 / f64 data)");
+    ndi_ring_desc ring{};
+    ring.n_slots = n_slots;
+    ring.chunk_queries = chunk_queries;
+    ndi_eval_opts o{};
+    o.q_memspace = NDI_MEM_HOST; o.out_memspace = NDI_MEM_DEVICE; o.path = dev->path;
+    ndi_oob_info info{};
+    auto tramp = [](void* user, const ndi_ring_chunk* c) -> void* {
+      return (*static_cast<const std::function<void*(const RingChunk&)>*>(user))(*c);
+    };
+    int st = ndi_interp1d_eval_ring(dev->h, xs.data.data(), xs.len(), &ring, tramp,
+                                    const_cast<void*>(static_cast<const void*>(&consume)), &o, &info);
+    if (st != NDI_OK) detail::throw_eval(st, info);
+  }
 
   T interp_scalar(T v) const {  // :108-114
     if (data.ndim() != 1) throw Panic("interp_scalar needs 1-D data");
@@ -308,6 +424,17 @@ class Interp1D {  // interp1d/mod.rs:39-51
     strategy->interp_array_into(*this, xs.data.data(), xs.len(), buffer.data.data(), lanes());
   }
 };
+
+template <class T>
+void detail::HostLinear<T>::interp_into(const Interp1D<T>& ip, T* target, T x) const {   // linear.rs:73-98
+  if (!extrapolate && !ip.is_in_range(x))
+    throw InterpolateError("x = " + detail::debug_value(x) + " is not in range", 0, (double)x, 0);
+  const size_t i = detail::lower_index_generic(ip.x, x);
+  const size_t L = ip.lanes();
+  const T* y1 = ip.data.data.data() + i * L;
+  const T* y2 = y1 + L;
+  for (size_t l = 0; l < L; ++l) target[l] = detail::calc_frac(ip.x[i], y1[l], ip.x[i + 1], y2[l], x);
+}
 
 template <class T>
 class Interp1DBuilder {  // interp1d/mod.rs:60-70, 389-477
@@ -387,6 +514,12 @@ struct Device2D : Interp2DStrategy<T> {
     interp_array_into(i, &x, &y, 1, target, lanes);
   }
 };
+// Bilinear::interp_into (bilinear.rs:64-99) for element types the device path does not cover (integers ...)
+template <class T>
+struct HostBilinear : Interp2DStrategy<T> {
+  bool extrapolate = false;
+  void interp_into(const Interp2D<T>& ip, T* target, T x, T y) const override;
+};
 }  // namespace detail
 
 template <class T>
@@ -398,15 +531,21 @@ class Bilinear : public Interp2DStrategyBuilder<T> {  // src/interp2d/strategies
   size_t MINIMUM_DATA_LENGHT() const override { return 2; }  // bilinear.rs:41
   std::shared_ptr<Interp2DStrategy<T>> build(const std::vector<T>& x, const std::vector<T>& y,
                                              const Array<T>& data) override {
-    auto s = std::make_shared<detail::Device2D<T>>();
-    ndi_interp2d_desc d{};
-    d.dtype = detail::DType<T>::id; d.extrapolate = extrapolate_; d.device = 0; d.memspace = NDI_MEM_HOST;
-    d.nx = data.shape[0]; d.ny = data.shape[1]; d.lanes = s->lanes = detail::prod(data.shape, 2);
-    d.x_len = x.size(); d.y_len = y.size(); d.x = x.data(); d.y = y.data(); d.data = data.data.data();
-    d.validate = 0;
-    int st = ndi_interp2d_create(&d, &s->h);
-    if (st != NDI_OK) detail::throw_builder(st);
-    return s;
+    if constexpr (!std::is_same_v<T, float> && !std::is_same_v<T, double>) {
+      auto s = std::make_shared<detail::HostBilinear<T>>();   // integers: the reference's generic per-query path
+      s->extrapolate = extrapolate_;
+      return s;
+    } else {
+      auto s = std::make_shared<detail::Device2D<T>>();
+      ndi_interp2d_desc d{};
+      d.dtype = detail::DType<T>::id; d.extrapolate = extrapolate_; d.device = 0; d.memspace = NDI_MEM_HOST;
+      d.nx = data.shape[0]; d.ny = data.shape[1]; d.lanes = s->lanes = detail::prod(data.shape, 2);
+      d.x_len = x.size(); d.y_len = y.size(); d.x = x.data(); d.y = y.data(); d.data = data.data.data();
+      d.validate = 0;
+      int st = ndi_interp2d_create(&d, &s->h);
+      if (st != NDI_OK) detail::throw_builder(st);
+      return s;
+    }
   }
 };
 
@@ -440,6 +579,25 @@ class Interp2D {  // interp2d/mod.rs:36-48
     return zs;
   }
 };
+
+template <class T>
+void detail::HostBilinear<T>::interp_into(const Interp2D<T>& ip, T* target, T x, T y) const {   // bilinear.rs:64-99
+  if (!extrapolate && !ip.is_in_x_range(x))    // x before y (:71-80)
+    throw InterpolateError("x = " + detail::debug_value(x) + " is not in range", 0, (double)x, 0);
+  if (!extrapolate && !ip.is_in_y_range(y))
+    throw InterpolateError("y = " + detail::debug_value(y) + " is not in range", 0, (double)y, 1);
+  const size_t xi = detail::lower_index_generic(ip.x, x), yi = detail::lower_index_generic(ip.y, y);
+  const size_t L = ip.lanes(), ny = ip.data.shape[1];
+  const T* g = ip.data.data.data();
+  const T x1 = ip.x[xi], x2 = ip.x[xi + 1], y1 = ip.y[yi], y2 = ip.y[yi + 1];
+  for (size_t l = 0; l < L; ++l) {
+    const T z11 = g[(xi * ny + yi) * L + l], z12 = g[(xi * ny + yi + 1) * L + l];
+    const T z21 = g[((xi + 1) * ny + yi) * L + l], z22 = g[((xi + 1) * ny + yi + 1) * L + l];
+    const T z1 = detail::calc_frac(x1, z11, x2, z21, x);   // :88-97
+    const T z2 = detail::calc_frac(x1, z12, x2, z22, x);
+    target[l] = detail::calc_frac(y1, z1, y2, z2, y);
+  }
+}
 
 template <class T>
 class Interp2DBuilder {  // interp2d/mod.rs:52-64, 382-519

@@ -40,11 +40,36 @@ _lib = None
 
 
 def lib() -> C.CDLL:
+    """liboracle.so (portable x86-64-v3 build), or the library named by ORACLE_LIB (the sanitizer build in
+    tests/test_oracle_sanitized.py)."""
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+        override = os.environ.get("ORACLE_LIB")
+        if override:
+            _lib = C.CDLL(override)
+        else:
+            build()
+            _lib = C.CDLL(_LIB_PATH)
     return _lib
+
+
+def use_native() -> str:
+    """Switches this process to liboracle_native.so: -O3 -march=native (the flags BASELINE.md states for the timed
+    CPU baseline), compiled on the host it runs on -- a binary built for this container's CPU must not travel to
+    another host.  Falls back to the portable build when the compile fails.  Returns the flags in use."""
+    global _lib
+    import platform
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"liboracle_native_{platform.node()}.so")
+    try:
+        subprocess.run(["g++", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC",
+                        "-fvisibility=hidden", "-pthread", "-shared", "-o", out, os.path.join(_HERE, "oracle.cpp")],
+                       check=True, capture_output=True)
+        _lib = C.CDLL(out)
+        return "-O3 -march=native -ffp-contract=off"
+    except Exception:
+        lib()
+        return "-O3 -march=x86-64-v3 -ffp-contract=off (native build failed)"
 
 
 def _suf(dtype) -> str:

@@ -10,6 +10,11 @@
 
 using namespace ndarray_interp;
 static int failures = 0;
+// the two HIP runtime calls the ring consumer below needs (plain C prototypes; the mirror itself needs no HIP header)
+extern "C" int hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                                int kind, void* stream);
+extern "C" int hipStreamSynchronize(void* stream);
+
 #define CHECK(cond)                                                                  \
   do {                                                                               \
     if (!(cond)) { ++failures; std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); } \
@@ -47,6 +52,41 @@ static void host_only() {
   CHECK(monotonic_prop<double>({1.1, 2.0, 3.123, 3.123, 4.5}) == Monotonic::Rising);
   CHECK(monotonic_prop<float>({5.8f, 4.1f, 3.1f, 3.1f, 2.0f}) == Monotonic::Falling);
   CHECK(monotonic_prop<double>({1, 1, 1}) == Monotonic::NotMonotonic);
+  // ---- integer element types: the reference's generic per-query path, no device ----
+  {  // tests/interp2d.rs:29-47 (i32 data, default axes / i32 x axis), :63-82 (out of bounds, x before y)
+    Array<int> d({3, 4}, std::vector<int>{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12});
+    auto ip = Interp2DBuilder<int>::new_(d).build();
+    CHECK(ip.interp_scalar(0, 0) == 1); CHECK(ip.interp_scalar(2, 3) == 12);
+    CHECK(ip.interp_scalar(2, 0) == 9); CHECK(ip.interp_scalar(0, 3) == 4);
+    auto ipx = Interp2DBuilder<int>::new_(d).x({1, 2, 3}).build();
+    CHECK(ipx.interp_scalar(1, 0) == 1); CHECK(ipx.interp_scalar(3, 3) == 12);
+    CHECK(ipx.interp_scalar(3, 0) == 9); CHECK(ipx.interp_scalar(1, 3) == 4);
+    try { ip.interp(-1, 1); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.axis == 0 && std::string(e.what()) == "x = -1 is not in range"); }
+    try { ip.interp(1, -1); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.axis == 1); }
+    try { ip.interp(3, 1); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.axis == 0); }
+    try { ip.interp(1, 4); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.axis == 1); }
+    // batched entry = the trait's default loop; first-error index
+    Array<int> qx({3}, std::vector<int>{0, 5, 1}), qy({3}, std::vector<int>{0, 0, 1});
+    try { ip.interp_array(qx, qy); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.index == 1); }
+  }
+  {  // Linear::calc_frac on i32 (linear.rs:29-36): integer division truncates toward zero
+    auto ip = Interp1DBuilder<int>::new_(Array<int>::from_vec({0, 10})).x({0, 4}).build();
+    auto r = ip.interp_array(Array<int>::from_vec({0, 1, 2, 3, 4}));
+    CHECK((r.data == std::vector<int>{0, 2, 4, 6, 8}));
+    auto ipn = Interp1DBuilder<int>::new_(Array<int>::from_vec({10, 0})).x({0, 4}).build();
+    CHECK(ipn.interp_scalar(1) == 8 && ipn.interp_scalar(3) == 4);
+    Array<int> d2({3, 2}, std::vector<int>{0, 7, 3, -7, 9, 0});
+    auto ip2 = Interp1DBuilder<int>::new_(d2).x({0, 2, 5}).build();
+    auto r2 = ip2.interp_array(Array<int>::from_vec({1, 2, 4}));
+    CHECK((r2.data == std::vector<int>{1, 0, 3, -7, 7, -3}));
+    auto ipe = Interp1DBuilder<long>::new_(Array<long>::from_vec({0, 10})).x({0, 4}).strategy(Linear<long>::new_().extrapolate(true)).build();
+    CHECK(ipe.interp_scalar(6) == 12 && ipe.interp_scalar(-1) == -2);
+    CHECK(throws<InterpolateError>([&] { ip.interp_scalar(5); }));
+    // tests/interp1d.rs:122-140 with their i32 arrays
+    CHECK(throws<BuilderError>([] { Interp1DBuilder<int>::new_(Array<int>::from_vec({1})).build(); }, BuilderError::NotEnoughData));
+    CHECK(throws<BuilderError>([] { Interp1DBuilder<int>::new_(Array<int>::from_vec({1, 2})).x({1, 2, 3}).build(); }, BuilderError::ShapeError));
+    CHECK(throws<BuilderError>([] { Interp1DBuilder<int>::new_(Array<int>::from_vec({1, 2, 3})).x({1, 2, 2}).build(); }, BuilderError::Monotonic));
+  }
 }
 
 // examples/custom_strategy.rs
@@ -147,6 +187,38 @@ static void device() {
     auto r = ip3.interp_array(arr({0.0, 0.5}), arr({0.5, 1.0}));
     CHECK((r.shape == std::vector<size_t>{2, 2, 2}));
     CHECK((r.data == std::vector<double>{1.5, 15.0, -1.5, -15.0, 3.5, 35.0, -3.5, -35.0}));
+  }
+  {  // interp_array through the library-owned device ring: every chunk equals the matching rows of one batch
+    const size_t n = 50, L = 512, Q = 5000, chunk = 1024;
+    std::vector<double> xk(n), yv(n * L), qs(Q);
+    for (size_t i = 0; i < n; ++i) xk[i] = 0.1 * i + 0.01 * (i % 3);
+    for (size_t i = 0; i < n * L; ++i) yv[i] = std::sin(0.001 * i) + 0.5;
+    for (size_t i = 0; i < Q; ++i) qs[i] = xk[0] + (xk[n - 1] - xk[0]) * ((i * 7919u) % Q) / double(Q);
+    auto ip = Interp1DBuilder<double>::new_(Array<double>({n, L}, yv)).x(xk).strategy(CubicSpline<double>::new_()).build();
+    auto whole = ip.interp_array(Array<double>::from_vec(qs));
+    std::vector<double> got(Q * L, -1.0);
+    size_t chunks = 0;
+    ip.interp_array_ring(Array<double>::from_vec(qs), chunk, 3, [&](const RingChunk& c) -> void* {
+      CHECK(c.index == chunks && c.q_begin == chunks * chunk && c.row_stride == 3 * L && c.slot == chunks % 3);
+      CHECK(hipMemcpy2DAsync(got.data() + c.q_begin * L, L * 8, c.out, c.row_stride * 8, L * 8, c.q_count, 2, c.stream) == 0);
+      CHECK(hipStreamSynchronize(c.stream) == 0);
+      ++chunks;
+      return nullptr;
+    });
+    CHECK(chunks == 5);
+    CHECK(got == whole.data);
+    // first error: exactly the rows before it are produced
+    qs[2500] = 99.0;
+    size_t rows = 0;
+    try {
+      ip.interp_array_ring(Array<double>::from_vec(qs), chunk, 2, [&](const RingChunk& c) -> void* { rows += c.q_count; return nullptr; });
+      CHECK(false);
+    } catch (const InterpolateError& e) { CHECK(e.index == 2500 && rows == 2500); }
+    // resident locator = one-shot search
+    Locator<double> loc(xk);
+    std::vector<double> lq{-1.0, xk[0], xk[7], 0.5 * (xk[7] + xk[8]), xk[n - 1], 100.0};
+    CHECK(loc.get_lower_index(lq) == get_lower_index<double>(xk, lq));
+    CHECK((loc.get_lower_index(lq) == std::vector<int64_t>{0, 0, 7, 7, (int64_t)n - 2, (int64_t)n - 2}));
   }
   {  // f32 is a first-class type (tests/cubic_spline_strat.rs:108-154)
     Array<float> d = Array<float>::from_vec({1.f, 2.f, 2.5f, 2.5f, 3.f, 2.f, 1.f, -2.f, 3.f, 5.f, 6.3f, 8.f});

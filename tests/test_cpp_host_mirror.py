@@ -18,7 +18,7 @@ def _build():
     newest = max(os.path.getmtime(p) for p in (SRC, HDR, os.path.join(ROOT, "include", "ndinterp.h")))
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < newest:
         subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-o", BIN, SRC, "-L", LIBDIR, "-lndinterp_hip",
-                        "-Wl,-rpath," + LIBDIR], check=True, capture_output=True)
+                        "-Wl,-rpath," + LIBDIR, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True)
     return BIN
 
 

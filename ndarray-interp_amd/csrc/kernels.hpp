@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace ndi {
 
 constexpr unsigned long long NO_FAIL = ~0ull;
@@ -175,6 +177,52 @@ __device__ __forceinline__ uint32_t wave_count_le(const PyramidT<T, PTR>& P, T x
   return base + block_last_le<T, PTR>(P.lv0 + base, len, P.block, x) + 1u;
 }
 
+// Bucket index of an axis (a guess that is right by construction, for any strictly rising axis): M uniform buckets
+// over [k0, kn], bucket(x) = min(trunc((x - k0) * scale), M - 1), and lut[b] = number of knots whose bucket is < b
+// (M + 1 entries, u16, built on the host with the same arithmetic).  bucket() is monotone, so every knot in a lower
+// bucket is < x and every knot in a higher bucket is > x: the number of knots <= x is lut[b] plus the knots <= x
+// among the few in bucket b itself -- with M >= 2n that is 0-2 knots for well-spread axes, and a per-lane bisection
+// over [lut[b], lut[b+1]) covers clustered axes.  It replaces 7 cross-lane + 6-7 LDS bisection steps by ~4 LDS
+// reads (the bisection's random ds_read_b32 are bank-conflict bound: profiles/r02_tuning.md).  The reference does the
+// same in spirit: an O(1) guess first, a search only around it (vector_extensions.rs:68-110).
+template <class T>
+struct BucketIndex {
+  const uint16_t* lut;   // global memory, m + 1 entries; nullptr: no bucket index for this axis
+  uint32_t m;            // buckets (power of two)
+  T scale;               // m / (kn - k0), in T
+};
+using lds_u16 = const __attribute__((address_space(3))) uint16_t*;
+
+template <class T>
+__host__ __device__ __forceinline__ uint32_t bucket_of(T x, T k0, T scale, uint32_t m) {
+  const T d = x - k0;
+  const T f = d * scale;
+  const uint32_t b = (uint32_t)f;   // 0 <= f < ~m for k0 <= x <= kn
+  return b < m ? b : m - 1u;
+}
+
+// Number of knots <= x through the bucket index; knots and lut staged in LDS.  NaN -> 0.
+template <class T>
+__device__ __forceinline__ uint32_t lut_count_le(lds_ptr<T> k, uint32_t n, lds_u16 lut, uint32_t m, T scale, T k0,
+                                                 T kn, T x) {
+  if (!(x >= k0)) return 0u;   // below the axis, or NaN
+  if (x >= kn) return n;
+  const uint32_t b = bucket_of<T>(x, k0, scale, m);
+  uint32_t lo = lut[b];
+  uint32_t len = lut[b + 1u] - lo;
+  while (len > 0u) {           // count of k[lo .. lo+len) <= x (sorted): usually 0-2 knots
+    const uint32_t half = len >> 1;
+    const uint32_t mid = lo + half;
+    if (k[mid] <= x) {
+      lo = mid + 1u;
+      len -= half + 1u;
+    } else {
+      len = half;
+    }
+  }
+  return lo;
+}
+
 // Interval index of one query per lane: the O(1) guess of the reference for evenly spaced axes
 // (vector_extensions.rs:68-90: mid = calc_frac((k0,0),(kn,n-1),x), accepted iff k[mid] <= x < k[mid+1]),
 // and the cooperative search for the whole wave as soon as one lane's guess is not accepted.  Either way the
@@ -199,6 +247,16 @@ __device__ __forceinline__ uint32_t locate_index(const PyramidT<T, PTR>& P, T k0
   return i;
 }
 
+// The same through the bucket index (knots and lut in LDS); no cross-lane step.
+template <class T>
+__device__ __forceinline__ uint32_t locate_index_lut(const PyramidLds<T>& P, lds_u16 lut, uint32_t m, T scale, T k0,
+                                                     T kn, T x) {
+  const uint32_t ub = lut_count_le<T>(P.lv0, P.n, lut, m, scale, k0, kn, x);
+  uint32_t s = (ub == 0) ? 0u : ub - 1u;
+  if (s > P.n - 2u) s = P.n - 2u;
+  return s;
+}
+
 template <class T>
 struct LocateArgs {
   Pyramid<T> pyr;          // global-memory pyramid
@@ -210,6 +268,7 @@ struct LocateArgs {
   unsigned long long* first_fail;  // atomicMin target
   int mode;                // ExtrapMode
   int stage_lds;           // copy the pyramid into LDS first
+  BucketIndex<T> bx;       // bucket index, staged behind the pyramid when bx.lut != nullptr (needs stage_lds)
   // grouping support (BUCKETED formulation): workgroup b handles the contiguous query slice
   // [b*slice, (b+1)*slice) and, if hist != nullptr, leaves its interval histogram in hist[b][nb]
   uint64_t slice;
@@ -219,7 +278,8 @@ struct LocateArgs {
 
 // Body of locate_kernel for one pyramid address space.
 template <class T, class PTR>
-__device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const PyramidT<T, PTR>& P, uint32_t* s_hist) {
+__device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const PyramidT<T, PTR>& P, uint32_t* s_hist,
+                                             lds_u16 lut = nullptr) {
   const uint32_t tid = threadIdx.x;
   const T k0 = P.lv0[0];
   const T kn = P.lv0[P.n - 1];
@@ -240,7 +300,12 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;
     // unique i with k[i] <= x < k[i+1], clamped to [0, n-2]  (vector_extensions.rs:61-66, 100-110);
     // all 64 lanes take part (cross-lane exchange inside)
-    const uint32_t i = locate_index<T, PTR>(P, k0, kn, xs, lane);
+    uint32_t i;
+    if constexpr (std::is_same<PTR, lds_ptr<T>>::value) {
+      i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs) : locate_index<T, PTR>(P, k0, kn, xs, lane);
+    } else {
+      i = locate_index<T, PTR>(P, k0, kn, xs, lane);
+    }
     if (!active) continue;
     const bool isnan_q = !(xs == xs);
     const bool bad = (A.mode == EX_NO) ? !inr : isnan_q;
@@ -272,6 +337,15 @@ __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
     for (uint32_t i = tid; i < n1; i += blockDim.x) s1[i] = A.pyr.lv1[i];
     hist_off = ((size_t)(n + n1) * sizeof(T) + 15u) & ~(size_t)15u;
   }
+  lds_u16 lut = nullptr;
+  if (STAGE && A.bx.lut) {   // [pyramid | lut | histogram]; the lut is copied as 32-bit words (m + 1 entries, padded)
+    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + hist_off);
+    const uint32_t words = (A.bx.m + 2u) / 2u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.bx.lut);
+    for (uint32_t i = tid; i < words; i += blockDim.x) sl[i] = src[i];
+    lut = (lds_u16)(smem_raw + hist_off);
+    hist_off += ((size_t)words * 4u + 15u) & ~(size_t)15u;
+  }
   if (A.hist) {
     s_hist = reinterpret_cast<uint32_t*>(smem_raw + hist_off);
     for (uint32_t i = tid; i < A.nb; i += blockDim.x) s_hist[i] = 0u;
@@ -282,7 +356,7 @@ __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
     P.lv0 = (lds_ptr<T>)(smem_raw);
     P.lv1 = P.lv0 + n;
     P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
-    locate_slice<T, lds_ptr<T>>(A, P, s_hist);
+    locate_slice<T, lds_ptr<T>>(A, P, s_hist, lut);
   } else {
     locate_slice<T, const T*>(A, A.pyr, s_hist);
   }
@@ -306,6 +380,7 @@ struct Locate2Args {
   unsigned long long* first_fail;  // [2]: x, y
   int mode;
   uint64_t slice;
+  BucketIndex<T> bx, by;   // bucket indices, staged behind the two pyramids when non-null (both or none)
 };
 
 template <class T>
@@ -325,6 +400,19 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   PY.lv0 = PX.lv0 + nxa;
   PY.lv1 = PY.lv0 + A.py.n;
   PY.n = A.py.n; PY.n1 = A.py.n1; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
+  lds_u16 lutx = nullptr, luty = nullptr;
+  if (A.bx.lut && A.by.lut) {
+    const size_t off = ((size_t)(nxa + nya) * sizeof(T) + 15u) & ~(size_t)15u;
+    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
+    const uint32_t wx = (A.bx.m + 2u) / 2u, wy = (A.by.m + 2u) / 2u;
+    const uint32_t* srcx = reinterpret_cast<const uint32_t*>(A.bx.lut);
+    const uint32_t* srcy = reinterpret_cast<const uint32_t*>(A.by.lut);
+    for (uint32_t i = tid; i < wx; i += blockDim.x) sl[i] = srcx[i];
+    for (uint32_t i = tid; i < wy; i += blockDim.x) sl[wx + i] = srcy[i];
+    __syncthreads();
+    lutx = (lds_u16)(smem_raw + off);
+    luty = (lds_u16)(smem_raw + off + (size_t)wx * 4u);
+  }
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
   const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
@@ -339,8 +427,10 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
     const T x = x_next, y = y_next;
     x_next = (qi + blockDim.x < q_end) ? A.qx[qi + blockDim.x] : x0;
     y_next = (qi + blockDim.x < q_end) ? A.qy[qi + blockDim.x] : y0;
-    const uint32_t ix = locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
-    const uint32_t iy = locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
+    const uint32_t ix = lutx ? locate_index_lut<T>(PX, lutx, A.bx.m, A.bx.scale, x0, xn, x)
+                             : locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
+    const uint32_t iy = luty ? locate_index_lut<T>(PY, luty, A.by.m, A.by.scale, y0, yn, y)
+                             : locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
     if (!active) continue;
     // Interp2D::is_in_x_range / is_in_y_range (interp2d/mod.rs:374-379); NaN handling as in locate_slice
     const bool badx = (A.mode == EX_NO) ? !((x0 <= x) && (x <= xn)) : !(x == x);

@@ -183,6 +183,37 @@ struct DevicePyramid {
       even = std::fabs((double)knots[i] - ((double)knots[0] + step * (double)i)) < 0.45 * step;
     view.guess = even ? 1 : 0;
     lds_bytes = all.size() * sizeof(T);
+    build_bucket_index(knots, n, even);
+  }
+
+  // Bucket index (kernels.hpp, BucketIndex): only for axes the O(1) formula guess does not already resolve, with
+  // u16 entries (n <= 65535) and more than one top-level block.  Built with bucket_of(), the function the device uses.
+  DevBuf lut_buf;
+  BucketIndex<T> bidx{nullptr, 0, T(0)};
+  size_t lut_bytes = 0;   // LDS bytes of the staged lut (16-byte multiple); 0 = none
+  void build_bucket_index(const T* knots, uint64_t n, bool even) {
+    bidx = BucketIndex<T>{nullptr, 0, T(0)};
+    lut_bytes = 0;
+    if (even || n <= 64 || n > 65535) return;
+    uint32_t m = 1;
+    while (m < 2 * n) m *= 2;                       // 2n <= m < 4n buckets
+    const T k0 = knots[0], kn = knots[n - 1];
+    const T scale = T(m) / (kn - k0);
+    if (!(scale > T(0)) || !std::isfinite((double)scale)) return;   // degenerate span: keep the pyramid search
+    std::vector<uint16_t> lut(m + 2 + 6, 0);        // m + 1 entries, padded to a whole number of 16-byte units
+    std::vector<uint32_t> cnt(m, 0);
+    for (uint64_t i = 0; i < n; ++i) cnt[bucket_of<T>(knots[i], k0, scale, m)]++;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < m; ++b) {
+      lut[b] = (uint16_t)run;
+      run += cnt[b];
+    }
+    for (size_t b = m; b < lut.size(); ++b) lut[b] = (uint16_t)n;   // lut[m] = n; padding likewise
+    const size_t bytes = (((size_t)(m + 2) / 2) * 4 + 15) & ~(size_t)15;
+    lut_buf.reserve(std::max(bytes, lut.size() * sizeof(uint16_t)));
+    NDI_HIP(hipMemcpy(lut_buf.p, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    bidx = BucketIndex<T>{lut_buf.as<uint16_t>(), m, scale};
+    lut_bytes = bytes;
   }
 };
 
@@ -316,7 +347,21 @@ constexpr uint32_t GROUP_MAX_BINS = 16384;   // histogram must fit LDS next to t
 template <class T>
 static bool lds_sort_fits(const DevicePyramid<T>& pyr, uint64_t nb) {
   const size_t stage = pyr.lds_bytes <= LDS_STAGE_LIMIT ? ((pyr.lds_bytes + 15) & ~(size_t)15) : 0;
-  return nb <= GROUP_MAX_BINS && stage + nb * 4 <= LDS_STAGE_LIMIT;
+  return nb <= GROUP_MAX_BINS && stage + nb * 4 <= LDS_STAGE_LIMIT;   // (the bucket index is dropped first)
+}
+
+// Compute units of the current device (cached per device).
+static unsigned cu_count() {
+  static std::mutex mu;
+  static std::map<int, unsigned> cache;
+  int dev = 0;
+  NDI_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find(dev);
+  if (it != cache.end()) return it->second;
+  int n = 0;
+  NDI_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+  return cache[dev] = (unsigned)std::max(n, 1);
 }
 
 // Workgroup size for a kernel that needs `lds` bytes per workgroup: as few threads as keep 32 waves on a CU
@@ -358,6 +403,16 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
   uint64_t blocks = hist ? std::min<uint64_t>((nq + 2047) / 2048, GROUP_MAX_BLOCKS)
                          : std::min<uint64_t>((nq + 1023) / 1024, 2048);
   blocks = std::max<uint64_t>(blocks, 1);
+  A.bx = BucketIndex<T>{nullptr, 0, T(0)};
+  static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+  if (lut_env && A.stage_lds && pyr.lut_bytes && nq >= 4096 &&
+      shmem + pyr.lut_bytes + (hist ? (size_t)nb * 4 : 0) <= LDS_STAGE_LIMIT) {
+    A.bx = pyr.bidx;          // bucket index staged behind the pyramid: [pyramid | lut | histogram]
+    shmem += pyr.lut_bytes;
+    // staging is the fixed cost of a workgroup now: no more workgroups than the chip holds at once
+    const size_t total = shmem + (hist ? (size_t)nb * 4 : 0);
+    blocks = std::min<uint64_t>(blocks, (uint64_t)cu_count() * std::max<size_t>(1, (160 * 1024) / total));
+  }
   if (hist) shmem += (size_t)nb * 4;
   const unsigned threads = threads_for_lds(shmem);
   uint64_t slice = (nq + blocks - 1) / blocks;
@@ -1106,14 +1161,25 @@ struct Interp2DImpl final : Interp2DBase {
       LA.xi = ws.idx.as<uint32_t>(); LA.yi = ws.idx2.as<uint32_t>();
       LA.first_fail = &st->first_fail[0];
       LA.mode = mode;
-      const unsigned threads = threads_for_lds(both);
+      LA.bx = BucketIndex<T>{nullptr, 0, T(0)};
+      LA.by = LA.bx;
+      static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+      size_t both_l = both;
+      if (lut_env && px.lut_bytes && py.lut_bytes && nq >= 4096 && both + px.lut_bytes + py.lut_bytes <= LDS_STAGE_LIMIT) {
+        LA.bx = px.bidx;      // [x pyramid | y pyramid | x lut | y lut]
+        LA.by = py.bidx;
+        both_l = both + px.lut_bytes + py.lut_bytes;
+      }
+      const unsigned threads = threads_for_lds(both_l);
       uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, 2048));
+      if (LA.bx.lut)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
+        blocks = std::min<uint64_t>(blocks, (uint64_t)cu_count() * std::max<size_t>(1, (160 * 1024) / both_l));
       uint64_t slice = (nq + blocks - 1) / blocks;
       slice = (slice + threads - 1) / threads * threads;
       blocks = (nq + slice - 1) / slice;
       LA.slice = slice;
       allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T>), (int)LDS_STAGE_LIMIT);
-      launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), both, locate2_kernel<T>, LA);
+      launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), both_l, locate2_kernel<T>, LA);
     } else {
       run_locate<T>(s, px, qx, nq, ws.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
       run_locate<T>(s, py, qy, nq, ws.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);

@@ -385,3 +385,57 @@ def test_one_process_drives_every_device(pkg):
     for d in range(ndev):
         assert np.array_equal(results[d][0], ref), d
 
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_bucket_index_edge_axes(pkg, dt):
+    """The bucket index behind the search (kernels.hpp BucketIndex; used for >= 4096 queries on axes the O(1) formula
+    guess does not resolve, n <= 65535): axes with almost every knot in one bucket, a tiny span on a large offset,
+    the u16 limit, and queries on / next to every knot and bucket edge."""
+    rng = np.random.default_rng(61)
+    eps = np.finfo(dt).eps
+    axes = {
+        "clustered head": np.concatenate([np.linspace(0.0, 1e-6, 3000), np.linspace(1e-3, 1.0, 200)]),
+        "clustered tail": np.concatenate([np.linspace(0.0, 1.0, 100), 1.0 + np.linspace(1e-7, 1e-5, 5000)]),
+        "tiny span, big offset": 1000.0 + np.cumsum(rng.uniform(1, 3, 2000)) * 1000.0 * eps * 4,
+        "two scales": np.unique(np.concatenate([rng.uniform(0, 1e-3, 4000), rng.uniform(0, 1e3, 4000)])),
+        "n = 65535": np.cumsum(rng.uniform(0.5, 1.5, 65535)),
+        "n = 65536 (no index)": np.cumsum(rng.uniform(0.5, 1.5, 65536)),
+        "n = 65": np.cumsum(rng.uniform(0.5, 1.5, 65)),
+    }
+    for name, k in axes.items():
+        k = np.unique(k.astype(dt))
+        n = k.size
+        span = float(k[-1] - k[0])
+        # bucket edges of the index the library builds (m = smallest power of two >= 2n)
+        m = 1
+        while m < 2 * n:
+            m *= 2
+        edges = (k[0] + (np.arange(m + 1) / m) * span).astype(dt)
+        q = np.concatenate([rng.uniform(k[0] - 0.01 * span, k[-1] + 0.01 * span, 20000).astype(dt), k,
+                            np.nextafter(k, dt(-np.inf)), np.nextafter(k, dt(np.inf)), edges,
+                            np.nextafter(edges, dt(-np.inf)), np.nextafter(edges, dt(np.inf)),
+                            np.array([np.inf, -np.inf, np.nan, k[0], k[-1]], dtype=dt)])
+        got = pkg.get_lower_index(k, q)
+        exp = oracle.get_lower_index(k, q)
+        assert np.array_equal(got, exp), name
+        fin = ~np.isnan(q)
+        assert np.array_equal(got[fin], np.clip(np.searchsorted(k, q[fin], side="right") - 1, 0, n - 2)), name
+    # the same axes through a 2-D interpolator (both axes indexed in one launch) and the spline's locate + histogram
+    import torch
+    kx = np.unique(axes["two scales"].astype(dt)); ky = np.unique(axes["clustered head"].astype(dt))
+    g = rng.random((kx.size, ky.size, 2)).astype(dt)
+    bi = pkg.Interp2DBuilder.new(torch.as_tensor(g, device="cuda:0")).x(torch.as_tensor(kx, device="cuda:0")) \
+        .y(torch.as_tensor(ky, device="cuda:0")).build()
+    qx = rng.uniform(kx[0], kx[-1], 30000).astype(dt); qy = rng.uniform(ky[0], ky[-1], 30000).astype(dt)
+    qy[:5000] = rng.uniform(0, 1e-6, 5000).astype(dt)          # into the cluster
+    _, _, _, ref = oracle.interp2d_bilinear(kx, ky, g, qx, qy)
+    assert np.array_equal(bi.interp_array(qx, qy), ref)
+    y = rng.uniform(0, 1, (ky.size, 1024)).astype(dt)
+    sp = pkg.Interp1DBuilder.new(y).x(ky).strategy(pkg.CubicSpline.new()).build()
+    st, a, b = oracle.cubic_build(ky, y)
+    qq = np.concatenate([rng.uniform(ky[0], ky[-1], 20000), rng.uniform(0, 1e-6, 20000)]).astype(dt)
+    _, _, ref = oracle.interp1d_cubic(ky, y, a, b, qq)
+    for path in (pkg.PATH_BUCKETED, pkg.PATH_GATHER):
+        sp.strategy.path = path
+        assert np.array_equal(sp.interp_array(qq), ref), path

@@ -380,7 +380,7 @@ struct Locate2Args {
   unsigned long long* first_fail;  // [2]: x, y
   int mode;
   uint64_t slice;
-  BucketIndex<T> bx, by;   // bucket indices, staged behind the two pyramids when non-null (both or none)
+  BucketIndex<T> bx, by;   // bucket indices, staged behind the two pyramids when non-null
 };
 
 template <class T>
@@ -401,17 +401,17 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   PY.lv1 = PY.lv0 + A.py.n;
   PY.n = A.py.n; PY.n1 = A.py.n1; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
   lds_u16 lutx = nullptr, luty = nullptr;
-  if (A.bx.lut && A.by.lut) {
+  if (A.bx.lut || A.by.lut) {   // either axis may come without an index (its formula guess is exact)
     const size_t off = ((size_t)(nxa + nya) * sizeof(T) + 15u) & ~(size_t)15u;
     uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
-    const uint32_t wx = (A.bx.m + 2u) / 2u, wy = (A.by.m + 2u) / 2u;
+    const uint32_t wx = A.bx.lut ? (A.bx.m + 2u) / 2u : 0u, wy = A.by.lut ? (A.by.m + 2u) / 2u : 0u;
     const uint32_t* srcx = reinterpret_cast<const uint32_t*>(A.bx.lut);
     const uint32_t* srcy = reinterpret_cast<const uint32_t*>(A.by.lut);
     for (uint32_t i = tid; i < wx; i += blockDim.x) sl[i] = srcx[i];
     for (uint32_t i = tid; i < wy; i += blockDim.x) sl[wx + i] = srcy[i];
     __syncthreads();
-    lutx = (lds_u16)(smem_raw + off);
-    luty = (lds_u16)(smem_raw + off + (size_t)wx * 4u);
+    if (wx) lutx = (lds_u16)(smem_raw + off);
+    if (wy) luty = (lds_u16)(smem_raw + off + (size_t)wx * 4u);
   }
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
@@ -457,10 +457,29 @@ struct Eval1Args {
   T* out;
   uint64_t lanes, out_stride, nq;
   const StatusBlock* status;
-  // bucketed
-  const uint32_t* perm;
+  // bucketed: per grouped position one record {query index, interval, s as raw bits} with s = t (cubic) or the raw
+  // query value (linear) -- written by the grouping kernels, read sequentially by the evaluation (the per-query
+  // idx[qi] / t[qi] gathers it replaces were 0.13-0.25 GB of random line reads per 1e6 queries, and reads cost the
+  // write stream several times their share of the bytes: profiles/r02_tuning.md)
+  const uint4* rec;
   uint32_t run;   // consecutive chunks per workgroup (0 = 1)
 };
+
+template <class T>
+__device__ __forceinline__ uint4 make_rec(uint32_t qi, uint32_t i, T s);
+template <>
+__device__ __forceinline__ uint4 make_rec<double>(uint32_t qi, uint32_t i, double s) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, s);
+  return make_uint4(qi, i, (uint32_t)b, (uint32_t)(b >> 32));
+}
+template <>
+__device__ __forceinline__ uint4 make_rec<float>(uint32_t qi, uint32_t i, float s) {
+  return make_uint4(qi, i, __builtin_bit_cast(uint32_t, s), 0u);
+}
+__device__ __forceinline__ double rec_value(const uint4& r, double) {
+  return __builtin_bit_cast(double, ((unsigned long long)r.w << 32) | r.z);
+}
+__device__ __forceinline__ float rec_value(const uint4& r, float) { return __builtin_bit_cast(float, r.z); }
 
 // Per-query scalars shared by all lanes of a row.
 template <class T, int STRAT>
@@ -724,14 +743,16 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* count
   if (tid == 1023u) status->n_valid = part[1023];
 }
 
-__global__ __launch_bounds__(BLOCK) void bucket_scatter_kernel(const uint32_t* idx, uint64_t nq,
+template <class T>
+__global__ __launch_bounds__(BLOCK) void bucket_scatter_kernel(const uint32_t* idx, const T* sval, uint64_t nq,
                                                                const StatusBlock* status,
-                                                               uint32_t* cursor, uint32_t* perm) {
+                                                               uint32_t* cursor, uint4* rec) {
   const uint64_t limit = nq;
   for (uint64_t qi = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; qi < limit;
        qi += (uint64_t)gridDim.x * BLOCK) {
-    const uint32_t pos = atomicAdd(&cursor[idx[qi]], 1u);
-    perm[pos] = (uint32_t)qi;
+    const uint32_t i = idx[qi];
+    const uint32_t pos = atomicAdd(&cursor[i], 1u);
+    rec[pos] = make_rec<T>((uint32_t)qi, i, sval[qi]);
   }
 }
 
@@ -764,9 +785,10 @@ __global__ __launch_bounds__(BLOCK) void group_offsets_kernel(uint32_t* hist, ui
   totals[bin] = run;
 }
 
-__global__ __launch_bounds__(BLOCK) void group_scatter_kernel(const uint32_t* idx, uint64_t nq, uint64_t slice,
-                                                              const uint32_t* slice_off, const uint32_t* base,
-                                                              uint32_t nb, uint32_t* perm) {
+template <class T>
+__global__ __launch_bounds__(BLOCK) void group_scatter_kernel(const uint32_t* idx, const T* sval, uint64_t nq,
+                                                              uint64_t slice, const uint32_t* slice_off,
+                                                              const uint32_t* base, uint32_t nb, uint4* rec) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem_raw);
   const uint32_t* off = slice_off + (uint64_t)blockIdx.x * nb;
@@ -776,8 +798,9 @@ __global__ __launch_bounds__(BLOCK) void group_scatter_kernel(const uint32_t* id
   uint64_t q_end = q_begin + slice;
   if (q_end > nq) q_end = nq;
   for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += BLOCK) {
-    const uint32_t pos = atomicAdd(&cur[idx[qi]], 1u);
-    perm[pos] = (uint32_t)qi;
+    const uint32_t i = idx[qi];
+    const uint32_t pos = atomicAdd(&cur[i], 1u);
+    rec[pos] = make_rec<T>((uint32_t)qi, i, sval[qi]);
   }
 }
 
@@ -830,10 +853,10 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
         const uint32_t cnt = (n_valid - p0 < (uint64_t)CQ) ? (uint32_t)(n_valid - p0) : (uint32_t)CQ;
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) {
-          const uint32_t qi = A.perm[p0 + j];
-          s_q[j] = qi;
-          s_i[j] = A.idx[qi];
-          s_s[j] = (STRAT == ST_CUBIC) ? A.t[qi] : A.q[qi];
+          const uint4 r = A.rec[p0 + j];
+          s_q[j] = r.x;
+          s_i[j] = r.y;
+          s_s[j] = rec_value(r, T(0));
         }
         __syncthreads();
         for (uint32_t j = 0; j < cnt; ++j) {

@@ -183,18 +183,39 @@ struct DevicePyramid {
       even = std::fabs((double)knots[i] - ((double)knots[0] + step * (double)i)) < 0.45 * step;
     view.guess = even ? 1 : 0;
     lds_bytes = all.size() * sizeof(T);
-    build_bucket_index(knots, n, even);
+    // Is the formula guess right for EVERY x (then no bucket index is needed)?  The guess is monotone in x, so it is
+    // enough that it maps every knot k[i] and the last value before k[i+1] to i (same T arithmetic as locate_index).
+    bool exact = even;
+    if (exact) {
+      const T k0 = knots[0], kn = knots[n - 1];
+      auto guess = [&](T x) -> uint64_t {
+        const T m = (T(n - 1u) - T(0)) / (kn - k0) * (x - k0) + T(0);
+        return (m >= T(0)) ? (uint64_t)(m < T(n - 2u) ? m : T(n - 2u)) : 0u;
+      };
+      for (uint64_t i = 0; exact && i + 1 < n; ++i)
+        exact = guess(knots[i]) == std::min<uint64_t>(i, n - 2) &&
+                guess(std::nextafter(knots[i + 1], knots[i])) == std::min<uint64_t>(i, n - 2);
+    }
+    guess_is_exact = exact;
   }
 
-  // Bucket index (kernels.hpp, BucketIndex): only for axes the O(1) formula guess does not already resolve, with
+  // The bucket index is built on first use by a batch large enough to use it (>= 4096 queries): one-shot searches
+  // and latency-bound small batches never pay for it.
+  bool guess_is_exact = false;
+  std::once_flag lut_once;
+  void ensure_bucket_index() {
+    std::call_once(lut_once, [this] { build_bucket_index(host_knots.data(), host_knots.size(), guess_is_exact); });
+  }
+
+  // Bucket index (kernels.hpp, BucketIndex): only for axes the O(1) formula guess does not resolve for every x, with
   // u16 entries (n <= 65535) and more than one top-level block.  Built with bucket_of(), the function the device uses.
   DevBuf lut_buf;
   BucketIndex<T> bidx{nullptr, 0, T(0)};
   size_t lut_bytes = 0;   // LDS bytes of the staged lut (16-byte multiple); 0 = none
-  void build_bucket_index(const T* knots, uint64_t n, bool even) {
+  void build_bucket_index(const T* knots, uint64_t n, bool guess_is_exact) {
     bidx = BucketIndex<T>{nullptr, 0, T(0)};
     lut_bytes = 0;
-    if (even || n <= 64 || n > 65535) return;
+    if (guess_is_exact || n <= 64 || n > 65535) return;
     uint32_t m = 1;
     while (m < 2 * n) m *= 2;                       // 2n <= m < 4n buckets
     const T k0 = knots[0], kn = knots[n - 1];
@@ -340,7 +361,8 @@ static void reset_status(Workspace& ws, hipStream_t s) {
                          sizeof(StatusBlock) - 2 * sizeof(unsigned long long), s));
 }
 
-constexpr uint32_t BUCKETED_RUN = 4;         // consecutive 128-query chunks per workgroup of eval_bucketed_kernel
+constexpr uint32_t BUCKETED_RUN = 1;         // consecutive 128-query chunks per workgroup of eval_bucketed_kernel
+                                             // (1 / 4 / 8 / 16 / 32 measured equal within 1 %: tools/sweep_target.py)
 constexpr uint32_t GROUP_MAX_BLOCKS = 256;   // query slices of the block-local counting sort
 constexpr uint32_t GROUP_MAX_BINS = 16384;   // histogram must fit LDS next to the pyramid
 
@@ -405,6 +427,7 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
   blocks = std::max<uint64_t>(blocks, 1);
   A.bx = BucketIndex<T>{nullptr, 0, T(0)};
   static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+  if (lut_env && A.stage_lds && nq >= 4096) const_cast<DevicePyramid<T>&>(pyr).ensure_bucket_index();
   if (lut_env && A.stage_lds && pyr.lut_bytes && nq >= 4096 &&
       shmem + pyr.lut_bytes + (hist ? (size_t)nb * 4 : 0) <= LDS_STAGE_LIMIT) {
     A.bx = pyr.bidx;          // bucket index staged behind the pyramid: [pyramid | lut | histogram]
@@ -689,8 +712,9 @@ struct Interp1DImpl final : Interp1DBase {
       const uint32_t nb = (uint32_t)(n - 1);
       ws.counts.reserve((size_t)nb * sizeof(uint32_t));
       ws.cursor.reserve((size_t)nb * sizeof(uint32_t));
-      ws.perm.reserve(nq * sizeof(uint32_t));
-      A.perm = ws.perm.as<uint32_t>();
+      ws.perm.reserve(nq * sizeof(uint4));
+      A.rec = ws.perm.as<uint4>();
+      const T* sval = strategy == NDI_CUBIC_SPLINE ? (const T*)ws.t.as<T>() : q;   // t (cubic) / raw x (linear)
       if (lds_sort_fits(pyr, nb)) {
         // block-local counting sort: histogram per query slice in LDS, no global atomics
         ws.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
@@ -703,11 +727,11 @@ struct Interp1DImpl final : Interp1DBase {
                            ws.hist.as<uint32_t>(), blocks, nb, ws.counts.as<uint32_t>());
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
                            ws.cursor.as<uint32_t>(), st);
-        allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter_kernel), (int)(GROUP_MAX_BINS * 4));
-        hipLaunchKernelGGL(group_scatter_kernel, dim3(blocks), dim3(BLOCK), (size_t)nb * 4, s,
-                           (const uint32_t*)ws.idx.as<uint32_t>(), nq, slice,
+        allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter_kernel<T>), (int)(GROUP_MAX_BINS * 4));
+        hipLaunchKernelGGL(group_scatter_kernel<T>, dim3(blocks), dim3(BLOCK), (size_t)nb * 4, s,
+                           (const uint32_t*)ws.idx.as<uint32_t>(), sval, nq, slice,
                            (const uint32_t*)ws.hist.as<uint32_t>(), (const uint32_t*)ws.cursor.as<uint32_t>(),
-                           nb, ws.perm.as<uint32_t>());
+                           nb, ws.perm.as<uint4>());
         NDI_HIP(hipGetLastError());
         ps.done();
       } else {
@@ -720,8 +744,8 @@ struct Interp1DImpl final : Interp1DBase {
                            ws.counts.as<uint32_t>());
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
                            ws.cursor.as<uint32_t>(), st);
-        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(BLOCK), 0, s, A.idx, nq, st,
-                           ws.cursor.as<uint32_t>(), ws.perm.as<uint32_t>());
+        hipLaunchKernelGGL(bucket_scatter_kernel<T>, dim3(g), dim3(BLOCK), 0, s, A.idx, sval, nq, st,
+                           ws.cursor.as<uint32_t>(), ws.perm.as<uint4>());
         NDI_HIP(hipGetLastError());
         ps.done();
       }
@@ -730,7 +754,8 @@ struct Interp1DImpl final : Interp1DBase {
       const uint64_t segs = (LV + (uint64_t)BLOCK * U - 1) / ((uint64_t)BLOCK * U);
       // a multiple of 8 so that a workgroup keeps its XCD residue when it strides (XCD-aware chunk order);
       // every workgroup takes a run of consecutive chunks (operand rows stay in registers across them)
-      static const uint32_t run_env = [] { const char* e = std::getenv("NDI_BUCKETED_RUN"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+      const char* run_e = std::getenv("NDI_BUCKETED_RUN");   // tuning knob (tools/sweep_target.py)
+      const uint32_t run_env = run_e ? (uint32_t)std::atoi(run_e) : 0u;
       const uint64_t per_xcd = ((nq + CQ - 1) / CQ + 7) / 8;
       A.run = run_env ? run_env : BUCKETED_RUN;
       const uint64_t runs_per_xcd = (per_xcd + A.run - 1) / A.run;
@@ -1165,8 +1190,13 @@ struct Interp2DImpl final : Interp2DBase {
       LA.by = LA.bx;
       static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
       size_t both_l = both;
-      if (lut_env && px.lut_bytes && py.lut_bytes && nq >= 4096 && both + px.lut_bytes + py.lut_bytes <= LDS_STAGE_LIMIT) {
-        LA.bx = px.bidx;      // [x pyramid | y pyramid | x lut | y lut]
+      if (lut_env && nq >= 4096) {
+        px.ensure_bucket_index();
+        py.ensure_bucket_index();
+      }
+      if (lut_env && (px.lut_bytes || py.lut_bytes) && nq >= 4096 &&
+          both + px.lut_bytes + py.lut_bytes <= LDS_STAGE_LIMIT) {
+        LA.bx = px.bidx;      // [x pyramid | y pyramid | x lut | y lut]; an axis whose formula guess is exact has none
         LA.by = py.bidx;
         both_l = both + px.lut_bytes + py.lut_bytes;
       }

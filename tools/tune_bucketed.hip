@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <random>
 #include <vector>
@@ -69,10 +70,10 @@ __global__ __launch_bounds__(TB) void variant_kernel(Eval1Args<double> A) {
     const uint32_t cnt = (n_valid - p0 < (uint64_t)CQ) ? (uint32_t)(n_valid - p0) : (uint32_t)CQ;
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < cnt; j += TB) {
-      const uint32_t qi = A.perm[p0 + j];
-      s_q[j] = qi;
-      s_i[j] = A.idx[qi];
-      s_s[j] = A.t[qi];
+      const uint4 r = A.rec[p0 + j];
+      s_q[j] = r.x;
+      s_i[j] = r.y;
+      s_s[j] = rec_value(r, 0.0);
     }
     __syncthreads();
     // MODE bit 4: every wave owns a contiguous 8 KiB piece of the row (its 8 stores are adjacent) instead of
@@ -81,11 +82,19 @@ __global__ __launch_bounds__(TB) void variant_kernel(Eval1Args<double> A) {
     constexpr uint64_t VSTEP = (MODE & 16) ? 64 : TB;
     V ryl[U], ryr[U], ra[U], rb[U];
     uint32_t cur = 0xffffffffu;
+    if (MODE & 128) {   // four live operand rows that are never loaded from memory
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double f = (double)(threadIdx.x + 256 * u) * 1e-3 + A.out_stride * 1e-9;
+        ryl[u] = V{f, f + 1.0}; ryr[u] = V{f * 2.0, f - 1.0}; ra[u] = V{f * 0.5, f * 0.25}; rb[u] = V{f + 3.0, f * 3.0};
+      }
+      cur = 0;
+    }
     for (uint32_t j = 0; j < cnt; ++j) {
       const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_i[j]);
       const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_q[j]);
       const double sj = s_s[j];
-      if ((MODE & 1) ? (cur == 0xffffffffu) : (i != cur)) {
+      if ((MODE & 128) ? false : ((MODE & 1) ? (cur == 0xffffffffu) : (i != cur))) {
         cur = i;
         const V* yl = reinterpret_cast<const V*>(A.data + (uint64_t)i * A.lanes);
         const V* yr = yl + LV;
@@ -99,6 +108,15 @@ __global__ __launch_bounds__(TB) void variant_kernel(Eval1Args<double> A) {
       }
       const RowCoef<double, ST_CUBIC> c = row_coef<double, ST_CUBIC>(A.knots, i, sj, sj);
       V* o = reinterpret_cast<V*>(A.out + (uint64_t)qi * A.out_stride);
+      if (MODE & 64) {   // all U results first, then the U stores back to back
+        V r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = row_point<double, ST_CUBIC, V>(c, ryl[u], ryr[u], ra[u], rb[u]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) store_stream<true>(o + (v0 + (uint64_t)u * VSTEP), r[u]);
+        continue;
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint64_t v = v0 + (uint64_t)u * VSTEP;
@@ -162,6 +180,17 @@ int main() {
   CK(hipMalloc(&d_t, Q * 8)); CK(hipMemcpy(d_t, t.data(), Q * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_idx, Q * 4)); CK(hipMemcpy(d_idx, idx.data(), Q * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_perm, Q * 4)); CK(hipMemcpy(d_perm, perm.data(), Q * 4, hipMemcpyHostToDevice));
+  uint4* d_rec;
+  {
+    std::vector<uint4> rec(Q);
+    for (uint64_t p = 0; p < Q; ++p) {
+      const uint32_t qi = perm[p];
+      unsigned long long b;
+      memcpy(&b, &t[qi], 8);
+      rec[p] = make_uint4(qi, idx[qi], (uint32_t)b, (uint32_t)(b >> 32));
+    }
+    CK(hipMalloc(&d_rec, Q * 16)); CK(hipMemcpy(d_rec, rec.data(), Q * 16, hipMemcpyHostToDevice));
+  }
   CK(hipMalloc(&d_st, sizeof(StatusBlock)));
   CK(hipMemset(d_st, 0xFF, 16));
   const size_t tab = n * L * 8;
@@ -187,7 +216,7 @@ int main() {
   }
   Eval1Args<double> A{};
   A.knots = d_x; A.data = d_data; A.ca = d_a; A.cb = d_b; A.q = d_q; A.idx = d_idx; A.t = d_t; A.out = d_out;
-  A.lanes = L; A.out_stride = stride; A.nq = Q; A.status = d_st; A.perm = d_perm;
+  A.lanes = L; A.out_stride = stride; A.nq = Q; A.status = d_st; A.rec = d_rec; A.run = 4;
   const uint64_t LV = L / 2;
 #define RUN_BK(U, CQ, FULL)                                                                                   \
   {                                                                                                           \
@@ -216,7 +245,7 @@ int main() {
     double tm = time_ms([&] { hipLaunchKernelGGL((variant_kernel<MODE, TB, UU>), dim3(7816), dim3(TB), 0, 0, A); });   \
     printf("{\"kernel\": \"variant\", \"mode\": %d, \"threads\": %d, \"U\": %d, \"ms\": %.3f, \"TBs\": %.2f}\n", MODE, TB, UU, tm, out_gb / tm); \
   }
-  RUN_VAR(0) RUN_VAR(1) RUN_VAR(2) RUN_VAR(3) RUN_VAR(4) RUN_VAR2(0, 512, 4) RUN_VAR2(0, 1024, 2) RUN_VAR2(0, 128, 16)
+  RUN_VAR(0) RUN_VAR(1) RUN_VAR(2) RUN_VAR(3) RUN_VAR2(128, 256, 8) RUN_VAR2(0, 256, 8) RUN_VAR2(128, 256, 8)
   if (getenv("TUNE_SWEEP")) {
   RUN_BK(8, 128, true) RUN_BK(8, 128, false) RUN_BK(4, 128, true) RUN_BK(2, 128, true) RUN_BK(1, 128, true)
   RUN_BK(8, 64, true) RUN_BK(8, 256, true) RUN_BK(4, 256, true) RUN_BK(4, 64, true) RUN_BK(8, 512, true)

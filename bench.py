@@ -374,7 +374,8 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         interp.strategy.path = pkg.PATH_GATHER
         interp.interp_array_ring(qd[:2 * chunk], chunk, None, slots=ring)
         pkg.profile_enable(True); pkg.profile_read(reset=True)
-        interp.interp_array_ring(qd, chunk, None, slots=ring)
+        for _pass in range(2):
+            interp.interp_array_ring(qd, chunk, None, slots=ring)
         gp = pkg.profile_read(reset=True); pkg.profile_enable(False)
         gms = gp["eval_ms"] / max(1, gp["eval_launches"])
         line["gather_formulation"] = {

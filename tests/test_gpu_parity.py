@@ -301,8 +301,8 @@ def test_cubic_eval_bit_exact(pkg, dt, n, L, Q):
 def test_cubic_many_knots_grouping_variants(pkg, dt, n, Q):
     """Grouping back ends of the bucketed formulation: 10000 knots = block-local sort with a large LDS
     histogram next to the staged pyramid; 20000 = more intervals than the LDS histogram holds -> global-atomic
-    histogram + placement; 70000 = more knots than the u16 bucket index covers and a two-level pyramid (1094 top
-    entries per block) too large for LDS, searched in global memory."""
+    histogram + placement; 70000 = more knots than the u16 bucket index covers and a pyramid too large for LDS
+    (560 KB of f64 knots), searched in global memory."""
     rng = np.random.default_rng(n)
     L = 512 if dt == np.float64 else 1024
     x = knots("jit", n, rng, dt)

@@ -183,10 +183,20 @@ class _DeviceStrategy1D(Interp1DStrategy):
             ring.n_slots = int(n_slots)
             ring.row_stride = self._lanes
 
+        failed = []
+
         def _cb(_user, cptr):
-            c = cptr.contents
-            view = slots[c.slot][:c.q_count] if slots is not None else None
-            ev = consumer(c, view)
+            # an exception must not unwind through the C frames: remember the first one, stop consuming, re-raise
+            # after the library call has returned
+            if failed:
+                return None
+            try:
+                c = cptr.contents
+                view = slots[c.slot][:c.q_count] if slots is not None else None
+                ev = consumer(c, view)
+            except BaseException as e:  # noqa: BLE001
+                failed.append(e)
+                return None
             if ev is None:
                 return None
             keep_events.append(ev)
@@ -201,6 +211,8 @@ class _DeviceStrategy1D(Interp1DStrategy):
         st = _capi.lib().ndi_interp1d_eval_ring(self._h, qb.ptr, qb.size, C.byref(ring), cb, None,
                                                 C.byref(opts), C.byref(info))
         del keep_events
+        if failed:
+            raise failed[0]
         if st != _capi.OK:
             raise_eval(st, info)
 

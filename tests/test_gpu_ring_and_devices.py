@@ -132,6 +132,24 @@ def test_ring_first_error_produces_exactly_the_rows_before_it(pkg):
     assert np.array_equal(np.concatenate([p[2] for p in produced]), ref)
 
 
+def test_ring_consumer_exception_is_reraised(pkg):
+    """An exception in a Python consumer does not unwind through the C frames and is not swallowed: the remaining
+    chunks are produced without being consumed and the first exception is re-raised after the call."""
+    rng = np.random.default_rng(15)
+    interp, x, y, a, b = _cubic(pkg, 30, 256, rng)
+    q = rng.uniform(x[0], x[-1], 5000)
+    seen = []
+
+    def consumer(c, rows):
+        seen.append(c.index)
+        if c.index == 1:
+            raise ValueError("consumer failed on chunk 1")
+    with pytest.raises(ValueError, match="consumer failed on chunk 1"):
+        interp.interp_array_ring(q, 1000, consumer, n_slots=2)
+    assert seen == [0, 1]
+    assert np.array_equal(interp.interp_array(q), oracle.interp1d_cubic(x, y, a, b, q)[2])   # the handle is fine
+
+
 def test_ring_consumer_on_its_own_stream(pkg):
     """A consumer that drains the slot on another stream returns an event; the library's stream waits for it
     before the slot is overwritten (2 slots, 9 chunks: every slot is reused four times)."""

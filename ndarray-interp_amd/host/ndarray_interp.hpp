@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <numeric>
@@ -381,11 +382,15 @@ class Interp1D {  // interp1d/mod.rs:39-51
     ndi_eval_opts o{};
     o.q_memspace = NDI_MEM_HOST; o.out_memspace = NDI_MEM_DEVICE; o.path = dev->path;
     ndi_oob_info info{};
+    // an exception of the consumer must not unwind through the C ABI: keep the first one, stop consuming, rethrow
+    struct Ctx { const std::function<void*(const RingChunk&)>* fn; std::exception_ptr err; } ctx{&consume, nullptr};
     auto tramp = [](void* user, const ndi_ring_chunk* c) -> void* {
-      return (*static_cast<const std::function<void*(const RingChunk&)>*>(user))(*c);
+      Ctx* cx = static_cast<Ctx*>(user);
+      if (cx->err) return nullptr;
+      try { return (*cx->fn)(*c); } catch (...) { cx->err = std::current_exception(); return nullptr; }
     };
-    int st = ndi_interp1d_eval_ring(dev->h, xs.data.data(), xs.len(), &ring, tramp,
-                                    const_cast<void*>(static_cast<const void*>(&consume)), &o, &info);
+    int st = ndi_interp1d_eval_ring(dev->h, xs.data.data(), xs.len(), &ring, tramp, &ctx, &o, &info);
+    if (ctx.err) std::rethrow_exception(ctx.err);
     if (st != NDI_OK) detail::throw_eval(st, info);
   }
 

@@ -63,11 +63,12 @@ int main(int argc, char** argv) {
   for (uint32_t j = 0; j < n1; ++j) pyr[n + j] = x[j * 64];
   for (uint32_t j = 0; j < n2; ++j) pyr[n + n1 + j] = x[j * 4096];
   double *d_pyr, *d_q, *d_t, *d_data, *d_a, *d_b, *d_out;
-  uint32_t *d_idx, *d_perm, *d_counts, *d_cursor;
+  uint32_t *d_idx, *d_counts, *d_cursor;
+  uint4* d_rec;
   StatusBlock* d_st;
   CK(hipMalloc(&d_pyr, pyr.size() * 8)); CK(hipMemcpy(d_pyr, pyr.data(), pyr.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_q, Q * 8)); CK(hipMemcpy(d_q, q.data(), Q * 8, hipMemcpyHostToDevice));
-  CK(hipMalloc(&d_t, Q * 8)); CK(hipMalloc(&d_idx, Q * 4)); CK(hipMalloc(&d_perm, Q * 4));
+  CK(hipMalloc(&d_t, Q * 8)); CK(hipMalloc(&d_idx, Q * 4)); CK(hipMalloc(&d_rec, Q * 16));
   CK(hipMalloc(&d_counts, n * 4)); CK(hipMalloc(&d_cursor, n * 4)); CK(hipMalloc(&d_st, sizeof(StatusBlock)));
   const size_t tab = n * L * 8;
   CK(hipMalloc(&d_data, tab)); CK(hipMalloc(&d_a, tab)); CK(hipMalloc(&d_b, tab));
@@ -107,7 +108,7 @@ int main(int argc, char** argv) {
     CK(hipMemsetAsync(d_counts, 0, nb * 4, 0));
     hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(256), 0, 0, d_idx, Q, d_st, d_counts);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, 0, d_counts, nb, d_cursor, d_st);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(g), dim3(256), 0, 0, d_idx, Q, d_st, d_cursor, d_perm);
+    hipLaunchKernelGGL(bucket_scatter_kernel<double>, dim3(g), dim3(256), 0, 0, d_idx, (const double*)d_t, Q, d_st, d_cursor, d_rec);
   });
   printf("bucket count+scan+scatter          %8.3f ms\n", t_grp);
 
@@ -127,7 +128,7 @@ int main(int argc, char** argv) {
 
   Eval1Args<double> A{};
   A.knots = d_pyr; A.data = d_data; A.ca = d_a; A.cb = d_b; A.q = d_q; A.idx = d_idx; A.t = d_t; A.out = d_out;
-  A.lanes = L; A.out_stride = L; A.nq = Q; A.status = d_st; A.perm = d_perm;
+  A.lanes = L; A.out_stride = L; A.nq = Q; A.status = d_st; A.rec = d_rec; A.run = 1;
   const uint64_t LV = L / 2;
 #define RUN_BK(U, CQ, NT)                                                                              \
   {                                                                                                    \
@@ -140,35 +141,6 @@ int main(int argc, char** argv) {
   RUN_BK(1, 128, true) RUN_BK(2, 128, true) RUN_BK(4, 128, true) RUN_BK(8, 128, true)
   RUN_BK(4, 64, true) RUN_BK(4, 256, true) RUN_BK(4, 512, true) RUN_BK(2, 256, true) RUN_BK(2, 512, true) RUN_BK(8, 256, true)
   RUN_BK(4, 128, false) RUN_BK(4, 256, false) RUN_BK(2, 256, false) RUN_BK(8, 256, false)
-  }
-  {  // permutation layouts: how the order of the output rows affects the write stream
-    std::vector<uint32_t> hidx(Q), perm(Q);
-    CK(hipMemcpy(hidx.data(), d_idx, Q * 4, hipMemcpyDeviceToHost));
-    auto run_perm = [&](const char* name) {
-      CK(hipMemcpy(d_perm, perm.data(), Q * 4, hipMemcpyHostToDevice));
-      for (int rep = 0; rep < 2; ++rep) RUN_BK(8, 128, true)
-      printf("   ^ perm layout: %s\n", name);
-    };
-    for (uint32_t i = 0; i < Q; ++i) perm[i] = i;
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return hidx[a] < hidx[b]; });
-    run_perm("interval-major, ascending q inside an interval");
-    {
-      std::mt19937 g2(7);
-      size_t b = 0;
-      while (b < Q) { size_t e = b; while (e < Q && hidx[perm[e]] == hidx[perm[b]]) ++e; std::shuffle(perm.begin() + b, perm.begin() + e, g2); b = e; }
-    }
-    run_perm("interval-major, random q inside an interval");
-    for (uint32_t ns : {2u, 4u, 8u, 16u, 64u}) {
-      const uint64_t ss = (Q + ns - 1) / ns;
-      for (uint32_t i = 0; i < Q; ++i) perm[i] = i;
-      std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
-        const uint64_t sa = a / ss, sb = b / ss;
-        return sa != sb ? sa < sb : hidx[a] < hidx[b]; });
-      char nm[96]; snprintf(nm, sizeof nm, "%u superslices (slice-major, then interval)", ns);
-      run_perm(nm);
-    }
-    for (uint32_t i = 0; i < Q; ++i) perm[i] = i;
-    run_perm("identity (no grouping: sequential rows, reload per query)");
   }
 #define RUN_RW(U, NT)                                                                                  \
   {                                                                                                    \

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 #include "../ndarray-interp_amd/csrc/kernels.hpp"
@@ -28,18 +29,26 @@ template <class T, int U> static void run(const char* name, uint64_t L, uint64_t
   std::vector<T> t(Q);
   for (uint64_t i = 0; i < Q; ++i) { idx[i] = (uint32_t)(rng() % (n - 1)); t[i] = (T)((rng() >> 11) * (1.0 / 9007199254740992.0)); perm[i] = (uint32_t)i; }
   std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return idx[a] < idx[b]; });
-  T *data, *ca, *cb, *dt, *knots; uint32_t *didx, *dperm; StatusBlock* st;
+  T *data, *ca, *cb, *dt, *knots; uint32_t *didx; uint4* drec; StatusBlock* st;
   CK(hipMalloc(&data, n * L * sizeof(T))); CK(hipMalloc(&ca, n * L * sizeof(T))); CK(hipMalloc(&cb, n * L * sizeof(T)));
-  CK(hipMalloc(&dt, Q * sizeof(T))); CK(hipMalloc(&didx, Q * 4)); CK(hipMalloc(&dperm, Q * 4)); CK(hipMalloc(&st, sizeof(StatusBlock)));
+  CK(hipMalloc(&dt, Q * sizeof(T))); CK(hipMalloc(&didx, Q * 4)); CK(hipMalloc(&drec, Q * 16)); CK(hipMalloc(&st, sizeof(StatusBlock)));
   CK(hipMalloc(&knots, n * sizeof(T)));
   hipLaunchKernelGGL(fill_rand<T>, dim3(4096), dim3(256), 0, 0, data, n * L, 1u);
   hipLaunchKernelGGL(fill_rand<T>, dim3(4096), dim3(256), 0, 0, ca, n * L, 2u);
   hipLaunchKernelGGL(fill_rand<T>, dim3(4096), dim3(256), 0, 0, cb, n * L, 3u);
   CK(hipMemcpy(dt, t.data(), Q * sizeof(T), hipMemcpyHostToDevice)); CK(hipMemcpy(didx, idx.data(), Q * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(dperm, perm.data(), Q * 4, hipMemcpyHostToDevice));
+  {   // grouped records {query index, interval, t bits} as the library's scatter pass writes them
+    std::vector<uint4> rec(Q);
+    for (uint64_t p = 0; p < Q; ++p) {
+      const uint32_t qi = perm[p];
+      if (sizeof(T) == 8) { unsigned long long b; memcpy(&b, &t[qi], 8); rec[p] = make_uint4(qi, idx[qi], (uint32_t)b, (uint32_t)(b >> 32)); }
+      else { uint32_t b; memcpy(&b, &t[qi], 4); rec[p] = make_uint4(qi, idx[qi], b, 0u); }
+    }
+    CK(hipMemcpy(drec, rec.data(), Q * 16, hipMemcpyHostToDevice));
+  }
   CK(hipMemset(st, 0xFF, 16)); CK(hipMemset((char*)st + 16, 0, sizeof(StatusBlock) - 16));
   Eval1Args<T> A{}; A.knots = knots; A.data = data; A.ca = ca; A.cb = cb; A.q = dt; A.idx = didx; A.t = dt; A.out = (T*)d_out;
-  A.lanes = L; A.out_stride = L; A.nq = Q; A.status = st; A.perm = dperm;
+  A.lanes = L; A.out_stride = L; A.nq = Q; A.status = st; A.rec = drec; A.run = 1;
   const uint64_t LV = L / Wide<T>::N;
   const unsigned segs = (unsigned)((LV + 256 * U - 1) / (256 * U));
   const uint64_t per = ((Q + 127) / 128 + 7) / 8;

@@ -58,7 +58,7 @@ template <class T, int U> static void run(const char* name, uint64_t L, uint64_t
     double t2 = time_ms([&] { hipLaunchKernelGGL((eval_bucketed_kernel<T, ST_LINEAR, U, 128, true>), dim3((unsigned)(per * 8), segs), dim3(256), 0, 0, A); });
     printf("%s U=%d L=%llu  cubic %7.3f ms (%5.0f GB/s out)   linear-formula %7.3f ms (%5.0f GB/s out)\n", name, U, (unsigned long long)L, t1, out_gb / t1 * 1e3, t2, out_gb / t2 * 1e3);
   }
-  CK(hipFree(data)); CK(hipFree(ca)); CK(hipFree(cb)); CK(hipFree(dt)); CK(hipFree(didx)); CK(hipFree(dperm)); CK(hipFree(st)); CK(hipFree(knots));
+  CK(hipFree(data)); CK(hipFree(ca)); CK(hipFree(cb)); CK(hipFree(dt)); CK(hipFree(didx)); CK(hipFree(drec)); CK(hipFree(st)); CK(hipFree(knots));
 }
 int main() {
   const uint64_t Q = 1000000;

@@ -202,9 +202,11 @@ struct DevicePyramid {
   // The bucket index is built on first use by a batch large enough to use it (>= 4096 queries): one-shot searches
   // and latency-bound small batches never pay for it.
   bool guess_is_exact = false;
-  std::once_flag lut_once;
-  void ensure_bucket_index() {
-    std::call_once(lut_once, [this] { build_bucket_index(host_knots.data(), host_knots.size(), guess_is_exact); });
+  mutable std::once_flag lut_once;
+  void ensure_bucket_index() const {   // lazily built cache: logically const
+    std::call_once(lut_once, [this] {
+      const_cast<DevicePyramid*>(this)->build_bucket_index(host_knots.data(), host_knots.size(), guess_is_exact);
+    });
   }
 
   // Bucket index (kernels.hpp, BucketIndex): only for axes the O(1) formula guess does not resolve for every x, with
@@ -427,7 +429,7 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
   blocks = std::max<uint64_t>(blocks, 1);
   A.bx = BucketIndex<T>{nullptr, 0, T(0)};
   static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
-  if (lut_env && A.stage_lds && nq >= 4096) const_cast<DevicePyramid<T>&>(pyr).ensure_bucket_index();
+  if (lut_env && A.stage_lds && nq >= 4096) pyr.ensure_bucket_index();
   if (lut_env && A.stage_lds && pyr.lut_bytes && nq >= 4096 &&
       shmem + pyr.lut_bytes + (hist ? (size_t)nb * 4 : 0) <= LDS_STAGE_LIMIT) {
     A.bx = pyr.bidx;          // bucket index staged behind the pyramid: [pyramid | lut | histogram]

@@ -933,30 +933,30 @@ struct KnotPtr<T, true> { using type = const __attribute__((address_space(3))) T
 
 // 2-D grouping key: the tile (2^sx x 2^sy cells) a query's cell falls in.  One workgroup per contiguous
 // query slice; leaves the keys and the slice's tile histogram (same layout as locate_kernel's).
-__global__ __launch_bounds__(BLOCK) void tile_hist_kernel(const uint32_t* xi, const uint32_t* yi, uint64_t nq,
-                                                          uint64_t slice, uint32_t sx, uint32_t sy, uint32_t nty,
-                                                          uint32_t nb, uint32_t* key, uint32_t* hist) {
+__global__ __launch_bounds__(1024) void tile_hist_kernel(const uint32_t* xi, const uint32_t* yi, uint64_t nq,
+                                                         uint64_t slice, uint32_t sx, uint32_t sy, uint32_t nty,
+                                                         uint32_t nb, uint32_t* key, uint32_t* hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem_raw);
-  for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) s_hist[i] = 0u;
+  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_hist[i] = 0u;
   __syncthreads();
   const uint64_t q_begin = (uint64_t)blockIdx.x * slice;
   uint64_t q_end = q_begin + slice;
   if (q_end > nq) q_end = nq;
-  for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += BLOCK) {
+  for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += blockDim.x) {
     const uint32_t k = (xi[qi] >> sx) * nty + (yi[qi] >> sy);
     key[qi] = k;
     atomicAdd(&s_hist[k], 1u);
   }
   __syncthreads();
   uint32_t* dst = hist + (uint64_t)blockIdx.x * nb;
-  for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) dst[i] = s_hist[i];
+  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) dst[i] = s_hist[i];
 }
 
 // Places every query's record at its tile-grouped position (block-local cursors in LDS, see
 // group_scatter_kernel): sequential reads in query order, one 16-byte and one 2*sizeof(T) write per query.
 template <class T>
-__global__ __launch_bounds__(BLOCK) void group_scatter2d_kernel(const uint32_t* key, const uint32_t* xi,
+__global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* key, const uint32_t* xi,
                                                                 const uint32_t* yi, const T* qx, const T* qy,
                                                                 uint64_t nq, uint64_t slice,
                                                                 const uint32_t* slice_off, const uint32_t* base,
@@ -964,12 +964,12 @@ __global__ __launch_bounds__(BLOCK) void group_scatter2d_kernel(const uint32_t* 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem_raw);
   const uint32_t* off = slice_off + (uint64_t)blockIdx.x * nb;
-  for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) cur[i] = off[i] + base[i];
+  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cur[i] = off[i] + base[i];
   __syncthreads();
   const uint64_t q_begin = (uint64_t)blockIdx.x * slice;
   uint64_t q_end = q_begin + slice;
   if (q_end > nq) q_end = nq;
-  for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += BLOCK) {
+  for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += blockDim.x) {
     const uint32_t pos = atomicAdd(&cur[key[qi]], 1u);
     rec_i[pos] = make_uint4((uint32_t)qi, xi[qi], yi[qi], 0u);
     rec_q[2 * (uint64_t)pos] = qx[qi];

@@ -1255,6 +1255,8 @@ struct Interp2DImpl final : Interp2DBase {
       uint64_t slice = (nq + blocks - 1) / blocks;
       slice = (slice + BLOCK - 1) / BLOCK * BLOCK;
       blocks = (nq + slice - 1) / slice;
+      // the two grouping kernels are latency-bound chains (load -> LDS atomic -> scattered store): many waves per CU
+      const unsigned gthreads = slice >= 4096 ? 1024u : (unsigned)BLOCK;
       ws.t.reserve(nq * sizeof(uint32_t));      // keys
       ws.perm.reserve(nq * sizeof(uint4));            // grouped records {qi, xi, yi}
       ws.stage[1].reserve(nq * 2 * sizeof(T));        // grouped {qx, qy}
@@ -1264,14 +1266,14 @@ struct Interp2DImpl final : Interp2DBase {
       allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T>), (int)(GROUP_MAX_BINS * 4));
       allow_dynamic_lds(reinterpret_cast<const void*>(&tile_hist_kernel), (int)(GROUP_MAX_BINS * 4));
       ProfScope ps(s, PC_GROUP);
-      hipLaunchKernelGGL(tile_hist_kernel, dim3((unsigned)blocks), dim3(BLOCK), (size_t)nb * 4, s,
+      hipLaunchKernelGGL(tile_hist_kernel, dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
                          (const uint32_t*)A.xi, (const uint32_t*)A.yi, nq, slice, sx, sy, nty, nb,
                          ws.t.as<uint32_t>(), ws.hist.as<uint32_t>());
       hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
                          ws.hist.as<uint32_t>(), (uint32_t)blocks, nb, ws.counts.as<uint32_t>());
       hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
                          ws.cursor.as<uint32_t>(), st);
-      hipLaunchKernelGGL(group_scatter2d_kernel<T>, dim3((unsigned)blocks), dim3(BLOCK), (size_t)nb * 4, s,
+      hipLaunchKernelGGL(group_scatter2d_kernel<T>, dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
                          (const uint32_t*)ws.t.as<uint32_t>(), (const uint32_t*)A.xi, (const uint32_t*)A.yi, qx, qy,
                          nq, slice, (const uint32_t*)ws.hist.as<uint32_t>(),
                          (const uint32_t*)ws.cursor.as<uint32_t>(), nb, ws.perm.as<uint4>(), ws.stage[1].as<T>());

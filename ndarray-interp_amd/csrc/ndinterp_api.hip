@@ -147,6 +147,28 @@ struct ProfScope {
     NDI_HIP(hipEventRecord(r.b, s));
     std::lock_guard<std::mutex> g(g_prof_mu);
     g_prof_recs.push_back(r);
+    if (g_prof_recs.size() >= 4096) fold_finished_locked();   // profiling left on and never read: stay bounded
+  }
+  // Adds the records whose kernels have finished to the running totals and frees their events (g_prof_mu held).
+  static void fold_finished_locked() {
+    size_t keep = 0;
+    for (size_t i = 0; i < g_prof_recs.size(); ++i) {
+      ProfRec& r = g_prof_recs[i];
+      if (hipEventQuery(r.b) != hipSuccess) {
+        (void)hipGetLastError();
+        g_prof_recs[keep++] = r;
+        continue;
+      }
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+        if (r.cat == PC_EVAL) { g_prof_acc.eval_launches++; g_prof_acc.eval_ms += ms; }
+        else if (r.cat == PC_LOCATE) { g_prof_acc.locate_launches++; g_prof_acc.locate_ms += ms; }
+        else { g_prof_acc.group_launches++; g_prof_acc.group_ms += ms; }
+      }
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    g_prof_recs.resize(keep);
   }
 };
 

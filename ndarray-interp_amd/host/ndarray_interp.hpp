@@ -244,6 +244,49 @@ struct Interp1DStrategyBuilder {  // trait Interp1DStrategyBuilder, strategies/m
   virtual std::shared_ptr<Interp1DStrategy<T>> build(const std::vector<T>& x, const Array<T>& data) = 0;
 };
 
+// boundary conditions (cubic_spline.rs:153-217)
+struct SingleBoundary {
+  int kind = NDI_BC_NOT_A_KNOT;
+  double value = 0.0;
+  static SingleBoundary NotAKnot() { return {NDI_BC_NOT_A_KNOT, 0.0}; }
+  static SingleBoundary Natural() { return {NDI_BC_NATURAL, 0.0}; }
+  static SingleBoundary Clamped() { return {NDI_BC_CLAMPED, 0.0}; }
+  static SingleBoundary FirstDeriv(double v) { return {NDI_BC_FIRST_DERIV, v}; }
+  static SingleBoundary SecondDeriv(double v) { return {NDI_BC_SECOND_DERIV, v}; }
+};
+struct RowBoundary {   // cubic_spline.rs:170-202: the boundary of one data row
+  SingleBoundary left, right;
+  static RowBoundary NotAKnot() { return {SingleBoundary::NotAKnot(), SingleBoundary::NotAKnot()}; }
+  static RowBoundary Natural() { return {SingleBoundary::Natural(), SingleBoundary::Natural()}; }
+  static RowBoundary Clamped() { return {SingleBoundary::Clamped(), SingleBoundary::Clamped()}; }
+  static RowBoundary Mixed(SingleBoundary l, SingleBoundary r) { return {l, r}; }
+};
+struct BoundaryCondition {
+  bool periodic = false;
+  SingleBoundary left, right;
+  // BoundaryCondition::Individual (cubic_spline.rs:165-167, 332-347): one RowBoundary per trailing element, shape
+  // [1, data.shape[1..]] flattened in C order; empty = one boundary for the whole dataset
+  std::vector<RowBoundary> rows;
+  std::vector<size_t> rows_shape;
+  static BoundaryCondition Individual(std::vector<size_t> shape, std::vector<RowBoundary> r) {
+    BoundaryCondition b;
+    b.rows = std::move(r);
+    b.rows_shape = std::move(shape);
+    return b;
+  }
+  static BoundaryCondition whole(bool per, SingleBoundary l, SingleBoundary r) {
+    BoundaryCondition b;
+    b.periodic = per; b.left = l; b.right = r;
+    return b;
+  }
+  static BoundaryCondition NotAKnot() { return whole(false, SingleBoundary::NotAKnot(), SingleBoundary::NotAKnot()); }
+  static BoundaryCondition Natural() { return whole(false, SingleBoundary::Natural(), SingleBoundary::Natural()); }
+  static BoundaryCondition Clamped() { return whole(false, SingleBoundary::Clamped(), SingleBoundary::Clamped()); }
+  static BoundaryCondition Periodic() { return whole(true, {}, {}); }
+  // RowBoundary::Mixed applied to the whole dataset
+  static BoundaryCondition Mixed(SingleBoundary l, SingleBoundary r) { return whole(false, l, r); }
+};
+
 namespace detail {
 template <class T>
 struct Device1D : Interp1DStrategy<T> {  // owns an ndi_interp1d*
@@ -252,8 +295,18 @@ struct Device1D : Interp1DStrategy<T> {  // owns an ndi_interp1d*
   int path = NDI_PATH_AUTO;
   ~Device1D() override { ndi_interp1d_destroy(h); }
   void create(const std::vector<T>& x, const Array<T>& data, int strategy, bool extrapolate, bool periodic,
-              ndi_boundary left, ndi_boundary right, int device) {
+              ndi_boundary left, ndi_boundary right, int device, const std::vector<RowBoundary>* rows = nullptr) {
     ndi_interp1d_desc d{};
+    std::vector<int32_t> lk, rk;
+    std::vector<double> lv, rv;
+    if (rows) {   // BoundaryCondition::Individual -> the four lane_* arrays of the C ABI
+      for (const RowBoundary& r : *rows) {
+        lk.push_back(r.left.kind); lv.push_back(r.left.value);
+        rk.push_back(r.right.kind); rv.push_back(r.right.value);
+      }
+      d.lane_left_kind = lk.data(); d.lane_left_value = lv.data();
+      d.lane_right_kind = rk.data(); d.lane_right_value = rv.data();
+    }
     d.dtype = DType<T>::id; d.strategy = strategy; d.extrapolate = extrapolate; d.device = device;
     d.n = data.shape[0]; d.lanes = lanes = prod(data.shape, 1); d.x_len = x.size();
     d.x = x.data(); d.data = data.data.data(); d.memspace = NDI_MEM_HOST;
@@ -307,27 +360,6 @@ class Linear : public Interp1DStrategyBuilder<T> {
   }
 };
 
-// boundary conditions (cubic_spline.rs:153-217)
-struct SingleBoundary {
-  int kind = NDI_BC_NOT_A_KNOT;
-  double value = 0.0;
-  static SingleBoundary NotAKnot() { return {NDI_BC_NOT_A_KNOT, 0.0}; }
-  static SingleBoundary Natural() { return {NDI_BC_NATURAL, 0.0}; }
-  static SingleBoundary Clamped() { return {NDI_BC_CLAMPED, 0.0}; }
-  static SingleBoundary FirstDeriv(double v) { return {NDI_BC_FIRST_DERIV, v}; }
-  static SingleBoundary SecondDeriv(double v) { return {NDI_BC_SECOND_DERIV, v}; }
-};
-struct BoundaryCondition {
-  bool periodic = false;
-  SingleBoundary left, right;
-  static BoundaryCondition NotAKnot() { return {false, SingleBoundary::NotAKnot(), SingleBoundary::NotAKnot()}; }
-  static BoundaryCondition Natural() { return {false, SingleBoundary::Natural(), SingleBoundary::Natural()}; }
-  static BoundaryCondition Clamped() { return {false, SingleBoundary::Clamped(), SingleBoundary::Clamped()}; }
-  static BoundaryCondition Periodic() { return {true, {}, {}}; }
-  // RowBoundary::Mixed applied to the whole dataset
-  static BoundaryCondition Mixed(SingleBoundary l, SingleBoundary r) { return {false, l, r}; }
-};
-
 template <class T>
 class CubicSpline : public Interp1DStrategyBuilder<T> {  // cubic_spline.rs:85-88, 723-771
   bool extrapolate_ = false;
@@ -341,6 +373,16 @@ class CubicSpline : public Interp1DStrategyBuilder<T> {  // cubic_spline.rs:85-8
     static_assert(std::is_same_v<T, float> || std::is_same_v<T, double>,
                   "CubicSpline needs a float element type (the reference's trait bounds: Pow / Euclid on T)");
     auto s = std::make_shared<detail::Device1D<T>>();
+    if (!boundary_.rows.empty() || !boundary_.rows_shape.empty()) {   // Individual: shape [1, data.shape[1..]] (:332-340)
+      std::vector<size_t> expect{1};
+      expect.insert(expect.end(), data.shape.begin() + 1, data.shape.end());
+      if (boundary_.rows_shape != expect || boundary_.rows.size() != detail::prod(expect))
+        throw BuilderError(BuilderError::ShapeError, "Boundary conditions array has wrong shape. Expected: " +
+                                                         detail::shape_str(expect) + ", got: " +
+                                                         detail::shape_str(boundary_.rows_shape));
+      s->create(x, data, NDI_CUBIC_SPLINE, extrapolate_, false, {0, 0.0}, {0, 0.0}, 0, &boundary_.rows);
+      return s;
+    }
     s->create(x, data, NDI_CUBIC_SPLINE, extrapolate_, boundary_.periodic,
               {boundary_.left.kind, boundary_.left.value}, {boundary_.right.kind, boundary_.right.value}, 0);
     return s;

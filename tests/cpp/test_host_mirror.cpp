@@ -2,6 +2,8 @@
 // way the reference's own tests drive the crate (tests/interp1d.rs, tests/interp2d.rs,
 // tests/cubic_spline_strat.rs, examples/custom_strategy.rs).  `--host-only` runs the cases that need no GPU
 // (builder validation); without it the device cases run too.  Exit code = number of failed checks.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -219,6 +221,27 @@ static void device() {
     std::vector<double> lq{-1.0, xk[0], xk[7], 0.5 * (xk[7] + xk[8]), xk[n - 1], 100.0};
     CHECK(loc.get_lower_index(lq) == get_lower_index<double>(xk, lq));
     CHECK((loc.get_lower_index(lq) == std::vector<int64_t>{0, 0, 7, 7, (int64_t)n - 2, (int64_t)n - 2}));
+  }
+  {  // tests/cubic_spline_strat.rs:191-255 multidim_multi_bounds: BoundaryCondition::Individual, non-uniform x
+    Array<double> y({3, 2}, std::vector<double>{0.5, 1.0, 0.0, 1.5, 3.0, 0.5});
+    auto bc = BoundaryCondition::Individual({1, 2}, {RowBoundary::Natural(),
+                                                     RowBoundary::Mixed(SingleBoundary::NotAKnot(), SingleBoundary::FirstDeriv(0.5))});
+    auto ip = Interp1DBuilder<double>::new_(y).x({-1.0, 0.0, 3.0})
+                  .strategy(CubicSpline<double>::new_().boundary(bc).extrapolate(true)).build();
+    auto r = ip.interp_array(Array<double>::linspace(-2.0, 4.0, 15));
+    const double e0[15] = {1., 0.85787172, 0.59766764, 0.30794461, 0.07725948, -0.00655977, 0.10058309, 0.375,
+                           0.78717201, 1.30758017, 1.90670554, 2.55502915, 3.22303207, 3.88119534, 4.5};
+    const double e1[15] = {-1.13194444, 0.02834467, 0.81235828, 1.27749433, 1.48115079, 1.48072562, 1.33361678,
+                           1.09722222, 0.82893991, 0.5861678, 0.42630385, 0.40674603, 0.58489229, 1.01814059, 1.76388889};
+    for (int i = 0; i < 15; ++i) {
+      CHECK(std::fabs(r[2 * i] - e0[i]) <= 1e-3 * std::max(std::fabs(e0[i]), std::fabs(r[2 * i])) + EPS);
+      CHECK(std::fabs(r[2 * i + 1] - e1[i]) <= 1e-3 * std::max(std::fabs(e1[i]), std::fabs(r[2 * i + 1])) + EPS);
+    }
+    // wrong shape of the boundary array: tests/cubic_spline_strat.rs:413-440
+    CHECK(throws<BuilderError>([&] {
+      Interp1DBuilder<double>::new_(y).strategy(CubicSpline<double>::new_().boundary(BoundaryCondition::Individual(
+          {1, 3}, {RowBoundary::Natural(), RowBoundary::Clamped(), RowBoundary::NotAKnot()}))).build(); },
+      BuilderError::ShapeError));
   }
   {  // f32 is a first-class type (tests/cubic_spline_strat.rs:108-154)
     Array<float> d = Array<float>::from_vec({1.f, 2.f, 2.5f, 2.5f, 3.f, 2.f, 1.f, -2.f, 3.f, 5.f, 6.3f, 8.f});

@@ -617,13 +617,43 @@ class Interp2D {  // interp2d/mod.rs:36-48
     strategy->interp_into(*this, t.data.data(), xv, yv);
     return t;
   }
+  void interp_into(T xv, T yv, Array<T>& buffer) const {  // :150-167; panics on a wrong buffer shape
+    if (buffer.shape != lanes_shape())
+      throw Panic("incompatible shapes expected: " + detail::shape_str(lanes_shape()) + ", got: " +
+                  detail::shape_str(buffer.shape));
+    strategy->interp_into(*this, buffer.data.data(), xv, yv);
+  }
+  // (x knot, y knot, pointer to the lanes of the grid point) -- interp2d/mod.rs:348-364
+  struct Point { T x, y; const T* data; };
+  Point index_point(size_t x_idx, size_t y_idx) const {
+    return {x.at(x_idx), y.at(y_idx), data.data.data() + (x_idx * data.shape[1] + y_idx) * lanes()};
+  }
+  std::pair<size_t, size_t> get_index_left_of(T xv, T yv) const {  // :370-372
+    auto one = [](const std::vector<T>& k, T v) {
+      auto r = get_lower_index<T>(k, {v});
+      if (r[0] < 0) throw Panic("not implemented: failed to convert NaN to usize");
+      return (size_t)r[0];
+    };
+    return {one(x, xv), one(y, yv)};
+  }
+  std::vector<size_t> get_buffer_shape(const std::vector<size_t>& dq) const {  // :310-321
+    std::vector<size_t> s = dq;
+    s.insert(s.end(), data.shape.begin() + 2, data.shape.end());
+    return s;
+  }
   Array<T> interp_array(const Array<T>& xs, const Array<T>& ys) const {  // :175-196
     if (xs.shape != ys.shape) throw Panic("`xs.shape()` and `ys.shape()` do not match");
-    std::vector<size_t> s = xs.shape;
-    s.insert(s.end(), data.shape.begin() + 2, data.shape.end());
-    Array<T> zs(s);
-    strategy->interp_array_into(*this, xs.data.data(), ys.data.data(), xs.len(), zs.data.data(), lanes());
+    Array<T> zs(get_buffer_shape(xs.shape));
+    interp_array_into(xs, ys, zs);
     return zs;
+  }
+  void interp_array_into(const Array<T>& xs, const Array<T>& ys, Array<T>& buffer) const {  // :215-285
+    if (xs.shape != ys.shape) throw Panic("`xs.shape()` and `ys.shape()` do not match");
+    const auto expect = get_buffer_shape(xs.shape);
+    if (buffer.shape != expect)
+      throw Panic("incompatible shapes expected: " + detail::shape_str(expect) + ", got: " +
+                  detail::shape_str(buffer.shape));
+    strategy->interp_array_into(*this, xs.data.data(), ys.data.data(), xs.len(), buffer.data.data(), lanes());
   }
 };
 

@@ -184,6 +184,19 @@ static void device() {
     try { ip2.interp(1.0, -1.0); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.axis == 1); }
     try { ip2.interp(3.0, 9.0); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.axis == 0); }
     CHECK(throws<Panic>([&] { ip2.interp_array(arr({0.0, 1.0}), arr({0.0, 1.0, 2.0})); }));
+    {  // inherent helpers of Interp2D (interp2d/mod.rs:150-167, 215-285, 348-372)
+      auto pt = ip.index_point(1, 2);
+      CHECK(pt.x == 1.0 && pt.y == -1.0 && pt.data[0] == 7.0);
+      CHECK((ip.get_index_left_of(1.5, -2.5) == std::pair<size_t, size_t>{1, 0}));
+      Array<double> one(std::vector<size_t>{}), wrong({2});
+      ip.interp_into(2.0, 0.0, one);
+      CHECK(one[0] == 12.0);
+      CHECK(throws<Panic>([&] { ip.interp_into(2.0, 0.0, wrong); }));
+      Array<double> buf({2}), bad({3});
+      ip2.interp_array_into(arr({0.0, 2.0}), arr({0.0, 3.0}), buf);
+      CHECK(buf[0] == 1.0 && buf[1] == 12.0);
+      CHECK(throws<Panic>([&] { ip2.interp_array_into(arr({0.0, 2.0}), arr({0.0, 3.0}), bad); }));
+    }
     Array<double> nd({2, 2, 2, 2}, std::vector<double>{1, 10, -1, -10, 2, 20, -2, -20, 3, 30, -3, -30, 5, 50, -5, -50});
     auto ip3 = Interp2DBuilder<double>::new_(nd).build();
     auto r = ip3.interp_array(arr({0.0, 0.5}), arr({0.5, 1.0}));

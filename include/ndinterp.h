@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define NDI_VERSION_MAJOR 0
-#define NDI_VERSION_MINOR 2
+#define NDI_VERSION_MINOR 3
 
 /* BuilderError / InterpolateError (src/lib.rs:127-146) + ABI-only codes. */
 typedef enum ndi_status {
@@ -209,7 +209,11 @@ ndi_status ndi_interp2d_finish(const ndi_interp2d* h, void* stream, ndi_oob_info
  * First-error semantics are the reference's: a range pre-pass over all queries finds the lowest failing flat
  * index F before any chunk is produced; exactly the rows [0, F) are produced (the last chunk is cut short),
  * then NDI_OUT_OF_BOUNDS / NDI_NAN_QUERY is returned with info filled in.  The call returns after the last
- * chunk's kernels (and the consumer's stream-ordered work) have completed. */
+ * chunk's kernels (and the consumer's stream-ordered work) have completed.
+ *
+ * Internally the producer is a two-stream pipeline: the search + grouping of chunk k+1 run on a side stream the
+ * handle owns while chunk k is evaluated on opts->stream (event-ordered; two scratch sets).  Everything the
+ * consumer can observe -- the chunk's rows and chunk->stream -- is on opts->stream. */
 typedef struct ndi_ring_chunk {
   uint64_t index;      /* chunk number, 0, 1, ... */
   uint64_t q_begin;    /* flat index of the chunk's first query */
@@ -217,7 +221,7 @@ typedef struct ndi_ring_chunk {
   void* out;           /* device pointer, T[q_count][row_stride] */
   uint64_t row_stride; /* elements */
   uint32_t slot;       /* ring slot the chunk lives in */
-  uint32_t reserved;
+  uint32_t shard;      /* sharded evaluation: index of the handle (device) that produced the chunk; else 0 */
   void* stream;        /* hipStream_t the chunk's kernels were enqueued on */
 } ndi_ring_chunk;
 
@@ -245,6 +249,58 @@ ndi_status ndi_interp1d_eval_ring(const ndi_interp1d* h, const void* q, uint64_t
 ndi_status ndi_interp2d_eval_ring(const ndi_interp2d* h, const void* qx, const void* qy, uint64_t nq,
                                   const ndi_ring_desc* ring, ndi_ring_consumer consume, void* user,
                                   const ndi_eval_opts* opts, ndi_oob_info* info);
+
+/* ---- sharded evaluation: one call, several devices -------------------------------------------------
+ * The reference is single-threaded; its multi-worker shape is one interpolator driven from many threads over
+ * contiguous blocks of the query array (benches/bench_interp1d.rs:49-79; rayon support "planned", README.md:16-18).
+ * These calls are that shape below the host language: `handles` are n_shards replicas of one interpolator (same
+ * knots / data / strategy; normally one per device, built with ndi_interp{1,2}d_create and desc.device = d), the
+ * flattened query array is split into contiguous blocks -- shard i owns [lo_i, hi_i) = ndi_shard_bounds(nq, i,
+ * n_shards), block sizes differ by at most one -- and every shard is evaluated by its own host thread on its
+ * handle's device (shard 0 on the calling thread).  No device-to-device traffic, no collective.
+ *
+ * First-error semantics are the reference's serial loop (src/interp1d/mod.rs:326-343, src/interp2d/mod.rs:287-307)
+ * over the WHOLE batch: every shard range-checks its block first, the shards agree on the minimum failing flat
+ * index F at a host barrier, and exactly the rows [0, F) are produced -- rows at or after F are never written, in
+ * any shard.  info->index is the global flat index.
+ *
+ * ndi_shard_io (one per shard):
+ *   q / qy  NULL: the shard reads its block of the flattened q (qx, qy) -- these are then host arrays or memory
+ *           every device can read; non-NULL: the shard's own block (hi_i - lo_i queries), e.g. already resident on
+ *           the shard's device.  Memory space of either form: opts->q_memspace.
+ *   out     the shard's rows, T[hi_i - lo_i][out_row_stride], memory space opts->out_memspace (device pointers
+ *           belong to the shard's device).  For one host output array: out = base + lo_i * out_row_stride.
+ *   stream  hipStream_t on the shard's device (NULL = its default stream); opts->stream is ignored.
+ * The handles must be distinct.  opts->async_launch is ignored (the call returns when every shard has finished). */
+typedef struct ndi_shard_io {
+  const void* q;
+  const void* qy;
+  void* out;
+  void* stream;
+} ndi_shard_io;
+
+void ndi_shard_bounds(uint64_t nq, uint32_t shard, uint32_t n_shards, uint64_t* lo, uint64_t* hi);
+
+ndi_status ndi_interp1d_eval_sharded(const ndi_interp1d* const* handles, uint32_t n_shards, const void* q,
+                                     uint64_t nq, const ndi_shard_io* io, uint64_t out_row_stride,
+                                     const ndi_eval_opts* opts, ndi_oob_info* info);
+ndi_status ndi_interp2d_eval_sharded(const ndi_interp2d* const* handles, uint32_t n_shards, const void* qx,
+                                     const void* qy, uint64_t nq, const ndi_shard_io* io, uint64_t out_row_stride,
+                                     const ndi_eval_opts* opts, ndi_oob_info* info);
+
+/* The same through one device-output ring per shard (rings[i] on handles[i]'s device; slots == NULL: the handle
+ * owns it): what ndi_interp{1,2}d_eval_ring is to one device.  `io` may be NULL (out is unused).  `consume` is
+ * called from the shards' host threads CONCURRENTLY (once per chunk, in order within a shard); chunk->shard names
+ * the shard, chunk->q_begin is the global flat index of the chunk's first query, chunk->index counts within the
+ * shard.  Exactly the rows [0, F) are handed out. */
+ndi_status ndi_interp1d_eval_ring_sharded(const ndi_interp1d* const* handles, uint32_t n_shards, const void* q,
+                                          uint64_t nq, const ndi_shard_io* io, const ndi_ring_desc* rings,
+                                          ndi_ring_consumer consume, void* user, const ndi_eval_opts* opts,
+                                          ndi_oob_info* info);
+ndi_status ndi_interp2d_eval_ring_sharded(const ndi_interp2d* const* handles, uint32_t n_shards, const void* qx,
+                                          const void* qy, uint64_t nq, const ndi_shard_io* io,
+                                          const ndi_ring_desc* rings, ndi_ring_consumer consume, void* user,
+                                          const ndi_eval_opts* opts, ndi_oob_info* info);
 
 /* Per-(stream, host thread) scratch is cached on the handle (at most 16 idle sets are kept; the least recently
  * used idle set is freed beyond that).  trim frees every idle set and a library-owned ring now. */

@@ -66,12 +66,16 @@ class Profile(C.Structure):
 
 class RingChunk(C.Structure):
     _fields_ = [("index", C.c_uint64), ("q_begin", C.c_uint64), ("q_count", C.c_uint64), ("out", C.c_void_p),
-                ("row_stride", C.c_uint64), ("slot", C.c_uint32), ("reserved", C.c_uint32), ("stream", C.c_void_p)]
+                ("row_stride", C.c_uint64), ("slot", C.c_uint32), ("shard", C.c_uint32), ("stream", C.c_void_p)]
 
 
 class RingDesc(C.Structure):
     _fields_ = [("slots", C.POINTER(C.c_void_p)), ("n_slots", C.c_uint32), ("reserved", C.c_uint32),
                 ("chunk_queries", C.c_uint64), ("row_stride", C.c_uint64)]
+
+
+class ShardIO(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("qy", C.c_void_p), ("out", C.c_void_p), ("stream", C.c_void_p)]
 
 
 RING_CONSUMER = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(RingChunk))
@@ -92,6 +96,17 @@ SYMBOLS = {
                                          C.POINTER(EvalOpts), C.POINTER(OobInfo)]),
     "ndi_interp2d_eval_ring": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(RingDesc), RING_CONSUMER, _P,
                                          C.POINTER(EvalOpts), C.POINTER(OobInfo)]),
+    "ndi_shard_bounds": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ndi_interp1d_eval_sharded": (C.c_int, [C.POINTER(_P), C.c_uint32, _P, C.c_uint64, C.POINTER(ShardIO), C.c_uint64,
+                                            C.POINTER(EvalOpts), C.POINTER(OobInfo)]),
+    "ndi_interp2d_eval_sharded": (C.c_int, [C.POINTER(_P), C.c_uint32, _P, _P, C.c_uint64, C.POINTER(ShardIO),
+                                            C.c_uint64, C.POINTER(EvalOpts), C.POINTER(OobInfo)]),
+    "ndi_interp1d_eval_ring_sharded": (C.c_int, [C.POINTER(_P), C.c_uint32, _P, C.c_uint64, C.POINTER(ShardIO),
+                                                 C.POINTER(RingDesc), RING_CONSUMER, _P, C.POINTER(EvalOpts),
+                                                 C.POINTER(OobInfo)]),
+    "ndi_interp2d_eval_ring_sharded": (C.c_int, [C.POINTER(_P), C.c_uint32, _P, _P, C.c_uint64, C.POINTER(ShardIO),
+                                                 C.POINTER(RingDesc), RING_CONSUMER, _P, C.POINTER(EvalOpts),
+                                                 C.POINTER(OobInfo)]),
     "ndi_interp1d_trim": (C.c_int, [_P]),
     "ndi_interp2d_trim": (C.c_int, [_P]),
     "ndi_interp1d_scratch_sets": (C.c_uint64, [_P]),

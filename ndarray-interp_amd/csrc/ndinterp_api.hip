@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -268,11 +269,33 @@ constexpr size_t LDS_STAGE_LIMIT = 150 * 1024;          // of the CU's 160 KiB
 // ---------------------------------------------------------------------------------------------
 // workspace: per (handle, stream) scratch, reused across stream-ordered evaluations
 // ---------------------------------------------------------------------------------------------
+// One set of per-chunk scratch: what the locate / group kernels of a chunk write and its evaluation reads.  A
+// workspace carries two, so that the ring evaluation can locate + group chunk k+1 on a side stream while chunk k is
+// being evaluated (the set is handed back by the eval_done event).
+struct Scratch {
+  DevBuf idx, idx2, t, perm, counts, cursor, hist, status, recq;
+  hipEvent_t prep_done = nullptr, eval_done = nullptr;
+  Scratch() = default;
+  Scratch(const Scratch&) = delete;
+  Scratch& operator=(const Scratch&) = delete;
+  ~Scratch() {
+    if (prep_done) (void)hipEventDestroy(prep_done);
+    if (eval_done) (void)hipEventDestroy(eval_done);
+  }
+  void ensure_events() {
+    if (!prep_done) NDI_HIP(hipEventCreateWithFlags(&prep_done, hipEventDisableTiming));
+    if (!eval_done) NDI_HIP(hipEventCreateWithFlags(&eval_done, hipEventDisableTiming));
+  }
+};
+
 struct Workspace {
-  DevBuf idx, idx2, t, perm, counts, cursor, hist, status, qdev, qdev2, stage[2];
+  Scratch sc[2];
+  DevBuf status, qdev, qdev2, stage;   // status: the range pre-pass of the ring / sharded evaluations
   StatusBlock* host_status = nullptr;  // pinned
   void* pin = nullptr;                 // pinned bounce buffer of the small-batch host path
   size_t pin_bytes = 0;
+  hipStream_t side = nullptr;          // ring evaluation: locate + group of the next chunk run here
+  hipEvent_t ev = nullptr;             // general-purpose ordering event (timing disabled)
   // record of the last batch (for finish())
   uint64_t last_nq = 0;
   const void* last_q = nullptr;
@@ -283,6 +306,8 @@ struct Workspace {
   int users = 0;
   uint64_t last_use = 0;
   ~Workspace() {
+    if (side) (void)hipStreamDestroy(side);   // waits for the stream's work
+    if (ev) (void)hipEventDestroy(ev);
     if (host_status) (void)hipHostFree(host_status);
     if (pin) (void)hipHostFree(pin);
   }
@@ -296,7 +321,16 @@ struct Workspace {
   }
   void ensure_status() {
     status.reserve(sizeof(StatusBlock));
+    for (Scratch& s : sc) s.status.reserve(sizeof(StatusBlock));
     if (!host_status) NDI_HIP(hipHostMalloc((void**)&host_status, sizeof(StatusBlock), hipHostMallocDefault));
+  }
+  hipStream_t side_stream() {
+    if (!side) NDI_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    return side;
+  }
+  hipEvent_t order_event() {
+    if (!ev) NDI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return ev;
   }
 };
 
@@ -377,11 +411,10 @@ static void launch1(hipStream_t s, int cat, dim3 grid, dim3 block, size_t shmem,
   ps.done();
 }
 
-static void reset_status(Workspace& ws, hipStream_t s) {
-  ws.ensure_status();
+static void reset_status(void* status, hipStream_t s) {
   // first_fail[0..1] = NO_FAIL (all ones), the rest zero
-  NDI_HIP(hipMemsetAsync(ws.status.p, 0xFF, 2 * sizeof(unsigned long long), s));
-  NDI_HIP(hipMemsetAsync((char*)ws.status.p + 2 * sizeof(unsigned long long), 0,
+  NDI_HIP(hipMemsetAsync(status, 0xFF, 2 * sizeof(unsigned long long), s));
+  NDI_HIP(hipMemsetAsync((char*)status + 2 * sizeof(unsigned long long), 0,
                          sizeof(StatusBlock) - 2 * sizeof(unsigned long long), s));
 }
 
@@ -478,12 +511,25 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+static ndi_status check_ring_desc(const ndi_ring_desc* ring, uint64_t lanes, uint64_t* stride) {
+  if (!ring || ring->n_slots == 0 || ring->chunk_queries == 0)
+    return fail(NDI_BAD_ARG, "ring needs n_slots >= 1 and chunk_queries >= 1");
+  *stride = ring->row_stride ? ring->row_stride : lanes;
+  if (*stride < lanes) return fail(NDI_BAD_ARG, "ring row_stride (%llu) < lanes (%llu)",
+                                   (unsigned long long)*stride, (unsigned long long)lanes);
+  if (ring->slots)
+    for (uint32_t i = 0; i < ring->n_slots; ++i)
+      if (!ring->slots[i]) return fail(NDI_BAD_ARG, "ring slot %u is null", i);
+  return NDI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Interp1D
 // ---------------------------------------------------------------------------------------------
 struct Interp1DBase {
   virtual ~Interp1DBase() = default;
   int dtype = 0, device = 0;
+  uint64_t lanes = 0;
   virtual ndi_status eval(const void* q, uint64_t nq, void* out, uint64_t out_stride,
                           const ndi_eval_opts* opts, ndi_oob_info* info) = 0;
   virtual ndi_status finish(void* stream, ndi_oob_info* info) = 0;
@@ -498,7 +544,7 @@ template <class T>
 struct Interp1DImpl final : Interp1DBase {
   int strategy = NDI_LINEAR;
   int mode = EX_NO;
-  uint64_t n = 0, lanes = 0;
+  uint64_t n = 0;
   DevicePyramid<T> pyr;
   DevBuf data, ca, cb;
   SpaceSet spaces;
@@ -668,40 +714,103 @@ struct Interp1DImpl final : Interp1DBase {
   }
 
   // ---- evaluation core on device pointers --------------------------------------------------
-  void enqueue(hipStream_t s, Workspace& ws, const T* q, uint64_t nq, T* out, uint64_t out_stride,
-               int path) {
-    ws.idx.reserve(nq * sizeof(uint32_t));
-    if (strategy == NDI_CUBIC_SPLINE) ws.t.reserve(nq * sizeof(T));
-    reset_status(ws, s);
-    StatusBlock* st = ws.status.as<StatusBlock>();
+  // A batch is evaluated in two stages that may run on different streams: prep() = search (+ grouping) into a
+  // scratch set, launch_eval() = the evaluation kernel reading that set.  Plan1 carries what prep() decided.
+  struct Plan1 {
+    enum Kind { SMALL, BUCKETED, ROWS, FLAT } kind = ROWS;
+    const T* q = nullptr;
+    uint64_t nq = 0;
+    T* out = nullptr;
+    uint64_t out_stride = 0;
+    bool vec_ok = false;
+    uint64_t LV = 0;
+  };
 
-    Eval1Args<T> A{};
-    A.knots = pyr.view.lv0;
-    A.data = data.as<T>();
-    A.ca = ca.as<T>();
-    A.cb = cb.as<T>();
-    A.q = q;
-    A.idx = ws.idx.as<uint32_t>();
-    A.t = ws.t.as<T>();
-    A.out = out;
-    A.lanes = lanes;
-    A.out_stride = out_stride;
-    A.nq = nq;
-    A.status = st;
+  Plan1 prep(hipStream_t s, Scratch& sc, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path) {
+    Plan1 P;
+    P.q = q; P.nq = nq; P.out = out; P.out_stride = out_stride;
+    sc.idx.reserve(nq * sizeof(uint32_t));
+    if (strategy == NDI_CUBIC_SPLINE) sc.t.reserve(nq * sizeof(T));
+    sc.status.reserve(sizeof(StatusBlock));
+    reset_status(sc.status.p, s);
+    StatusBlock* st = sc.status.as<StatusBlock>();
 
     if (lanes <= 2 && pyr.lds_bytes <= LDS_STAGE_LIMIT) {   // one thread per query only pays for 1-2 lanes
       // short trailing axes: range pre-check (so rows after the first failing query stay untouched in the
       // caller's buffer), then search + evaluation fused in one launch -- no index / t round trip through HBM
+      P.kind = Plan1::SMALL;
       g_last_path.store(NDI_PATH_GATHER);
       const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
       const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
-      {
-        ProfScope ps(s, PC_LOCATE);
-        hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, q, (const T*)nullptr, nq, k0, kn, k0, kn,
-                           mode, &st->first_fail[0]);
+      ProfScope ps(s, PC_LOCATE);
+      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, q, (const T*)nullptr, nq, k0, kn, k0, kn,
+                         mode, &st->first_fail[0]);
+      NDI_HIP(hipGetLastError());
+      ps.done();
+      return P;
+    }
+    constexpr int VN = Wide<T>::N;
+    P.vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
+    P.LV = P.vec_ok ? lanes / VN : lanes;
+    const bool rows_ok = P.vec_ok && P.LV >= (uint64_t)BLOCK;
+    bool bucketed = false;
+    if (path == NDI_PATH_BUCKETED) bucketed = rows_ok && nq < 0xffffffffull;
+    else if (path == NDI_PATH_AUTO) bucketed = rows_ok && nq < 0xffffffffull && nq >= 5 * (n - 1);  // measured crossover (tools/auto_threshold.py)
+    g_last_path.store(bucketed ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
+    T* t_out = strategy == NDI_CUBIC_SPLINE ? sc.t.as<T>() : nullptr;
+
+    if (bucketed) {
+      P.kind = Plan1::BUCKETED;
+      const uint32_t nb = (uint32_t)(n - 1);
+      sc.counts.reserve((size_t)nb * sizeof(uint32_t));
+      sc.cursor.reserve((size_t)nb * sizeof(uint32_t));
+      sc.perm.reserve(nq * sizeof(uint4));
+      const T* sval = strategy == NDI_CUBIC_SPLINE ? (const T*)sc.t.as<T>() : q;   // t (cubic) / raw x (linear)
+      if (lds_sort_fits(pyr, nb)) {
+        // block-local counting sort: histogram per query slice in LDS, no global atomics
+        sc.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
+        uint64_t slice = 0;
+        uint32_t blocks = 0;
+        run_locate<T>(s, pyr, q, nq, sc.idx.as<uint32_t>(), nullptr, t_out,
+                      &st->first_fail[0], mode, sc.hist.as<uint32_t>(), nb, &slice, &blocks);
+        ProfScope ps(s, PC_GROUP);
+        hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
+                           sc.hist.as<uint32_t>(), blocks, nb, sc.counts.as<uint32_t>());
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, sc.counts.as<uint32_t>(), nb,
+                           sc.cursor.as<uint32_t>(), st);
+        allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter_kernel<T>), (int)(GROUP_MAX_BINS * 4));
+        hipLaunchKernelGGL(group_scatter_kernel<T>, dim3(blocks), dim3(BLOCK), (size_t)nb * 4, s,
+                           (const uint32_t*)sc.idx.as<uint32_t>(), sval, nq, slice,
+                           (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(),
+                           nb, sc.perm.as<uint4>());
+        NDI_HIP(hipGetLastError());
+        ps.done();
+      } else {
+        // many intervals: histogram and placement with global atomics
+        run_locate<T>(s, pyr, q, nq, sc.idx.as<uint32_t>(), nullptr, t_out, &st->first_fail[0], mode);
+        ProfScope ps(s, PC_GROUP);
+        NDI_HIP(hipMemsetAsync(sc.counts.p, 0, (size_t)nb * sizeof(uint32_t), s));
+        const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 2048));
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(BLOCK), 0, s, (const uint32_t*)sc.idx.as<uint32_t>(), nq,
+                           (const StatusBlock*)st, sc.counts.as<uint32_t>());
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, sc.counts.as<uint32_t>(), nb,
+                           sc.cursor.as<uint32_t>(), st);
+        hipLaunchKernelGGL(bucket_scatter_kernel<T>, dim3(g), dim3(BLOCK), 0, s, (const uint32_t*)sc.idx.as<uint32_t>(),
+                           sval, nq, (const StatusBlock*)st, sc.cursor.as<uint32_t>(), sc.perm.as<uint4>());
         NDI_HIP(hipGetLastError());
         ps.done();
       }
+      return P;
+    }
+    run_locate<T>(s, pyr, q, nq, sc.idx.as<uint32_t>(), nullptr, t_out, &st->first_fail[0], mode);
+    P.kind = rows_ok ? Plan1::ROWS : Plan1::FLAT;
+    return P;
+  }
+
+  void launch_eval(hipStream_t s, Scratch& sc, const Plan1& P) {
+    StatusBlock* st = sc.status.as<StatusBlock>();
+    const uint64_t nq = P.nq;
+    if (P.kind == Plan1::SMALL) {
       allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>), (int)LDS_STAGE_LIMIT);
       allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>), (int)LDS_STAGE_LIMIT);
       EvalSmallArgs<T> S{};
@@ -709,77 +818,47 @@ struct Interp1DImpl final : Interp1DBase {
       S.data = data.as<T>();
       S.ca = ca.as<T>();
       S.cb = cb.as<T>();
-      S.q = q;
-      S.out = out;
+      S.q = P.q;
+      S.out = P.out;
       S.nq = nq;
-      S.out_stride = out_stride;
+      S.out_stride = P.out_stride;
       S.lanes = (uint32_t)lanes;
       S.mode = mode;
       S.first_fail = &st->first_fail[0];
       S.prechecked = 1;
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
       const size_t shmem = (pyr.lds_bytes + 15) & ~(size_t)15;
       if (strategy == NDI_CUBIC_SPLINE) launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), shmem, eval_small_kernel<T, ST_CUBIC>, S);
       else launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), shmem, eval_small_kernel<T, ST_LINEAR>, S);
       return;
     }
+    Eval1Args<T> A{};
+    A.knots = pyr.view.lv0;
+    A.data = data.as<T>();
+    A.ca = ca.as<T>();
+    A.cb = cb.as<T>();
+    A.q = P.q;
+    A.idx = sc.idx.as<uint32_t>();
+    A.t = sc.t.as<T>();
+    A.out = P.out;
+    A.lanes = lanes;
+    A.out_stride = P.out_stride;
+    A.nq = nq;
+    A.status = st;
     constexpr int VN = Wide<T>::N;
-    const bool vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
-    const uint64_t LV = vec_ok ? lanes / VN : lanes;
-    const bool rows_ok = vec_ok && LV >= (uint64_t)BLOCK;
-    bool bucketed = false;
-    if (path == NDI_PATH_BUCKETED) bucketed = rows_ok && nq < 0xffffffffull;
-    else if (path == NDI_PATH_AUTO) bucketed = rows_ok && nq < 0xffffffffull && nq >= 5 * (n - 1);  // measured crossover (tools/auto_threshold.py)
-    g_last_path.store(bucketed ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
-    T* t_out = strategy == NDI_CUBIC_SPLINE ? ws.t.as<T>() : nullptr;
-
-    if (bucketed) {
-      const uint32_t nb = (uint32_t)(n - 1);
-      ws.counts.reserve((size_t)nb * sizeof(uint32_t));
-      ws.cursor.reserve((size_t)nb * sizeof(uint32_t));
-      ws.perm.reserve(nq * sizeof(uint4));
-      A.rec = ws.perm.as<uint4>();
-      const T* sval = strategy == NDI_CUBIC_SPLINE ? (const T*)ws.t.as<T>() : q;   // t (cubic) / raw x (linear)
-      if (lds_sort_fits(pyr, nb)) {
-        // block-local counting sort: histogram per query slice in LDS, no global atomics
-        ws.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
-        uint64_t slice = 0;
-        uint32_t blocks = 0;
-        run_locate<T>(s, pyr, q, nq, ws.idx.as<uint32_t>(), nullptr, t_out,
-                      &st->first_fail[0], mode, ws.hist.as<uint32_t>(), nb, &slice, &blocks);
-        ProfScope ps(s, PC_GROUP);
-        hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
-                           ws.hist.as<uint32_t>(), blocks, nb, ws.counts.as<uint32_t>());
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
-                           ws.cursor.as<uint32_t>(), st);
-        allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter_kernel<T>), (int)(GROUP_MAX_BINS * 4));
-        hipLaunchKernelGGL(group_scatter_kernel<T>, dim3(blocks), dim3(BLOCK), (size_t)nb * 4, s,
-                           (const uint32_t*)ws.idx.as<uint32_t>(), sval, nq, slice,
-                           (const uint32_t*)ws.hist.as<uint32_t>(), (const uint32_t*)ws.cursor.as<uint32_t>(),
-                           nb, ws.perm.as<uint4>());
-        NDI_HIP(hipGetLastError());
-        ps.done();
-      } else {
-        // many intervals: histogram and placement with global atomics
-        run_locate<T>(s, pyr, q, nq, ws.idx.as<uint32_t>(), nullptr, t_out, &st->first_fail[0], mode);
-        ProfScope ps(s, PC_GROUP);
-        NDI_HIP(hipMemsetAsync(ws.counts.p, 0, (size_t)nb * sizeof(uint32_t), s));
-        const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 2048));
-        hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(BLOCK), 0, s, A.idx, nq, st,
-                           ws.counts.as<uint32_t>());
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
-                           ws.cursor.as<uint32_t>(), st);
-        hipLaunchKernelGGL(bucket_scatter_kernel<T>, dim3(g), dim3(BLOCK), 0, s, A.idx, sval, nq, st,
-                           ws.cursor.as<uint32_t>(), ws.perm.as<uint4>());
-        NDI_HIP(hipGetLastError());
-        ps.done();
-      }
+    const uint64_t LV = P.LV;
+    if (P.kind == Plan1::BUCKETED) {
+      A.rec = sc.perm.as<uint4>();
       constexpr int CQ = 128;
       const int U = LV >= 2048 ? 8 : (LV >= 1024 ? 4 : (LV >= 512 ? 2 : 1));
       const uint64_t segs = (LV + (uint64_t)BLOCK * U - 1) / ((uint64_t)BLOCK * U);
       // a multiple of 8 so that a workgroup keeps its XCD residue when it strides (XCD-aware chunk order);
       // every workgroup takes a run of consecutive chunks (operand rows stay in registers across them)
-      const char* run_e = std::getenv("NDI_BUCKETED_RUN");   // tuning knob (tools/sweep_target.py)
-      const uint32_t run_env = run_e ? (uint32_t)std::atoi(run_e) : 0u;
+      static const uint32_t run_env = [] {   // tuning knob (tools/sweep_target.py), read once
+        const char* e = std::getenv("NDI_BUCKETED_RUN");
+        const int v = e ? std::atoi(e) : 0;
+        return (uint32_t)(v > 0 && v <= 4096 ? v : 0);
+      }();
       const uint64_t per_xcd = ((nq + CQ - 1) / CQ + 7) / 8;
       A.run = run_env ? run_env : BUCKETED_RUN;
       const uint64_t runs_per_xcd = (per_xcd + A.run - 1) / A.run;
@@ -801,8 +880,7 @@ struct Interp1DImpl final : Interp1DBase {
 #undef NDI_BK
       return;
     }
-    run_locate<T>(s, pyr, q, nq, ws.idx.as<uint32_t>(), nullptr, t_out, &st->first_fail[0], mode);
-    if (rows_ok) {
+    if (P.kind == Plan1::ROWS) {
       // one 256-vector segment per workgroup pass and many workgroups: measured best on MI355X
       const uint64_t segs = (LV + BLOCK - 1) / BLOCK;
       const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nq, 65536));
@@ -817,33 +895,39 @@ struct Interp1DImpl final : Interp1DBase {
     const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 16384));
     ProfScope ps(s, PC_EVAL);
     if (strategy == NDI_CUBIC_SPLINE) {
-      if (vec_ok) hipLaunchKernelGGL((eval_flat_kernel<T, ST_CUBIC, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+      if (P.vec_ok) hipLaunchKernelGGL((eval_flat_kernel<T, ST_CUBIC, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
       else hipLaunchKernelGGL((eval_flat_kernel<T, ST_CUBIC, 1>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
     } else {
-      if (vec_ok) hipLaunchKernelGGL((eval_flat_kernel<T, ST_LINEAR, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
+      if (P.vec_ok) hipLaunchKernelGGL((eval_flat_kernel<T, ST_LINEAR, VN>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
       else hipLaunchKernelGGL((eval_flat_kernel<T, ST_LINEAR, 1>), dim3(gx), dim3(BLOCK), 0, s, A, tile_q);
     }
     NDI_HIP(hipGetLastError());
     ps.done();
   }
 
-  // Reads the status block back (stream must be idle) and converts it to the reference's error.
+  void enqueue(hipStream_t s, Workspace& ws, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path) {
+    launch_eval(s, ws.sc[0], prep(s, ws.sc[0], q, nq, out, out_stride, path));
+  }
+
+  // Reads the status block of the batch enqueued with scratch set 0 (stream must be idle afterwards) and converts
+  // it to the reference's error.
   ndi_status collect(hipStream_t s, Workspace& ws, uint64_t index_offset, ndi_oob_info* info) {
-    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    ws.ensure_status();
+    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.sc[0].status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
     NDI_HIP(hipStreamSynchronize(s));
     ws.pending = false;
     const unsigned long long ff = ws.host_status->first_fail[0];
     if (ff == NO_FAIL) return NDI_OK;
-    return report(ws, ff, index_offset, info);
+    return report(ws.last_q, ws.last_q_space, ff, index_offset, info);
   }
 
-  // The reference's error for the batch whose lowest failing (local) query index is ff.
-  ndi_status report(Workspace& ws, unsigned long long ff, uint64_t index_offset, ndi_oob_info* info) {
+  // The reference's error for the batch whose lowest failing query is q[ff] (reported as index_offset + ff).
+  ndi_status report(const void* q, int q_space, unsigned long long ff, uint64_t index_offset, ndi_oob_info* info) {
     T v;
-    if (ws.last_q_space == NDI_MEM_DEVICE)
-      NDI_HIP(hipMemcpy(&v, (const T*)ws.last_q + ff, sizeof(T), hipMemcpyDeviceToHost));
+    if (q_space == NDI_MEM_DEVICE)
+      NDI_HIP(hipMemcpy(&v, (const T*)q + ff, sizeof(T), hipMemcpyDeviceToHost));
     else
-      v = ((const T*)ws.last_q)[ff];
+      v = ((const T*)q)[ff];
     // without extrapolation every failure is a range failure (NaN included: "x = NaN is not in range");
     // with it the only failure is the search meeting a NaN -- the query itself or an infinite query that the
     // periodic wrap turned into NaN (the reference panics: vector_extensions.rs:83-84)
@@ -858,6 +942,32 @@ struct Interp1DImpl final : Interp1DBase {
     return fail(st, "x = %.17g is not in range", (double)v);
   }
 
+  // Host queries are uploaded once per call into the workspace.
+  const T* stage_queries(hipStream_t s, Workspace& ws, const void* q_, uint64_t nq, int q_space) {
+    if (q_space != NDI_MEM_HOST) return (const T*)q_;
+    ws.qdev.reserve(nq * sizeof(T));
+    NDI_HIP(hipMemcpyAsync(ws.qdev.p, q_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+    return ws.qdev.as<T>();
+  }
+
+  // Range pre-pass over a whole batch (8 B per query): the lowest failing index lands in ws.host_status once the
+  // stream has been synchronised.  The ring and the sharded evaluations need it before any row is produced.
+  void enqueue_prepass(hipStream_t s, Workspace& ws, const T* q, uint64_t nq) {
+    ws.ensure_status();
+    reset_status(ws.status.p, s);
+    StatusBlock* st = ws.status.as<StatusBlock>();
+    const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
+    const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+    {
+      ProfScope ps(s, PC_LOCATE);
+      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, q, (const T*)nullptr, nq, k0, kn, k0, kn,
+                         mode, &st->first_fail[0]);
+      NDI_HIP(hipGetLastError());
+      ps.done();
+    }
+    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+  }
+
   // Host output with short trailing axes (the reference's own bench shapes: scalar data, a few lanes):
   // one fused search+evaluate launch per chunk into a staging buffer the library owns, results and status
   // brought back with one synchronisation (small chunks bounce through pinned memory), and only the rows
@@ -867,23 +977,23 @@ struct Interp1DImpl final : Interp1DBase {
     const uint64_t row_bytes = lanes * sizeof(T);
     const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (64ull << 20) / row_bytes));
     constexpr size_t BOUNCE = 8ull << 20;
-    ws.stage[0].reserve(chunk_q * row_bytes);
+    ws.stage.reserve(chunk_q * row_bytes);
     ws.ensure_status();
     g_last_path.store(NDI_PATH_GATHER);
     allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>), (int)LDS_STAGE_LIMIT);
     allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>), (int)LDS_STAGE_LIMIT);
-    StatusBlock* st = ws.status.as<StatusBlock>();
+    StatusBlock* st = ws.sc[0].status.as<StatusBlock>();
     for (uint64_t off = 0; off < nq; off += chunk_q) {
       const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
       const size_t bytes = cq * row_bytes;
-      NDI_HIP(hipMemsetAsync(ws.status.p, 0xFF, 2 * sizeof(unsigned long long), s));
+      NDI_HIP(hipMemsetAsync(st, 0xFF, 2 * sizeof(unsigned long long), s));
       EvalSmallArgs<T> A{};
       A.pyr = pyr.view;
       A.data = data.as<T>();
       A.ca = ca.as<T>();
       A.cb = cb.as<T>();
       A.q = q_dev + off;
-      A.out = ws.stage[0].as<T>();
+      A.out = ws.stage.as<T>();
       A.nq = cq;
       A.out_stride = lanes;
       A.lanes = (uint32_t)lanes;
@@ -897,9 +1007,9 @@ struct Interp1DImpl final : Interp1DBase {
       const bool bounce = bytes <= BOUNCE;
       if (bounce) {
         ws.ensure_pin(BOUNCE);
-        NDI_HIP(hipMemcpyAsync(ws.pin, ws.stage[0].p, bytes, hipMemcpyDeviceToHost, s));
+        NDI_HIP(hipMemcpyAsync(ws.pin, ws.stage.p, bytes, hipMemcpyDeviceToHost, s));
       }
-      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipMemcpyAsync(ws.host_status, st, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
       NDI_HIP(hipStreamSynchronize(s));
       const unsigned long long ff = ws.host_status->first_fail[0];
       const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
@@ -911,15 +1021,45 @@ struct Interp1DImpl final : Interp1DBase {
             for (uint64_t r = 0; r < good; ++r)
               std::memcpy(dst + r * out_stride, (const char*)ws.pin + r * row_bytes, row_bytes);
         } else {
-          NDI_HIP(hipMemcpy2D(dst, out_stride * sizeof(T), ws.stage[0].p, row_bytes, row_bytes, good,
+          NDI_HIP(hipMemcpy2D(dst, out_stride * sizeof(T), ws.stage.p, row_bytes, row_bytes, good,
                               hipMemcpyDeviceToHost));
         }
       }
-      if (ff != NO_FAIL) {
-        ws.last_q = q_orig + off;
-        ws.last_q_space = q_space;
-        return collect(s, ws, off, info);
-      }
+      if (ff != NO_FAIL) return report(q_orig + off, q_space, ff, off, info);
+    }
+    return NDI_OK;
+  }
+
+  // interp_array_into on staged (device) queries; q_orig / q_space name the caller's array for error reports.
+  ndi_status eval_body(hipStream_t s, Workspace& ws, const T* q, const void* q_orig, int q_space, uint64_t nq,
+                       void* out_, uint64_t out_stride, const ndi_eval_opts& o, ndi_oob_info* info) {
+    ws.last_q = q_orig;
+    ws.last_q_space = q_space;
+    ws.last_nq = nq;
+    if (o.out_memspace == NDI_MEM_DEVICE) {
+      enqueue(s, ws, q, nq, (T*)out_, out_stride, o.path);
+      ws.pending = true;
+      if (o.async_launch) return NDI_OK;
+      return collect(s, ws, 0, info);
+    }
+    // host output: stream the batch through a device staging buffer in query chunks
+    const uint64_t row_bytes = lanes * sizeof(T);
+    if (lanes <= (uint64_t)SMALL_LANES && pyr.lds_bytes <= LDS_STAGE_LIMIT)
+      return eval_small_host(s, ws, q, (const T*)q_orig, q_space, nq, (T*)out_, out_stride, info);
+    const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / row_bytes));
+    ws.stage.reserve(chunk_q * row_bytes);
+    ws.ensure_status();
+    for (uint64_t off = 0; off < nq; off += chunk_q) {
+      const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
+      enqueue(s, ws, q + off, cq, ws.stage.as<T>(), lanes, o.path);
+      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.sc[0].status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipStreamSynchronize(s));
+      unsigned long long ff = ws.host_status->first_fail[0];
+      const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
+      if (good)
+        NDI_HIP(hipMemcpy2D((T*)out_ + off * out_stride, out_stride * sizeof(T), ws.stage.p, row_bytes,
+                            row_bytes, good, hipMemcpyDeviceToHost));
+      if (ff != NO_FAIL) return report((const T*)q_orig + off, q_space, ff, off, info);
     }
     return NDI_OK;
   }
@@ -937,41 +1077,8 @@ struct Interp1DImpl final : Interp1DBase {
     if (!q_ || !out_) return fail(NDI_BAD_ARG, "null query / output pointer");
     SpaceLease lease(spaces, s);
     Workspace& ws = lease.ws;
-    const T* q = (const T*)q_;
-    if (o.q_memspace == NDI_MEM_HOST) {
-      ws.qdev.reserve(nq * sizeof(T));
-      NDI_HIP(hipMemcpyAsync(ws.qdev.p, q_, nq * sizeof(T), hipMemcpyHostToDevice, s));
-      q = ws.qdev.as<T>();
-    }
-    ws.last_q = q_;
-    ws.last_q_space = o.q_memspace;
-    ws.last_nq = nq;
-    if (o.out_memspace == NDI_MEM_DEVICE) {
-      enqueue(s, ws, q, nq, (T*)out_, out_stride, o.path);
-      ws.pending = true;
-      if (o.async_launch) return NDI_OK;
-      return collect(s, ws, 0, info);
-    }
-    // host output: stream the batch through a device staging buffer in query chunks
-    const uint64_t row_bytes = lanes * sizeof(T);
-    if (lanes <= (uint64_t)SMALL_LANES && pyr.lds_bytes <= LDS_STAGE_LIMIT)
-      return eval_small_host(s, ws, q, (const T*)q_, o.q_memspace, nq, (T*)out_, out_stride, info);
-    const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / row_bytes));
-    ws.stage[0].reserve(chunk_q * row_bytes);
-    for (uint64_t off = 0; off < nq; off += chunk_q) {
-      const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
-      enqueue(s, ws, q + off, cq, ws.stage[0].as<T>(), lanes, o.path);
-      ws.last_q = (const T*)q_ + off;
-      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
-      NDI_HIP(hipStreamSynchronize(s));
-      unsigned long long ff = ws.host_status->first_fail[0];
-      const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
-      if (good)
-        NDI_HIP(hipMemcpy2D((T*)out_ + off * out_stride, out_stride * sizeof(T), ws.stage[0].p, row_bytes,
-                            row_bytes, good, hipMemcpyDeviceToHost));
-      if (ff != NO_FAIL) return collect(s, ws, off, info);
-    }
-    return NDI_OK;
+    const T* q = stage_queries(s, ws, q_, nq, o.q_memspace);
+    return eval_body(s, ws, q, q_, o.q_memspace, nq, out_, out_stride, o, info);
   }
 
   ndi_status finish(void* stream, ndi_oob_info* info) override {
@@ -986,85 +1093,108 @@ struct Interp1DImpl final : Interp1DBase {
     return collect(s, ws, 0, info);
   }
 
+  // ---- ring evaluation ----------------------------------------------------------------------
   // Interp1D::interp_array for outputs that do not fit / need not stay in device memory: chunks through a ring.
+  // The producer is a two-stream pipeline: locate + group of chunk k+1 run on the workspace's side stream into the
+  // other scratch set while chunk k is evaluated on the caller's stream; events order the two.
+  struct RingRun {
+    std::unique_lock<std::mutex> own;
+    std::vector<void*> slots;
+    uint64_t pitch = 0, chunk = 0, cq0 = 0;
+    uint32_t n_slots = 0;
+    Plan1 plan0;
+    hipStream_t side = nullptr;
+  };
+
+  // Resolves the ring and starts locate + group of chunk 0 on the side stream -- before the first failing index
+  // of the batch is known on the host (it does not depend on it: the evaluation kernels skip rows at / after the
+  // chunk's own first failure), so the range pre-pass and its synchronisation are hidden behind it.
+  void ring_begin(hipStream_t s, Workspace& ws, const T* q, uint64_t nq, const ndi_ring_desc* ring, uint64_t stride,
+                  const ndi_eval_opts& o, RingRun& R) {
+    R.n_slots = ring->n_slots;
+    R.chunk = ring->chunk_queries;
+    R.slots.resize(ring->n_slots);
+    R.pitch = stride;          // row pitch of a chunk, in elements
+    if (ring->slots) {
+      for (uint32_t i = 0; i < ring->n_slots; ++i) R.slots[i] = ring->slots[i];
+    } else {
+      R.own = std::unique_lock<std::mutex>(ring_own.mu);   // library-owned ring: one allocation, slots
+      ring_own.ensure(ring->n_slots, ring->chunk_queries, stride * sizeof(T));   // interleaved row by row (OwnedRing)
+      for (uint32_t i = 0; i < ring->n_slots; ++i) R.slots[i] = (char*)ring_own.buf.p + (size_t)i * stride * sizeof(T);
+      R.pitch = (uint64_t)ring->n_slots * stride;
+    }
+    R.side = ws.side_stream();
+    for (Scratch& sc : ws.sc) sc.ensure_events();
+    // the side stream starts after everything already enqueued on s (the query upload)
+    NDI_HIP(hipEventRecord(ws.order_event(), s));
+    NDI_HIP(hipStreamWaitEvent(R.side, ws.order_event(), 0));
+    R.cq0 = std::min<uint64_t>(R.chunk, nq);
+    R.plan0 = prep(R.side, ws.sc[0], q, R.cq0, (T*)R.slots[0], R.pitch, o.path);
+    NDI_HIP(hipEventRecord(ws.sc[0].prep_done, R.side));
+  }
+
+  // Produces the rows [0, limit) of the batch chunk by chunk.  q_offset / shard: position of this batch in a
+  // sharded evaluation (the consumer sees global query indices).
+  void ring_produce(hipStream_t s, Workspace& ws, const T* q, uint64_t limit, RingRun& R, ndi_ring_consumer consume,
+                    void* user, const ndi_eval_opts& o, uint64_t q_offset, uint32_t shard) {
+    std::vector<hipEvent_t> busy(R.n_slots, nullptr);
+    uint64_t k = 0;
+    for (uint64_t off = 0; off < limit; off += R.chunk, ++k) {
+      const uint64_t cq = std::min<uint64_t>(R.chunk, limit - off);
+      const uint32_t slot = (uint32_t)(k % R.n_slots);
+      Scratch& sc = ws.sc[k & 1];
+      Plan1 P = R.plan0;
+      if (k > 0) {
+        if (k >= 2) NDI_HIP(hipStreamWaitEvent(R.side, sc.eval_done, 0));   // chunk k-2 has released the set
+        P = prep(R.side, sc, q + off, cq, (T*)R.slots[slot], R.pitch, o.path);
+        NDI_HIP(hipEventRecord(sc.prep_done, R.side));
+      }
+      NDI_HIP(hipStreamWaitEvent(s, sc.prep_done, 0));
+      if (busy[slot]) {   // the consumer reads this slot on another stream: wait for it there
+        NDI_HIP(hipStreamWaitEvent(s, busy[slot], 0));
+        busy[slot] = nullptr;
+      }
+      launch_eval(s, sc, P);
+      NDI_HIP(hipEventRecord(sc.eval_done, s));
+      if (consume) {
+        ndi_ring_chunk c{};
+        c.index = k; c.q_begin = q_offset + off; c.q_count = cq; c.out = R.slots[slot]; c.row_stride = R.pitch;
+        c.slot = slot; c.shard = shard; c.stream = (void*)s;
+        busy[slot] = (hipEvent_t)consume(user, &c);
+      }
+    }
+    NDI_HIP(hipStreamSynchronize(s));
+    NDI_HIP(hipStreamSynchronize(R.side));   // (a speculative chunk 0 that was never evaluated)
+    for (hipEvent_t e : busy)
+      if (e) NDI_HIP(hipEventSynchronize(e));
+    ws.pending = false;
+  }
+
   ndi_status eval_ring(const void* q_, uint64_t nq, const ndi_ring_desc* ring, ndi_ring_consumer consume,
                        void* user, const ndi_eval_opts* opts, ndi_oob_info* info) override {
     DeviceGuard dg(device);
     ndi_eval_opts o{};
     if (opts) o = *opts;
     hipStream_t s = (hipStream_t)o.stream;
-    if (!ring || ring->n_slots == 0 || ring->chunk_queries == 0)
-      return fail(NDI_BAD_ARG, "ring needs n_slots >= 1 and chunk_queries >= 1");
-    const uint64_t stride = ring->row_stride ? ring->row_stride : lanes;
-    if (stride < lanes) return fail(NDI_BAD_ARG, "ring row_stride (%llu) < lanes (%llu)",
-                                    (unsigned long long)stride, (unsigned long long)lanes);
+    uint64_t stride = 0;
+    ndi_status rs = check_ring_desc(ring, lanes, &stride);
+    if (rs != NDI_OK) return rs;
     if (nq == 0) return NDI_OK;
     if (!q_) return fail(NDI_BAD_ARG, "null query pointer");
     Range rg("ndi_interp1d_eval_ring");
     SpaceLease lease(spaces, s);
     Workspace& ws = lease.ws;
-    const T* q = (const T*)q_;
-    if (o.q_memspace == NDI_MEM_HOST) {
-      ws.qdev.reserve(nq * sizeof(T));
-      NDI_HIP(hipMemcpyAsync(ws.qdev.p, q_, nq * sizeof(T), hipMemcpyHostToDevice, s));
-      q = ws.qdev.as<T>();
-    }
-    // range pre-pass over the whole batch: the first failing index is known before any chunk is produced
-    reset_status(ws, s);
-    StatusBlock* st = ws.status.as<StatusBlock>();
-    {
-      const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
-      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
-      ProfScope ps(s, PC_LOCATE);
-      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, q, (const T*)nullptr, nq, k0, kn, k0, kn,
-                         mode, &st->first_fail[0]);
-      NDI_HIP(hipGetLastError());
-      ps.done();
-    }
-    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    const T* q = stage_queries(s, ws, q_, nq, o.q_memspace);
+    // range pre-pass over the whole batch: the first failing index is known before any chunk is handed out
+    enqueue_prepass(s, ws, q, nq);
+    RingRun R;
+    ring_begin(s, ws, q, nq, ring, stride, o, R);
     NDI_HIP(hipStreamSynchronize(s));
     const unsigned long long ff = ws.host_status->first_fail[0];
     const uint64_t limit = ff == NO_FAIL ? nq : std::min<uint64_t>(nq, ff);
-
-    std::unique_lock<std::mutex> own(ring_own.mu, std::defer_lock);
-    std::vector<void*> slots(ring->n_slots);
-    uint64_t pitch = stride;          // row pitch of a chunk, in elements
-    if (ring->slots) {
-      for (uint32_t i = 0; i < ring->n_slots; ++i) {
-        if (!ring->slots[i]) return fail(NDI_BAD_ARG, "ring slot %u is null", i);
-        slots[i] = ring->slots[i];
-      }
-    } else {
-      own.lock();    // library-owned ring: one allocation, slots interleaved row by row (see OwnedRing)
-      ring_own.ensure(ring->n_slots, ring->chunk_queries, stride * sizeof(T));
-      for (uint32_t i = 0; i < ring->n_slots; ++i) slots[i] = (char*)ring_own.buf.p + (size_t)i * stride * sizeof(T);
-      pitch = (uint64_t)ring->n_slots * stride;
-    }
-    std::vector<hipEvent_t> busy(ring->n_slots, nullptr);
-    uint64_t k = 0;
-    for (uint64_t off = 0; off < limit; off += ring->chunk_queries, ++k) {
-      const uint64_t cq = std::min<uint64_t>(ring->chunk_queries, limit - off);
-      const uint32_t slot = (uint32_t)(k % ring->n_slots);
-      if (busy[slot]) {   // the consumer reads this slot on another stream: wait for it there
-        NDI_HIP(hipStreamWaitEvent(s, busy[slot], 0));
-        busy[slot] = nullptr;
-      }
-      enqueue(s, ws, q + off, cq, (T*)slots[slot], pitch, o.path);
-      if (consume) {
-        ndi_ring_chunk c{};
-        c.index = k; c.q_begin = off; c.q_count = cq; c.out = slots[slot]; c.row_stride = pitch;
-        c.slot = slot; c.stream = (void*)s;
-        busy[slot] = (hipEvent_t)consume(user, &c);
-      }
-    }
-    NDI_HIP(hipStreamSynchronize(s));
-    for (hipEvent_t e : busy)
-      if (e) NDI_HIP(hipEventSynchronize(e));
-    ws.pending = false;
+    ring_produce(s, ws, q, limit, R, consume, user, o, 0, 0);
     if (ff == NO_FAIL) return NDI_OK;
-    ws.last_q = q_;
-    ws.last_q_space = o.q_memspace;
-    return report(ws, ff, 0, info);
+    return report(q_, o.q_memspace, ff, 0, info);
   }
 
   ndi_status trim() override {
@@ -1148,6 +1278,7 @@ static ndi_status create1d(const ndi_interp1d_desc& d, Interp1DBase** out) {
 struct Interp2DBase {
   virtual ~Interp2DBase() = default;
   int dtype = 0, device = 0;
+  uint64_t lanes = 0;
   virtual ndi_status eval(const void* qx, const void* qy, uint64_t nq, void* out, uint64_t out_stride,
                           const ndi_eval_opts* opts, ndi_oob_info* info) = 0;
   virtual ndi_status finish(void* stream, ndi_oob_info* info) = 0;
@@ -1160,54 +1291,52 @@ struct Interp2DBase {
 template <class T>
 struct Interp2DImpl final : Interp2DBase {
   int mode = EX_NO;
-  uint64_t nx = 0, ny = 0, lanes = 0;
+  uint64_t nx = 0, ny = 0;
   DevicePyramid<T> px, py;
   DevBuf data;
   bool pair_packed = false;   // data holds the pair-packed layout (pack_pairs_kernel)
   SpaceSet spaces;
   OwnedRing ring_own;
 
-  void enqueue(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t nq, T* out,
-               uint64_t out_stride, int path) {
-    ws.idx.reserve(nq * sizeof(uint32_t));
-    ws.idx2.reserve(nq * sizeof(uint32_t));
-    reset_status(ws, s);
-    StatusBlock* st = ws.status.as<StatusBlock>();
+  // Two stages as in Interp1DImpl: prep() = both searches (+ the optional tile grouping) into a scratch set,
+  // launch_eval() = the bilinear kernel reading that set.
+  struct Plan2 {
+    enum Kind { SMALL, GATHER, TILED } kind = GATHER;
+    const T* qx = nullptr;
+    const T* qy = nullptr;
+    uint64_t nq = 0;
+    T* out = nullptr;
+    uint64_t out_stride = 0;
+  };
+
+  Plan2 prep(hipStream_t s, Scratch& sc, const T* qx, const T* qy, uint64_t nq, T* out, uint64_t out_stride,
+             int path) {
+    Plan2 P;
+    P.qx = qx; P.qy = qy; P.nq = nq; P.out = out; P.out_stride = out_stride;
+    sc.idx.reserve(nq * sizeof(uint32_t));
+    sc.idx2.reserve(nq * sizeof(uint32_t));
+    sc.status.reserve(sizeof(StatusBlock));
+    reset_status(sc.status.p, s);
+    StatusBlock* st = sc.status.as<StatusBlock>();
     const size_t both = ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15);
     if (lanes <= 2 && both <= LDS_STAGE_LIMIT && path != NDI_PATH_BUCKETED) {
       // short trailing axes: range pre-check, then both searches + evaluation fused in one launch
+      P.kind = Plan2::SMALL;
       g_last_path.store(NDI_PATH_GATHER);
       const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
-      {
-        ProfScope ps(s, PC_LOCATE);
-        hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
-                           px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode,
-                           &st->first_fail[0]);
-        NDI_HIP(hipGetLastError());
-        ps.done();
-      }
-      allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small2d_kernel<T>), (int)LDS_STAGE_LIMIT);
-      EvalSmall2Args<T> S{};
-      S.px = px.view; S.py = py.view;
-      S.data = data.as<T>();
-      S.qx = qx; S.qy = qy;
-      S.out = out;
-      S.nq = nq;
-      S.out_stride = out_stride;
-      S.row_cells = pair_packed ? ny - 1 : ny;
-      S.cell_elems = pair_packed ? 2 * lanes : lanes;
-      S.lanes = (uint32_t)lanes;
-      S.mode = mode;
-      S.first_fail = &st->first_fail[0];
-      S.prechecked = 1;
-      launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), both, eval_small2d_kernel<T>, S);
-      return;
+      ProfScope ps(s, PC_LOCATE);
+      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
+                         px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode,
+                         &st->first_fail[0]);
+      NDI_HIP(hipGetLastError());
+      ps.done();
+      return P;
     }
     if (both <= LDS_STAGE_LIMIT) {   // both axes in one launch
       Locate2Args<T> LA{};
       LA.px = px.view; LA.py = py.view;
       LA.qx = qx; LA.qy = qy; LA.nq = nq;
-      LA.xi = ws.idx.as<uint32_t>(); LA.yi = ws.idx2.as<uint32_t>();
+      LA.xi = sc.idx.as<uint32_t>(); LA.yi = sc.idx2.as<uint32_t>();
       LA.first_fail = &st->first_fail[0];
       LA.mode = mode;
       LA.bx = BucketIndex<T>{nullptr, 0, T(0)};
@@ -1235,29 +1364,9 @@ struct Interp2DImpl final : Interp2DBase {
       allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T>), (int)LDS_STAGE_LIMIT);
       launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), both_l, locate2_kernel<T>, LA);
     } else {
-      run_locate<T>(s, px, qx, nq, ws.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
-      run_locate<T>(s, py, qy, nq, ws.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);
+      run_locate<T>(s, px, qx, nq, sc.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
+      run_locate<T>(s, py, qy, nq, sc.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);
     }
-    Eval2Args<T> A{};
-    A.xk = px.view.lv0;
-    A.yk = py.view.lv0;
-    A.data = data.as<T>();
-    A.qx = qx;
-    A.qy = qy;
-    A.xi = ws.idx.as<uint32_t>();
-    A.yi = ws.idx2.as<uint32_t>();
-    A.out = out;
-    A.nx = nx;
-    A.ny = ny;
-    A.lanes = lanes;
-    A.out_stride = out_stride;
-    A.nq = nq;
-    A.row_cells = pair_packed ? ny - 1 : ny;
-    A.cell_elems = pair_packed ? 2 * lanes : lanes;
-    A.status = st;
-    A.rec_i = nullptr;
-    A.rec_q = nullptr;
-
     // BUCKETED for 2-D = tile grouping: queries are ordered by the tile of cells they fall in, so the
     // corner rows of a tile are fetched from HBM once and re-served by L2 / Infinity Cache.  Measured on
     // C3: the evaluation gets 17 % faster but placing the grouped records costs more
@@ -1271,6 +1380,7 @@ struct Interp2DImpl final : Interp2DBase {
     }
     g_last_path.store(tiled ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
     if (tiled) {
+      P.kind = Plan2::TILED;
       const uint32_t nty = tiles((uint32_t)ny - 1, sy);
       const uint32_t nb = tiles((uint32_t)nx - 1, sx) * nty;
       uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 4095) / 4096, GROUP_MAX_BLOCKS));
@@ -1279,33 +1389,81 @@ struct Interp2DImpl final : Interp2DBase {
       blocks = (nq + slice - 1) / slice;
       // the two grouping kernels are latency-bound chains (load -> LDS atomic -> scattered store): many waves per CU
       const unsigned gthreads = slice >= 4096 ? 1024u : (unsigned)BLOCK;
-      ws.t.reserve(nq * sizeof(uint32_t));      // keys
-      ws.perm.reserve(nq * sizeof(uint4));            // grouped records {qi, xi, yi}
-      ws.stage[1].reserve(nq * 2 * sizeof(T));        // grouped {qx, qy}
-      ws.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
-      ws.counts.reserve((size_t)nb * sizeof(uint32_t));
-      ws.cursor.reserve((size_t)nb * sizeof(uint32_t));
+      sc.t.reserve(nq * sizeof(uint32_t));      // keys
+      sc.perm.reserve(nq * sizeof(uint4));            // grouped records {qi, xi, yi}
+      sc.recq.reserve(nq * 2 * sizeof(T));            // grouped {qx, qy}
+      sc.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
+      sc.counts.reserve((size_t)nb * sizeof(uint32_t));
+      sc.cursor.reserve((size_t)nb * sizeof(uint32_t));
       allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T>), (int)(GROUP_MAX_BINS * 4));
       allow_dynamic_lds(reinterpret_cast<const void*>(&tile_hist_kernel), (int)(GROUP_MAX_BINS * 4));
       ProfScope ps(s, PC_GROUP);
       hipLaunchKernelGGL(tile_hist_kernel, dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
-                         (const uint32_t*)A.xi, (const uint32_t*)A.yi, nq, slice, sx, sy, nty, nb,
-                         ws.t.as<uint32_t>(), ws.hist.as<uint32_t>());
+                         (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), nq, slice,
+                         sx, sy, nty, nb, sc.t.as<uint32_t>(), sc.hist.as<uint32_t>());
       hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
-                         ws.hist.as<uint32_t>(), (uint32_t)blocks, nb, ws.counts.as<uint32_t>());
-      hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), nb,
-                         ws.cursor.as<uint32_t>(), st);
+                         sc.hist.as<uint32_t>(), (uint32_t)blocks, nb, sc.counts.as<uint32_t>());
+      hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, sc.counts.as<uint32_t>(), nb,
+                         sc.cursor.as<uint32_t>(), st);
       hipLaunchKernelGGL(group_scatter2d_kernel<T>, dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
-                         (const uint32_t*)ws.t.as<uint32_t>(), (const uint32_t*)A.xi, (const uint32_t*)A.yi, qx, qy,
-                         nq, slice, (const uint32_t*)ws.hist.as<uint32_t>(),
-                         (const uint32_t*)ws.cursor.as<uint32_t>(), nb, ws.perm.as<uint4>(), ws.stage[1].as<T>());
+                         (const uint32_t*)sc.t.as<uint32_t>(), (const uint32_t*)sc.idx.as<uint32_t>(),
+                         (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq, slice,
+                         (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(), nb,
+                         sc.perm.as<uint4>(), sc.recq.as<T>());
       NDI_HIP(hipGetLastError());
       ps.done();
-      A.rec_i = ws.perm.as<uint4>();
-      A.rec_q = ws.stage[1].as<T>();
+    }
+    return P;
+  }
+
+  void launch_eval(hipStream_t s, Scratch& sc, const Plan2& P) {
+    StatusBlock* st = sc.status.as<StatusBlock>();
+    const uint64_t nq = P.nq;
+    if (P.kind == Plan2::SMALL) {
+      const size_t both = ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15);
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+      allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small2d_kernel<T>), (int)LDS_STAGE_LIMIT);
+      EvalSmall2Args<T> S{};
+      S.px = px.view; S.py = py.view;
+      S.data = data.as<T>();
+      S.qx = P.qx; S.qy = P.qy;
+      S.out = P.out;
+      S.nq = nq;
+      S.out_stride = P.out_stride;
+      S.row_cells = pair_packed ? ny - 1 : ny;
+      S.cell_elems = pair_packed ? 2 * lanes : lanes;
+      S.lanes = (uint32_t)lanes;
+      S.mode = mode;
+      S.first_fail = &st->first_fail[0];
+      S.prechecked = 1;
+      launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), both, eval_small2d_kernel<T>, S);
+      return;
+    }
+    Eval2Args<T> A{};
+    A.xk = px.view.lv0;
+    A.yk = py.view.lv0;
+    A.data = data.as<T>();
+    A.qx = P.qx;
+    A.qy = P.qy;
+    A.xi = sc.idx.as<uint32_t>();
+    A.yi = sc.idx2.as<uint32_t>();
+    A.out = P.out;
+    A.nx = nx;
+    A.ny = ny;
+    A.lanes = lanes;
+    A.out_stride = P.out_stride;
+    A.nq = nq;
+    A.row_cells = pair_packed ? ny - 1 : ny;
+    A.cell_elems = pair_packed ? 2 * lanes : lanes;
+    A.status = st;
+    A.rec_i = nullptr;
+    A.rec_q = nullptr;
+    if (P.kind == Plan2::TILED) {
+      A.rec_i = sc.perm.as<uint4>();
+      A.rec_q = sc.recq.as<T>();
     }
     constexpr int VN = Wide<T>::N;
-    const bool vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
+    const bool vec_ok = (lanes % VN == 0) && (P.out_stride % VN == 0) && aligned16(P.out);
     const uint64_t LV = vec_ok ? lanes / VN : lanes;
     // knots in LDS: both axes must fit next to each other with two 1024-thread workgroups per CU, and the batch
     // must be large enough to amortise the staging
@@ -1332,23 +1490,29 @@ struct Interp2DImpl final : Interp2DBase {
     ps.done();
   }
 
+  void enqueue(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t nq, T* out,
+               uint64_t out_stride, int path) {
+    launch_eval(s, ws.sc[0], prep(s, ws.sc[0], qx, qy, nq, out, out_stride, path));
+  }
+
   ndi_status collect(hipStream_t s, Workspace& ws, uint64_t index_offset, ndi_oob_info* info) {
-    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    ws.ensure_status();
+    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.sc[0].status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
     NDI_HIP(hipStreamSynchronize(s));
     ws.pending = false;
     const unsigned long long fx = ws.host_status->first_fail[0], fy = ws.host_status->first_fail[1];
     if (fx == NO_FAIL && fy == NO_FAIL) return NDI_OK;
-    return report(ws, fx, fy, index_offset, info);
+    return report(ws.last_q, ws.last_q2, ws.last_q_space, fx, fy, index_offset, info);
   }
 
-  ndi_status report(Workspace& ws, unsigned long long fx, unsigned long long fy, uint64_t index_offset,
-                    ndi_oob_info* info) {
+  ndi_status report(const void* qx, const void* qy, int q_space, unsigned long long fx, unsigned long long fy,
+                    uint64_t index_offset, ndi_oob_info* info) {
     // x is tested before y for the same query (bilinear.rs:71-80)
     const int axis = (fx <= fy) ? 0 : 1;
     const unsigned long long ff = axis == 0 ? fx : fy;
-    const void* src = axis == 0 ? ws.last_q : ws.last_q2;
+    const void* src = axis == 0 ? qx : qy;
     T v;
-    if (ws.last_q_space == NDI_MEM_DEVICE)
+    if (q_space == NDI_MEM_DEVICE)
       NDI_HIP(hipMemcpy(&v, (const T*)src + ff, sizeof(T), hipMemcpyDeviceToHost));
     else
       v = ((const T*)src)[ff];
@@ -1366,6 +1530,36 @@ struct Interp2DImpl final : Interp2DBase {
     return fail(st, "%s = %.17g is not in range", axis == 0 ? "x" : "y", (double)v);
   }
 
+  void stage_queries(hipStream_t s, Workspace& ws, const void* qx_, const void* qy_, uint64_t nq, int q_space,
+                     const T** qx, const T** qy) {
+    *qx = (const T*)qx_;
+    *qy = (const T*)qy_;
+    if (q_space != NDI_MEM_HOST) return;
+    ws.qdev.reserve(nq * sizeof(T));
+    ws.qdev2.reserve(nq * sizeof(T));
+    NDI_HIP(hipMemcpyAsync(ws.qdev.p, qx_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+    NDI_HIP(hipMemcpyAsync(ws.qdev2.p, qy_, nq * sizeof(T), hipMemcpyHostToDevice, s));
+    *qx = ws.qdev.as<T>();
+    *qy = ws.qdev2.as<T>();
+  }
+
+  // Range pre-pass over a whole batch (see Interp1DImpl::enqueue_prepass): first_fail[0] = x, [1] = y.
+  void enqueue_prepass(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t nq) {
+    ws.ensure_status();
+    reset_status(ws.status.p, s);
+    StatusBlock* st = ws.status.as<StatusBlock>();
+    const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+    {
+      ProfScope ps(s, PC_LOCATE);
+      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
+                         px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode,
+                         &st->first_fail[0]);
+      NDI_HIP(hipGetLastError());
+      ps.done();
+    }
+    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+  }
+
   // Host output with short trailing axes: one fused launch per chunk (see Interp1DImpl::eval_small_host).
   ndi_status eval_small_host(hipStream_t s, Workspace& ws, const T* qx_dev, const T* qy_dev, const T* qx_orig,
                              const T* qy_orig, int q_space, uint64_t nq, T* out, uint64_t out_stride,
@@ -1373,21 +1567,21 @@ struct Interp2DImpl final : Interp2DBase {
     const uint64_t row_bytes = lanes * sizeof(T);
     const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (64ull << 20) / row_bytes));
     constexpr size_t BOUNCE = 8ull << 20;
-    ws.stage[0].reserve(chunk_q * row_bytes);
+    ws.stage.reserve(chunk_q * row_bytes);
     ws.ensure_status();
     g_last_path.store(NDI_PATH_GATHER);
     allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small2d_kernel<T>), (int)LDS_STAGE_LIMIT);
-    StatusBlock* st = ws.status.as<StatusBlock>();
+    StatusBlock* st = ws.sc[0].status.as<StatusBlock>();
     const size_t shmem = (px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15;
     for (uint64_t off = 0; off < nq; off += chunk_q) {
       const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
       const size_t bytes = cq * row_bytes;
-      NDI_HIP(hipMemsetAsync(ws.status.p, 0xFF, 2 * sizeof(unsigned long long), s));
+      NDI_HIP(hipMemsetAsync(st, 0xFF, 2 * sizeof(unsigned long long), s));
       EvalSmall2Args<T> A{};
       A.px = px.view; A.py = py.view;
       A.data = data.as<T>();
       A.qx = qx_dev + off; A.qy = qy_dev + off;
-      A.out = ws.stage[0].as<T>();
+      A.out = ws.stage.as<T>();
       A.nq = cq;
       A.out_stride = lanes;
       A.row_cells = pair_packed ? ny - 1 : ny;
@@ -1401,11 +1595,12 @@ struct Interp2DImpl final : Interp2DBase {
       const bool bounce = bytes <= BOUNCE;
       if (bounce) {
         ws.ensure_pin(BOUNCE);
-        NDI_HIP(hipMemcpyAsync(ws.pin, ws.stage[0].p, bytes, hipMemcpyDeviceToHost, s));
+        NDI_HIP(hipMemcpyAsync(ws.pin, ws.stage.p, bytes, hipMemcpyDeviceToHost, s));
       }
-      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipMemcpyAsync(ws.host_status, st, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
       NDI_HIP(hipStreamSynchronize(s));
-      const unsigned long long ff = std::min(ws.host_status->first_fail[0], ws.host_status->first_fail[1]);
+      const unsigned long long fx = ws.host_status->first_fail[0], fy = ws.host_status->first_fail[1];
+      const unsigned long long ff = std::min(fx, fy);
       const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
       T* dst = out + off * out_stride;
       if (good) {
@@ -1415,16 +1610,48 @@ struct Interp2DImpl final : Interp2DBase {
             for (uint64_t r = 0; r < good; ++r)
               std::memcpy(dst + r * out_stride, (const char*)ws.pin + r * row_bytes, row_bytes);
         } else {
-          NDI_HIP(hipMemcpy2D(dst, out_stride * sizeof(T), ws.stage[0].p, row_bytes, row_bytes, good,
+          NDI_HIP(hipMemcpy2D(dst, out_stride * sizeof(T), ws.stage.p, row_bytes, row_bytes, good,
                               hipMemcpyDeviceToHost));
         }
       }
-      if (ff != NO_FAIL) {
-        ws.last_q = qx_orig + off;
-        ws.last_q2 = qy_orig + off;
-        ws.last_q_space = q_space;
-        return collect(s, ws, off, info);
-      }
+      if (ff != NO_FAIL) return report(qx_orig + off, qy_orig + off, q_space, fx, fy, off, info);
+    }
+    return NDI_OK;
+  }
+
+  ndi_status eval_body(hipStream_t s, Workspace& ws, const T* qx, const T* qy, const void* qx_orig,
+                       const void* qy_orig, int q_space, uint64_t nq, void* out_, uint64_t out_stride,
+                       const ndi_eval_opts& o, ndi_oob_info* info) {
+    ws.last_q = qx_orig;
+    ws.last_q2 = qy_orig;
+    ws.last_q_space = q_space;
+    ws.last_nq = nq;
+    if (o.out_memspace == NDI_MEM_DEVICE) {
+      enqueue(s, ws, qx, qy, nq, (T*)out_, out_stride, o.path);
+      ws.pending = true;
+      if (o.async_launch) return NDI_OK;
+      return collect(s, ws, 0, info);
+    }
+    const uint64_t row_bytes = lanes * sizeof(T);
+    if (lanes <= (uint64_t)SMALL_LANES && ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15) <= LDS_STAGE_LIMIT)
+      return eval_small_host(s, ws, qx, qy, (const T*)qx_orig, (const T*)qy_orig, q_space, nq, (T*)out_, out_stride,
+                             info);
+    const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / row_bytes));
+    ws.stage.reserve(chunk_q * row_bytes);
+    ws.ensure_status();
+    for (uint64_t off = 0; off < nq; off += chunk_q) {
+      const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
+      enqueue(s, ws, qx + off, qy + off, cq, ws.stage.as<T>(), lanes, o.path);
+      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.sc[0].status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+      NDI_HIP(hipStreamSynchronize(s));
+      const unsigned long long fx = ws.host_status->first_fail[0], fy = ws.host_status->first_fail[1];
+      const unsigned long long ff = std::min(fx, fy);
+      const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
+      if (good)
+        NDI_HIP(hipMemcpy2D((T*)out_ + off * out_stride, out_stride * sizeof(T), ws.stage.p, row_bytes,
+                            row_bytes, good, hipMemcpyDeviceToHost));
+      if (ff != NO_FAIL)
+        return report((const T*)qx_orig + off, (const T*)qy_orig + off, q_space, fx, fy, off, info);
     }
     return NDI_OK;
   }
@@ -1442,46 +1669,9 @@ struct Interp2DImpl final : Interp2DBase {
     if (!qx_ || !qy_ || !out_) return fail(NDI_BAD_ARG, "null query / output pointer");
     SpaceLease lease(spaces, s);
     Workspace& ws = lease.ws;
-    const T* qx = (const T*)qx_;
-    const T* qy = (const T*)qy_;
-    if (o.q_memspace == NDI_MEM_HOST) {
-      ws.qdev.reserve(nq * sizeof(T));
-      ws.qdev2.reserve(nq * sizeof(T));
-      NDI_HIP(hipMemcpyAsync(ws.qdev.p, qx_, nq * sizeof(T), hipMemcpyHostToDevice, s));
-      NDI_HIP(hipMemcpyAsync(ws.qdev2.p, qy_, nq * sizeof(T), hipMemcpyHostToDevice, s));
-      qx = ws.qdev.as<T>();
-      qy = ws.qdev2.as<T>();
-    }
-    ws.last_q = qx_;
-    ws.last_q2 = qy_;
-    ws.last_q_space = o.q_memspace;
-    ws.last_nq = nq;
-    if (o.out_memspace == NDI_MEM_DEVICE) {
-      enqueue(s, ws, qx, qy, nq, (T*)out_, out_stride, o.path);
-      ws.pending = true;
-      if (o.async_launch) return NDI_OK;
-      return collect(s, ws, 0, info);
-    }
-    const uint64_t row_bytes = lanes * sizeof(T);
-    if (lanes <= (uint64_t)SMALL_LANES && ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15) <= LDS_STAGE_LIMIT)
-      return eval_small_host(s, ws, qx, qy, (const T*)qx_, (const T*)qy_, o.q_memspace, nq, (T*)out_, out_stride, info);
-    const uint64_t chunk_q = std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / row_bytes));
-    ws.stage[0].reserve(chunk_q * row_bytes);
-    for (uint64_t off = 0; off < nq; off += chunk_q) {
-      const uint64_t cq = std::min<uint64_t>(chunk_q, nq - off);
-      enqueue(s, ws, qx + off, qy + off, cq, ws.stage[0].as<T>(), lanes, o.path);
-      ws.last_q = (const T*)qx_ + off;
-      ws.last_q2 = (const T*)qy_ + off;
-      NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
-      NDI_HIP(hipStreamSynchronize(s));
-      const unsigned long long ff = std::min(ws.host_status->first_fail[0], ws.host_status->first_fail[1]);
-      const uint64_t good = (ff == NO_FAIL) ? cq : (uint64_t)ff;
-      if (good)
-        NDI_HIP(hipMemcpy2D((T*)out_ + off * out_stride, out_stride * sizeof(T), ws.stage[0].p, row_bytes,
-                            row_bytes, good, hipMemcpyDeviceToHost));
-      if (ff != NO_FAIL) return collect(s, ws, off, info);
-    }
-    return NDI_OK;
+    const T *qx, *qy;
+    stage_queries(s, ws, qx_, qy_, nq, o.q_memspace, &qx, &qy);
+    return eval_body(s, ws, qx, qy, qx_, qy_, o.q_memspace, nq, out_, out_stride, o, info);
   }
 
   ndi_status finish(void* stream, ndi_oob_info* info) override {
@@ -1496,6 +1686,75 @@ struct Interp2DImpl final : Interp2DBase {
     return collect(s, ws, 0, info);
   }
 
+  // ---- ring evaluation (see Interp1DImpl) ---------------------------------------------------
+  struct RingRun {
+    std::unique_lock<std::mutex> own;
+    std::vector<void*> slots;
+    uint64_t pitch = 0, chunk = 0, cq0 = 0;
+    uint32_t n_slots = 0;
+    Plan2 plan0;
+    hipStream_t side = nullptr;
+  };
+
+  void ring_begin(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t nq, const ndi_ring_desc* ring,
+                  uint64_t stride, const ndi_eval_opts& o, RingRun& R) {
+    R.n_slots = ring->n_slots;
+    R.chunk = ring->chunk_queries;
+    R.slots.resize(ring->n_slots);
+    R.pitch = stride;
+    if (ring->slots) {
+      for (uint32_t i = 0; i < ring->n_slots; ++i) R.slots[i] = ring->slots[i];
+    } else {
+      R.own = std::unique_lock<std::mutex>(ring_own.mu);
+      ring_own.ensure(ring->n_slots, ring->chunk_queries, stride * sizeof(T));
+      for (uint32_t i = 0; i < ring->n_slots; ++i) R.slots[i] = (char*)ring_own.buf.p + (size_t)i * stride * sizeof(T);
+      R.pitch = (uint64_t)ring->n_slots * stride;
+    }
+    R.side = ws.side_stream();
+    for (Scratch& sc : ws.sc) sc.ensure_events();
+    NDI_HIP(hipEventRecord(ws.order_event(), s));
+    NDI_HIP(hipStreamWaitEvent(R.side, ws.order_event(), 0));
+    R.cq0 = std::min<uint64_t>(R.chunk, nq);
+    R.plan0 = prep(R.side, ws.sc[0], qx, qy, R.cq0, (T*)R.slots[0], R.pitch, o.path);
+    NDI_HIP(hipEventRecord(ws.sc[0].prep_done, R.side));
+  }
+
+  void ring_produce(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t limit, RingRun& R,
+                    ndi_ring_consumer consume, void* user, const ndi_eval_opts& o, uint64_t q_offset,
+                    uint32_t shard) {
+    std::vector<hipEvent_t> busy(R.n_slots, nullptr);
+    uint64_t k = 0;
+    for (uint64_t off = 0; off < limit; off += R.chunk, ++k) {
+      const uint64_t cq = std::min<uint64_t>(R.chunk, limit - off);
+      const uint32_t slot = (uint32_t)(k % R.n_slots);
+      Scratch& sc = ws.sc[k & 1];
+      Plan2 P = R.plan0;
+      if (k > 0) {
+        if (k >= 2) NDI_HIP(hipStreamWaitEvent(R.side, sc.eval_done, 0));
+        P = prep(R.side, sc, qx + off, qy + off, cq, (T*)R.slots[slot], R.pitch, o.path);
+        NDI_HIP(hipEventRecord(sc.prep_done, R.side));
+      }
+      NDI_HIP(hipStreamWaitEvent(s, sc.prep_done, 0));
+      if (busy[slot]) {
+        NDI_HIP(hipStreamWaitEvent(s, busy[slot], 0));
+        busy[slot] = nullptr;
+      }
+      launch_eval(s, sc, P);
+      NDI_HIP(hipEventRecord(sc.eval_done, s));
+      if (consume) {
+        ndi_ring_chunk c{};
+        c.index = k; c.q_begin = q_offset + off; c.q_count = cq; c.out = R.slots[slot]; c.row_stride = R.pitch;
+        c.slot = slot; c.shard = shard; c.stream = (void*)s;
+        busy[slot] = (hipEvent_t)consume(user, &c);
+      }
+    }
+    NDI_HIP(hipStreamSynchronize(s));
+    NDI_HIP(hipStreamSynchronize(R.side));
+    for (hipEvent_t e : busy)
+      if (e) NDI_HIP(hipEventSynchronize(e));
+    ws.pending = false;
+  }
+
   // Interp2D::interp_array through a device-output ring (see Interp1DImpl::eval_ring).
   ndi_status eval_ring(const void* qx_, const void* qy_, uint64_t nq, const ndi_ring_desc* ring,
                        ndi_ring_consumer consume, void* user, const ndi_eval_opts* opts,
@@ -1504,83 +1763,26 @@ struct Interp2DImpl final : Interp2DBase {
     ndi_eval_opts o{};
     if (opts) o = *opts;
     hipStream_t s = (hipStream_t)o.stream;
-    if (!ring || ring->n_slots == 0 || ring->chunk_queries == 0)
-      return fail(NDI_BAD_ARG, "ring needs n_slots >= 1 and chunk_queries >= 1");
-    const uint64_t stride = ring->row_stride ? ring->row_stride : lanes;
-    if (stride < lanes) return fail(NDI_BAD_ARG, "ring row_stride (%llu) < lanes (%llu)",
-                                    (unsigned long long)stride, (unsigned long long)lanes);
+    uint64_t stride = 0;
+    ndi_status rs = check_ring_desc(ring, lanes, &stride);
+    if (rs != NDI_OK) return rs;
     if (nq == 0) return NDI_OK;
     if (!qx_ || !qy_) return fail(NDI_BAD_ARG, "null query pointer");
     Range rg("ndi_interp2d_eval_ring");
     SpaceLease lease(spaces, s);
     Workspace& ws = lease.ws;
-    const T* qx = (const T*)qx_;
-    const T* qy = (const T*)qy_;
-    if (o.q_memspace == NDI_MEM_HOST) {
-      ws.qdev.reserve(nq * sizeof(T));
-      ws.qdev2.reserve(nq * sizeof(T));
-      NDI_HIP(hipMemcpyAsync(ws.qdev.p, qx_, nq * sizeof(T), hipMemcpyHostToDevice, s));
-      NDI_HIP(hipMemcpyAsync(ws.qdev2.p, qy_, nq * sizeof(T), hipMemcpyHostToDevice, s));
-      qx = ws.qdev.as<T>();
-      qy = ws.qdev2.as<T>();
-    }
-    reset_status(ws, s);
-    StatusBlock* st = ws.status.as<StatusBlock>();
-    {
-      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
-      ProfScope ps(s, PC_LOCATE);
-      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
-                         px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode,
-                         &st->first_fail[0]);
-      NDI_HIP(hipGetLastError());
-      ps.done();
-    }
-    NDI_HIP(hipMemcpyAsync(ws.host_status, ws.status.p, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    const T *qx, *qy;
+    stage_queries(s, ws, qx_, qy_, nq, o.q_memspace, &qx, &qy);
+    enqueue_prepass(s, ws, qx, qy, nq);
+    RingRun R;
+    ring_begin(s, ws, qx, qy, nq, ring, stride, o, R);
     NDI_HIP(hipStreamSynchronize(s));
     const unsigned long long fx = ws.host_status->first_fail[0], fy = ws.host_status->first_fail[1];
     const unsigned long long ff = std::min(fx, fy);
     const uint64_t limit = ff == NO_FAIL ? nq : std::min<uint64_t>(nq, ff);
-
-    std::unique_lock<std::mutex> own(ring_own.mu, std::defer_lock);
-    std::vector<void*> slots(ring->n_slots);
-    uint64_t pitch = stride;          // row pitch of a chunk, in elements
-    if (ring->slots) {
-      for (uint32_t i = 0; i < ring->n_slots; ++i) {
-        if (!ring->slots[i]) return fail(NDI_BAD_ARG, "ring slot %u is null", i);
-        slots[i] = ring->slots[i];
-      }
-    } else {
-      own.lock();    // library-owned ring: one allocation, slots interleaved row by row (see OwnedRing)
-      ring_own.ensure(ring->n_slots, ring->chunk_queries, stride * sizeof(T));
-      for (uint32_t i = 0; i < ring->n_slots; ++i) slots[i] = (char*)ring_own.buf.p + (size_t)i * stride * sizeof(T);
-      pitch = (uint64_t)ring->n_slots * stride;
-    }
-    std::vector<hipEvent_t> busy(ring->n_slots, nullptr);
-    uint64_t k = 0;
-    for (uint64_t off = 0; off < limit; off += ring->chunk_queries, ++k) {
-      const uint64_t cq = std::min<uint64_t>(ring->chunk_queries, limit - off);
-      const uint32_t slot = (uint32_t)(k % ring->n_slots);
-      if (busy[slot]) {
-        NDI_HIP(hipStreamWaitEvent(s, busy[slot], 0));
-        busy[slot] = nullptr;
-      }
-      enqueue(s, ws, qx + off, qy + off, cq, (T*)slots[slot], pitch, o.path);
-      if (consume) {
-        ndi_ring_chunk c{};
-        c.index = k; c.q_begin = off; c.q_count = cq; c.out = slots[slot]; c.row_stride = pitch;
-        c.slot = slot; c.stream = (void*)s;
-        busy[slot] = (hipEvent_t)consume(user, &c);
-      }
-    }
-    NDI_HIP(hipStreamSynchronize(s));
-    for (hipEvent_t e : busy)
-      if (e) NDI_HIP(hipEventSynchronize(e));
-    ws.pending = false;
+    ring_produce(s, ws, qx, qy, limit, R, consume, user, o, 0, 0);
     if (ff == NO_FAIL) return NDI_OK;
-    ws.last_q = qx_;
-    ws.last_q2 = qy_;
-    ws.last_q_space = o.q_memspace;
-    return report(ws, fx, fy, 0, info);
+    return report(qx_, qy_, o.q_memspace, fx, fy, 0, info);
   }
 
   ndi_status trim() override {
@@ -1682,10 +1884,10 @@ struct LocatorImpl final : LocatorBase {
       SpaceLease lease(spaces, s);
       Workspace& ws = lease.ws;
       ws.qdev.reserve(nq * sizeof(T));
-      ws.stage[0].reserve(nq * sizeof(int64_t));
+      ws.stage.reserve(nq * sizeof(int64_t));
       NDI_HIP(hipMemcpyAsync(ws.qdev.p, q, nq * sizeof(T), hipMemcpyHostToDevice, s));
       qdev = ws.qdev.as<T>();
-      odev = ws.stage[0].as<int64_t>();
+      odev = ws.stage.as<int64_t>();
       run_locate<T>(s, pyr, qdev, nq, nullptr, odev, nullptr, nullptr, EX_YES);
       NDI_HIP(hipMemcpyAsync(out_idx, odev, nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
       NDI_HIP(hipStreamSynchronize(s));
@@ -1709,6 +1911,273 @@ static ndi_status create_locator(int device, const void* knots, uint64_t n, int 
   h->pyr.upload(x.data(), n);
   *out = h.release();
   return NDI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sharded evaluation: one call, N handles (normally one per device), one host thread per shard
+// ---------------------------------------------------------------------------------------------
+// The reference's multi-worker shape is one interpolator driven from many threads over contiguous blocks of the
+// query array (benches/bench_interp1d.rs:49-79).  Here shard i of n evaluates the block shard_range(nq, i, n) on
+// handles[i]'s device.  The reference's first-error result (interp1d/mod.rs:326-343) is reproduced across shards:
+// every shard range-checks its block first, the minimum global failing index F is agreed on at a host barrier, and
+// only the rows [0, F) are produced -- later rows are never written.  No device-to-device traffic.
+static void shard_range(uint64_t nq, uint32_t i, uint32_t n, uint64_t* lo, uint64_t* hi) {
+  const uint64_t base = nq / n, rem = nq % n;
+  *lo = (uint64_t)i * base + std::min<uint64_t>(i, rem);
+  *hi = *lo + base + (i < rem ? 1 : 0);
+}
+static uint64_t shard_lo(uint64_t nq, uint32_t i, uint32_t n) {
+  uint64_t lo, hi;
+  shard_range(nq, i, n, &lo, &hi);
+  return lo;
+}
+
+struct ShardBarrier {
+  std::mutex m;
+  std::condition_variable cv;
+  unsigned n, count = 0, gen = 0;
+  explicit ShardBarrier(unsigned n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> l(m);
+    const unsigned g = gen;
+    if (++count == n) {
+      count = 0;
+      ++gen;
+      cv.notify_all();
+    } else {
+      cv.wait(l, [&] { return g != gen; });
+    }
+  }
+};
+
+struct ShardOutcome {
+  ndi_status st = NDI_OK;
+  std::string msg;
+};
+
+// Shard: constructed on the worker thread (the scratch lease is keyed by the thread), pre() = upload + range
+// pre-pass (+ the ring's speculative first chunk), run(limit) = produce the shard's first `limit` rows.
+template <class Shard, class Job>
+static void run_shards(const Job& job, uint32_t n, std::vector<ShardOutcome>& out, unsigned long long F[2]) {
+  ShardBarrier bar(n);
+  std::atomic<unsigned long long> fx{NO_FAIL}, fy{NO_FAIL};
+  std::atomic<int> broken{0};
+  auto amin = [](std::atomic<unsigned long long>& a, unsigned long long v) {
+    unsigned long long c = a.load();
+    while (v < c && !a.compare_exchange_weak(c, v)) {
+    }
+  };
+  auto work = [&](uint32_t i) {
+    bool arrived = false;
+    try {
+      Shard c(job, i, n);
+      unsigned long long lx = NO_FAIL, ly = NO_FAIL;
+      c.pre(&lx, &ly);
+      if (lx != NO_FAIL) amin(fx, c.lo + lx);
+      if (ly != NO_FAIL) amin(fy, c.lo + ly);
+      arrived = true;
+      bar.wait();
+      const unsigned long long f = std::min(fx.load(), fy.load());
+      const uint64_t limit = broken.load() ? 0 : (f <= c.lo ? 0 : std::min<uint64_t>(c.cnt, f - c.lo));
+      const ndi_status st = c.run(limit);
+      if (st != NDI_OK) {
+        out[i].st = st;
+        out[i].msg = tls_error();
+      }
+    } catch (const HipFailure& f) {
+      out[i].st = from_hip(f);
+      out[i].msg = tls_error();
+      broken.store(1);
+    } catch (const std::bad_alloc&) {
+      out[i].st = NDI_HIP_ERROR;
+      out[i].msg = "host out of memory";
+      broken.store(1);
+    } catch (...) {
+      out[i].st = NDI_HIP_ERROR;
+      out[i].msg = "unexpected C++ exception";
+      broken.store(1);
+    }
+    if (!arrived) bar.wait();
+  };
+  std::vector<std::thread> th;
+  th.reserve(n);
+  for (uint32_t i = 1; i < n; ++i) th.emplace_back(work, i);
+  work(0);   // shard 0 runs on the calling thread
+  for (auto& t : th) t.join();
+  F[0] = fx.load();
+  F[1] = fy.load();
+}
+
+template <class T>
+struct Job1 {
+  std::vector<Interp1DImpl<T>*> H;
+  const void* q;
+  uint64_t nq;
+  const ndi_shard_io* io;
+  uint64_t out_stride;
+  const ndi_ring_desc* rings;
+  ndi_ring_consumer consume;
+  void* user;
+  ndi_eval_opts o;
+  const void* q_src(uint32_t i, uint32_t n) const {
+    return (io && io[i].q) ? io[i].q : (const void*)((const T*)q + shard_lo(nq, i, n));
+  }
+};
+
+template <class T>
+struct Shard1 {
+  const Job1<T>& J;
+  uint32_t i;
+  Interp1DImpl<T>* h;
+  uint64_t lo, cnt;
+  DeviceGuard dg;
+  hipStream_t s;
+  SpaceLease lease;
+  Workspace& ws;
+  const void* q_src;
+  const T* q = nullptr;
+  uint64_t stride = 0;
+  typename Interp1DImpl<T>::RingRun R;
+  Shard1(const Job1<T>& j, uint32_t i_, uint32_t n)
+      : J(j), i(i_), h(j.H[i_]), lo(shard_lo(j.nq, i_, n)), cnt(shard_lo(j.nq, i_ + 1, n) - shard_lo(j.nq, i_, n)),
+        dg(h->device), s((hipStream_t)(j.io ? j.io[i_].stream : nullptr)), lease(h->spaces, s), ws(lease.ws),
+        q_src(j.q_src(i_, n)) {}
+  void pre(unsigned long long* fx, unsigned long long*) {
+    if (!cnt) return;
+    q = h->stage_queries(s, ws, q_src, cnt, J.o.q_memspace);
+    h->enqueue_prepass(s, ws, q, cnt);
+    if (J.rings) {
+      (void)check_ring_desc(&J.rings[i], h->lanes, &stride);   // validated before the threads started
+      h->ring_begin(s, ws, q, cnt, &J.rings[i], stride, J.o, R);
+    }
+    NDI_HIP(hipStreamSynchronize(s));
+    *fx = ws.host_status->first_fail[0];
+  }
+  ndi_status run(uint64_t limit) {
+    if (!cnt) return NDI_OK;
+    if (J.rings) {
+      h->ring_produce(s, ws, q, limit, R, J.consume, J.user, J.o, lo, i);
+      return NDI_OK;
+    }
+    if (!limit) return NDI_OK;
+    ndi_eval_opts o = J.o;
+    o.async_launch = 0;
+    ndi_oob_info none{};
+    return h->eval_body(s, ws, q, q_src, J.o.q_memspace, limit, J.io[i].out, J.out_stride, o, &none);
+  }
+};
+
+template <class T>
+struct Job2 {
+  std::vector<Interp2DImpl<T>*> H;
+  const void* qx;
+  const void* qy;
+  uint64_t nq;
+  const ndi_shard_io* io;
+  uint64_t out_stride;
+  const ndi_ring_desc* rings;
+  ndi_ring_consumer consume;
+  void* user;
+  ndi_eval_opts o;
+  const void* qx_src(uint32_t i, uint32_t n) const {
+    return (io && io[i].q) ? io[i].q : (const void*)((const T*)qx + shard_lo(nq, i, n));
+  }
+  const void* qy_src(uint32_t i, uint32_t n) const {
+    return (io && io[i].q) ? io[i].qy : (const void*)((const T*)qy + shard_lo(nq, i, n));
+  }
+};
+
+template <class T>
+struct Shard2 {
+  const Job2<T>& J;
+  uint32_t i;
+  Interp2DImpl<T>* h;
+  uint64_t lo, cnt;
+  DeviceGuard dg;
+  hipStream_t s;
+  SpaceLease lease;
+  Workspace& ws;
+  const void* qx_src;
+  const void* qy_src;
+  const T* qx = nullptr;
+  const T* qy = nullptr;
+  uint64_t stride = 0;
+  typename Interp2DImpl<T>::RingRun R;
+  Shard2(const Job2<T>& j, uint32_t i_, uint32_t n)
+      : J(j), i(i_), h(j.H[i_]), lo(shard_lo(j.nq, i_, n)), cnt(shard_lo(j.nq, i_ + 1, n) - shard_lo(j.nq, i_, n)),
+        dg(h->device), s((hipStream_t)(j.io ? j.io[i_].stream : nullptr)), lease(h->spaces, s), ws(lease.ws),
+        qx_src(j.qx_src(i_, n)), qy_src(j.qy_src(i_, n)) {}
+  void pre(unsigned long long* fx, unsigned long long* fy) {
+    if (!cnt) return;
+    h->stage_queries(s, ws, qx_src, qy_src, cnt, J.o.q_memspace, &qx, &qy);
+    h->enqueue_prepass(s, ws, qx, qy, cnt);
+    if (J.rings) {
+      (void)check_ring_desc(&J.rings[i], h->lanes, &stride);
+      h->ring_begin(s, ws, qx, qy, cnt, &J.rings[i], stride, J.o, R);
+    }
+    NDI_HIP(hipStreamSynchronize(s));
+    *fx = ws.host_status->first_fail[0];
+    *fy = ws.host_status->first_fail[1];
+  }
+  ndi_status run(uint64_t limit) {
+    if (!cnt) return NDI_OK;
+    if (J.rings) {
+      h->ring_produce(s, ws, qx, qy, limit, R, J.consume, J.user, J.o, lo, i);
+      return NDI_OK;
+    }
+    if (!limit) return NDI_OK;
+    ndi_eval_opts o = J.o;
+    o.async_launch = 0;
+    ndi_oob_info none{};
+    return h->eval_body(s, ws, qx, qy, qx_src, qy_src, J.o.q_memspace, limit, J.io[i].out, J.out_stride, o, &none);
+  }
+};
+
+// Outcome of a sharded call on the calling thread: a device failure of any shard wins (lowest shard first);
+// otherwise the reference's first-error result for the global index F, reported by the shard that owns it.
+static ndi_status shards_failed(const std::vector<ShardOutcome>& out) {
+  for (size_t i = 0; i < out.size(); ++i)
+    if (out[i].st != NDI_OK) return fail(out[i].st, "shard %zu: %s", i, out[i].msg.c_str());
+  return NDI_OK;
+}
+static uint32_t shard_owner(uint64_t nq, uint32_t n, uint64_t index) {
+  for (uint32_t i = 0; i < n; ++i) {
+    uint64_t lo, hi;
+    shard_range(nq, i, n, &lo, &hi);
+    if (index >= lo && index < hi) return i;
+  }
+  return n - 1;
+}
+
+template <class T>
+static ndi_status sharded1d(Job1<T>& J, ndi_oob_info* info) {
+  const uint32_t n = (uint32_t)J.H.size();
+  std::vector<ShardOutcome> out(n);
+  unsigned long long F[2];
+  run_shards<Shard1<T>>(J, n, out, F);
+  ndi_status st = shards_failed(out);
+  if (st != NDI_OK || F[0] == NO_FAIL) return st;
+  const uint32_t w = shard_owner(J.nq, n, F[0]);
+  const uint64_t lo = shard_lo(J.nq, w, n);
+  DeviceGuard dg(J.H[w]->device);
+  return J.H[w]->report(J.q_src(w, n), J.o.q_memspace, F[0] - lo, lo, info);
+}
+
+template <class T>
+static ndi_status sharded2d(Job2<T>& J, ndi_oob_info* info) {
+  const uint32_t n = (uint32_t)J.H.size();
+  std::vector<ShardOutcome> out(n);
+  unsigned long long F[2];
+  run_shards<Shard2<T>>(J, n, out, F);
+  ndi_status st = shards_failed(out);
+  const unsigned long long f = std::min(F[0], F[1]);
+  if (st != NDI_OK || f == NO_FAIL) return st;
+  const uint32_t w = shard_owner(J.nq, n, f);
+  const uint64_t lo = shard_lo(J.nq, w, n);
+  DeviceGuard dg(J.H[w]->device);
+  // indices relative to the owner's block; an axis whose first failure lies in a later shard stays larger
+  const unsigned long long lx = F[0] == NO_FAIL ? NO_FAIL : F[0] - lo, ly = F[1] == NO_FAIL ? NO_FAIL : F[1] - lo;
+  return J.H[w]->report(J.qx_src(w, n), J.qy_src(w, n), J.o.q_memspace, lx, ly, lo, info);
 }
 
 }  // namespace ndi
@@ -1857,6 +2326,147 @@ NDI_API ndi_status ndi_interp2d_eval_ring(const ndi_interp2d* h, const void* qx,
   if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
   NDI_TRY
   return h->impl->eval_ring(qx, qy, nq, ring, consume, user, opts, info);
+  NDI_CATCH
+}
+
+// ---- sharded evaluation ------------------------------------------------------------------------
+NDI_API void ndi_shard_bounds(uint64_t nq, uint32_t shard, uint32_t n_shards, uint64_t* lo, uint64_t* hi) {
+  uint64_t l = 0, h = 0;
+  if (n_shards && shard < n_shards) ndi::shard_range(nq, shard, n_shards, &l, &h);
+  if (lo) *lo = l;
+  if (hi) *hi = h;
+}
+
+template <class Impl, class Handle>
+static ndi_status gather_handles(const Handle* const* handles, uint32_t n, int dtype, std::vector<Impl*>& out) {
+  out.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (handles[i]->impl->dtype != dtype || handles[i]->impl->lanes != handles[0]->impl->lanes)
+      return ndi::fail(NDI_BAD_ARG, "shard %u: the handles of a sharded call must be replicas (same element type "
+                       "and trailing lanes)", i);
+    out[i] = static_cast<Impl*>(handles[i]->impl);
+  }
+  return NDI_OK;
+}
+
+template <class Handle>
+static ndi_status check_sharded_args(const Handle* const* handles, uint32_t n, const void* q, const void* qy,
+                                     bool two_d, uint64_t nq, const ndi_shard_io* io, bool need_out,
+                                     const ndi_ring_desc* rings, bool need_rings, uint64_t out_stride) {
+  if (!handles || n == 0) return ndi::fail(NDI_BAD_ARG, "a sharded call needs at least one handle");
+  for (uint32_t i = 0; i < n; ++i)
+    if (!handles[i]) return ndi::fail(NDI_BAD_ARG, "shard %u: null handle", i);
+  for (uint32_t i = 0; i < n; ++i)
+    for (uint32_t j = 0; j < i; ++j)
+      if (handles[i] == handles[j]) return ndi::fail(NDI_BAD_ARG, "shards %u and %u share one handle", j, i);
+  const uint64_t lanes = handles[0]->impl->lanes;
+  if (need_out && !io) return ndi::fail(NDI_BAD_ARG, "null shard io array");
+  if (need_out && out_stride < lanes)
+    return ndi::fail(NDI_BAD_ARG, "out_row_stride (%llu) < lanes (%llu)", (unsigned long long)out_stride,
+                     (unsigned long long)lanes);
+  if (need_rings && !rings) return ndi::fail(NDI_BAD_ARG, "null ring array");
+  for (uint32_t i = 0; i < n && nq; ++i) {
+    uint64_t lo, hi;
+    ndi::shard_range(nq, i, n, &lo, &hi);
+    const bool own_q = io && io[i].q;
+    if (two_d && io && ((io[i].q != nullptr) != (io[i].qy != nullptr)))
+      return ndi::fail(NDI_BAD_ARG, "shard %u: q and qy must be given together", i);
+    if (!own_q && (!q || (two_d && !qy))) return ndi::fail(NDI_BAD_ARG, "null query pointer");
+    if (need_out && hi > lo && !io[i].out) return ndi::fail(NDI_BAD_ARG, "shard %u: null output pointer", i);
+    if (need_rings) {
+      uint64_t stride = 0;
+      ndi_status st = ndi::check_ring_desc(&rings[i], lanes, &stride);
+      if (st != NDI_OK) return st;
+    }
+  }
+  return NDI_OK;
+}
+
+NDI_API ndi_status ndi_interp1d_eval_sharded(const ndi_interp1d* const* handles, uint32_t n_shards, const void* q,
+                                             uint64_t nq, const ndi_shard_io* io, uint64_t out_row_stride,
+                                             const ndi_eval_opts* opts, ndi_oob_info* info) {
+  ndi_status st = check_sharded_args(handles, n_shards, q, nullptr, false, nq, io, true, nullptr, false, out_row_stride);
+  if (st != NDI_OK || nq == 0) return st;
+  NDI_TRY
+  ndi::Range rg("ndi_interp1d_eval_sharded");
+  const int dtype = handles[0]->impl->dtype;
+  ndi_eval_opts o{};
+  if (opts) o = *opts;
+  if (dtype == NDI_F32) {
+    ndi::Job1<float> J{{}, q, nq, io, out_row_stride, nullptr, nullptr, nullptr, o};
+    st = gather_handles(handles, n_shards, dtype, J.H);
+    return st != NDI_OK ? st : ndi::sharded1d<float>(J, info);
+  }
+  ndi::Job1<double> J{{}, q, nq, io, out_row_stride, nullptr, nullptr, nullptr, o};
+  st = gather_handles(handles, n_shards, dtype, J.H);
+  return st != NDI_OK ? st : ndi::sharded1d<double>(J, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp1d_eval_ring_sharded(const ndi_interp1d* const* handles, uint32_t n_shards,
+                                                  const void* q, uint64_t nq, const ndi_shard_io* io,
+                                                  const ndi_ring_desc* rings, ndi_ring_consumer consume, void* user,
+                                                  const ndi_eval_opts* opts, ndi_oob_info* info) {
+  ndi_status st = check_sharded_args(handles, n_shards, q, nullptr, false, nq, io, false, rings, true, 0);
+  if (st != NDI_OK || nq == 0) return st;
+  NDI_TRY
+  ndi::Range rg("ndi_interp1d_eval_ring_sharded");
+  const int dtype = handles[0]->impl->dtype;
+  ndi_eval_opts o{};
+  if (opts) o = *opts;
+  if (dtype == NDI_F32) {
+    ndi::Job1<float> J{{}, q, nq, io, 0, rings, consume, user, o};
+    st = gather_handles(handles, n_shards, dtype, J.H);
+    return st != NDI_OK ? st : ndi::sharded1d<float>(J, info);
+  }
+  ndi::Job1<double> J{{}, q, nq, io, 0, rings, consume, user, o};
+  st = gather_handles(handles, n_shards, dtype, J.H);
+  return st != NDI_OK ? st : ndi::sharded1d<double>(J, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp2d_eval_sharded(const ndi_interp2d* const* handles, uint32_t n_shards, const void* qx,
+                                             const void* qy, uint64_t nq, const ndi_shard_io* io,
+                                             uint64_t out_row_stride, const ndi_eval_opts* opts,
+                                             ndi_oob_info* info) {
+  ndi_status st = check_sharded_args(handles, n_shards, qx, qy, true, nq, io, true, nullptr, false, out_row_stride);
+  if (st != NDI_OK || nq == 0) return st;
+  NDI_TRY
+  ndi::Range rg("ndi_interp2d_eval_sharded");
+  const int dtype = handles[0]->impl->dtype;
+  ndi_eval_opts o{};
+  if (opts) o = *opts;
+  if (dtype == NDI_F32) {
+    ndi::Job2<float> J{{}, qx, qy, nq, io, out_row_stride, nullptr, nullptr, nullptr, o};
+    st = gather_handles(handles, n_shards, dtype, J.H);
+    return st != NDI_OK ? st : ndi::sharded2d<float>(J, info);
+  }
+  ndi::Job2<double> J{{}, qx, qy, nq, io, out_row_stride, nullptr, nullptr, nullptr, o};
+  st = gather_handles(handles, n_shards, dtype, J.H);
+  return st != NDI_OK ? st : ndi::sharded2d<double>(J, info);
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp2d_eval_ring_sharded(const ndi_interp2d* const* handles, uint32_t n_shards,
+                                                  const void* qx, const void* qy, uint64_t nq,
+                                                  const ndi_shard_io* io, const ndi_ring_desc* rings,
+                                                  ndi_ring_consumer consume, void* user, const ndi_eval_opts* opts,
+                                                  ndi_oob_info* info) {
+  ndi_status st = check_sharded_args(handles, n_shards, qx, qy, true, nq, io, false, rings, true, 0);
+  if (st != NDI_OK || nq == 0) return st;
+  NDI_TRY
+  ndi::Range rg("ndi_interp2d_eval_ring_sharded");
+  const int dtype = handles[0]->impl->dtype;
+  ndi_eval_opts o{};
+  if (opts) o = *opts;
+  if (dtype == NDI_F32) {
+    ndi::Job2<float> J{{}, qx, qy, nq, io, 0, rings, consume, user, o};
+    st = gather_handles(handles, n_shards, dtype, J.H);
+    return st != NDI_OK ? st : ndi::sharded2d<float>(J, info);
+  }
+  ndi::Job2<double> J{{}, qx, qy, nq, io, 0, rings, consume, user, o};
+  st = gather_handles(handles, n_shards, dtype, J.H);
+  return st != NDI_OK ? st : ndi::sharded2d<double>(J, info);
   NDI_CATCH
 }
 

@@ -19,6 +19,7 @@
 #include <exception>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <string>
@@ -95,6 +96,26 @@ inline std::string shape_str(const std::vector<size_t>& s) {
   return r + "]";
 }
 }  // namespace detail
+
+// ---- device selection ---------------------------------------------------------------------------------
+// The reference has no notion of a device; this mirror adds one build-side option (SURVEY 5 "config / flags"):
+// every built-in strategy builder has `.device(ordinal)`, and builders that are not told use `current_device()`,
+// a per-thread default (0 unless `set_current_device` was called) -- so a worker thread that owns device d can
+// call `set_current_device(d)` once and build unchanged code.
+namespace detail {
+inline int& tls_device() {
+  static thread_local int d = 0;
+  return d;
+}
+}  // namespace detail
+inline int current_device() { return detail::tls_device(); }
+inline void set_current_device(int ordinal) {
+  if (ordinal < 0 || ordinal >= ndi_device_count())
+    throw DeviceError("device ordinal " + std::to_string(ordinal) + " out of range [0, " +
+                      std::to_string(ndi_device_count()) + ")");
+  detail::tls_device() = ordinal;
+}
+inline int device_count() { return ndi_device_count(); }
 
 // ---- a minimal owned C-order n-d array (the host "ndarray") --------------------------------------
 template <class T>
@@ -182,7 +203,8 @@ Monotonic monotonic_prop(const std::vector<T>& v) {
   }
 }
 template <class T>
-std::vector<int64_t> get_lower_index(const std::vector<T>& knots, const std::vector<T>& xs, int device = 0) {
+std::vector<int64_t> get_lower_index(const std::vector<T>& knots, const std::vector<T>& xs, int device = -1) {
+  if (device < 0) device = current_device();
   std::vector<int64_t> out(xs.size());
   if constexpr (!std::is_same_v<T, float> && !std::is_same_v<T, double>) {
     for (size_t i = 0; i < xs.size(); ++i) out[i] = (int64_t)detail::lower_index_generic(knots, xs[i]);
@@ -199,7 +221,8 @@ template <class T>
 class Locator {
   ndi_locator* h_ = nullptr;
  public:
-  explicit Locator(const std::vector<T>& knots, int device = 0) {
+  explicit Locator(const std::vector<T>& knots, int device = -1) {
+    if (device < 0) device = current_device();
     int st = ndi_locator_create(detail::DType<T>::id, device, knots.data(), knots.size(), NDI_MEM_HOST, &h_);
     if (st != NDI_OK) throw DeviceError(ndi_last_error_string());
   }
@@ -293,9 +316,11 @@ struct Device1D : Interp1DStrategy<T> {  // owns an ndi_interp1d*
   ndi_interp1d* h = nullptr;
   size_t lanes = 1;
   int path = NDI_PATH_AUTO;
+  int device = 0;   // the HIP device that holds the tables
   ~Device1D() override { ndi_interp1d_destroy(h); }
   void create(const std::vector<T>& x, const Array<T>& data, int strategy, bool extrapolate, bool periodic,
-              ndi_boundary left, ndi_boundary right, int device, const std::vector<RowBoundary>* rows = nullptr) {
+              ndi_boundary left, ndi_boundary right, int device_, const std::vector<RowBoundary>* rows = nullptr) {
+    device = device_;
     ndi_interp1d_desc d{};
     std::vector<int32_t> lk, rk;
     std::vector<double> lv, rv;
@@ -342,10 +367,12 @@ using RingChunk = ndi_ring_chunk;
 template <class T>
 class Linear : public Interp1DStrategyBuilder<T> {
   bool extrapolate_ = false;
+  int device_ = -1;   // -1: current_device() at build time
  public:
   static Linear new_() { return Linear(); }
   Linear extrapolate(bool e) && { extrapolate_ = e; return std::move(*this); }
   Linear& extrapolate(bool e) & { extrapolate_ = e; return *this; }
+  Linear device(int ordinal) && { device_ = ordinal; return std::move(*this); }
   size_t MINIMUM_DATA_LENGHT() const override { return 2; }  // linear.rs:52
   std::shared_ptr<Interp1DStrategy<T>> build(const std::vector<T>& x, const Array<T>& data) override {
     if constexpr (!std::is_same_v<T, float> && !std::is_same_v<T, double>) {
@@ -354,7 +381,7 @@ class Linear : public Interp1DStrategyBuilder<T> {
       return s;
     } else {
       auto s = std::make_shared<detail::Device1D<T>>();
-      s->create(x, data, NDI_LINEAR, extrapolate_, false, {0, 0.0}, {0, 0.0}, 0);
+      s->create(x, data, NDI_LINEAR, extrapolate_, false, {0, 0.0}, {0, 0.0}, device_ >= 0 ? device_ : current_device());
       return s;
     }
   }
@@ -364,15 +391,18 @@ template <class T>
 class CubicSpline : public Interp1DStrategyBuilder<T> {  // cubic_spline.rs:85-88, 723-771
   bool extrapolate_ = false;
   BoundaryCondition boundary_ = BoundaryCondition::NotAKnot();  // default :724-729
+  int device_ = -1;   // -1: current_device() at build time
  public:
   static CubicSpline new_() { return CubicSpline(); }
   CubicSpline extrapolate(bool e) && { extrapolate_ = e; return std::move(*this); }
+  CubicSpline device(int ordinal) && { device_ = ordinal; return std::move(*this); }
   CubicSpline boundary(BoundaryCondition b) && { boundary_ = b; return std::move(*this); }
   size_t MINIMUM_DATA_LENGHT() const override { return 3; }  // cubic_spline.rs:751
   std::shared_ptr<Interp1DStrategy<T>> build(const std::vector<T>& x, const Array<T>& data) override {
     static_assert(std::is_same_v<T, float> || std::is_same_v<T, double>,
                   "CubicSpline needs a float element type (the reference's trait bounds: Pow / Euclid on T)");
     auto s = std::make_shared<detail::Device1D<T>>();
+    const int dev = device_ >= 0 ? device_ : current_device();
     if (!boundary_.rows.empty() || !boundary_.rows_shape.empty()) {   // Individual: shape [1, data.shape[1..]] (:332-340)
       std::vector<size_t> expect{1};
       expect.insert(expect.end(), data.shape.begin() + 1, data.shape.end());
@@ -380,11 +410,11 @@ class CubicSpline : public Interp1DStrategyBuilder<T> {  // cubic_spline.rs:85-8
         throw BuilderError(BuilderError::ShapeError, "Boundary conditions array has wrong shape. Expected: " +
                                                          detail::shape_str(expect) + ", got: " +
                                                          detail::shape_str(boundary_.rows_shape));
-      s->create(x, data, NDI_CUBIC_SPLINE, extrapolate_, false, {0, 0.0}, {0, 0.0}, 0, &boundary_.rows);
+      s->create(x, data, NDI_CUBIC_SPLINE, extrapolate_, false, {0, 0.0}, {0, 0.0}, dev, &boundary_.rows);
       return s;
     }
     s->create(x, data, NDI_CUBIC_SPLINE, extrapolate_, boundary_.periodic,
-              {boundary_.left.kind, boundary_.left.value}, {boundary_.right.kind, boundary_.right.value}, 0);
+              {boundary_.left.kind, boundary_.left.value}, {boundary_.right.kind, boundary_.right.value}, dev);
     return s;
   }
 };
@@ -548,6 +578,7 @@ template <class T>
 struct Device2D : Interp2DStrategy<T> {
   ndi_interp2d* h = nullptr;
   size_t lanes = 1;
+  int device = 0;
   ~Device2D() override { ndi_interp2d_destroy(h); }
   void interp_array_into(const Interp2D<T>&, const T* xs, const T* ys, size_t nq, T* out,
                          size_t row_stride) const override {
@@ -572,9 +603,11 @@ struct HostBilinear : Interp2DStrategy<T> {
 template <class T>
 class Bilinear : public Interp2DStrategyBuilder<T> {  // src/interp2d/strategies/bilinear.rs
   bool extrapolate_ = false;
+  int device_ = -1;   // -1: current_device() at build time
  public:
   static Bilinear new_() { return Bilinear(); }
   Bilinear extrapolate(bool yes) && { extrapolate_ = yes; return std::move(*this); }
+  Bilinear device(int ordinal) && { device_ = ordinal; return std::move(*this); }
   size_t MINIMUM_DATA_LENGHT() const override { return 2; }  // bilinear.rs:41
   std::shared_ptr<Interp2DStrategy<T>> build(const std::vector<T>& x, const std::vector<T>& y,
                                              const Array<T>& data) override {
@@ -585,7 +618,8 @@ class Bilinear : public Interp2DStrategyBuilder<T> {  // src/interp2d/strategies
     } else {
       auto s = std::make_shared<detail::Device2D<T>>();
       ndi_interp2d_desc d{};
-      d.dtype = detail::DType<T>::id; d.extrapolate = extrapolate_; d.device = 0; d.memspace = NDI_MEM_HOST;
+      s->device = device_ >= 0 ? device_ : current_device();
+      d.dtype = detail::DType<T>::id; d.extrapolate = extrapolate_; d.device = s->device; d.memspace = NDI_MEM_HOST;
       d.nx = data.shape[0]; d.ny = data.shape[1]; d.lanes = s->lanes = detail::prod(data.shape, 2);
       d.x_len = x.size(); d.y_len = y.size(); d.x = x.data(); d.y = y.data(); d.data = data.data.data();
       d.validate = 0;
@@ -717,5 +751,122 @@ class Interp2DBuilder {  // interp2d/mod.rs:52-64, 382-519
     return ip;
   }
 };
+
+// =================================================================================================
+// several devices, one call (ndi_interp{1,2}d_eval_sharded / _eval_ring_sharded)
+// =================================================================================================
+// `replicas`: interpolators built from the same arrays, one per device (`.device(d)` on the strategy builder).
+// The flattened query array is split into contiguous blocks (ndi_shard_bounds), every block is evaluated by its own
+// host thread inside the library on its replica's device, and the result is what the reference's serial loop over
+// the whole batch gives (interp1d/mod.rs:326-343): on Err the exception names the global flat index, rows before
+// it are written, later rows are untouched.  The reference's multi-worker shape is benches/bench_interp1d.rs:49-79.
+inline std::pair<size_t, size_t> shard_bounds(size_t nq, unsigned shard, unsigned n_shards) {
+  uint64_t lo = 0, hi = 0;
+  ndi_shard_bounds(nq, shard, n_shards, &lo, &hi);
+  return {(size_t)lo, (size_t)hi};
+}
+
+template <class T>
+void interp_array_into_sharded(const std::vector<const Interp1D<T>*>& replicas, const Array<T>& xs, Array<T>& buffer) {
+  if (replicas.empty()) throw Panic("interp_array_sharded needs at least one replica");
+  const auto expect = replicas[0]->get_buffer_shape(xs.shape);
+  if (buffer.shape != expect)
+    throw Panic("incompatible shapes expected: " + detail::shape_str(expect) + ", got: " + detail::shape_str(buffer.shape));
+  const size_t n = replicas.size(), lanes = replicas[0]->lanes(), nq = xs.len();
+  std::vector<const ndi_interp1d*> hs(n);
+  std::vector<ndi_shard_io> io(n);
+  for (size_t i = 0; i < n; ++i) {
+    auto dev = std::dynamic_pointer_cast<detail::Device1D<T>>(replicas[i]->strategy);
+    if (!dev) throw Panic("interp_array_sharded needs built-in device strategies (f32 / f64 data)");
+    hs[i] = dev->h;
+    io[i] = ndi_shard_io{nullptr, nullptr, buffer.data.data() + shard_bounds(nq, (unsigned)i, (unsigned)n).first * lanes, nullptr};
+  }
+  ndi_eval_opts o{};
+  o.q_memspace = NDI_MEM_HOST; o.out_memspace = NDI_MEM_HOST;
+  o.path = std::dynamic_pointer_cast<detail::Device1D<T>>(replicas[0]->strategy)->path;
+  ndi_oob_info info{};
+  int st = ndi_interp1d_eval_sharded(hs.data(), (uint32_t)n, xs.data.data(), nq, io.data(), lanes, &o, &info);
+  if (st != NDI_OK) detail::throw_eval(st, info);
+}
+template <class T>
+Array<T> interp_array_sharded(const std::vector<const Interp1D<T>*>& replicas, const Array<T>& xs) {
+  if (replicas.empty()) throw Panic("interp_array_sharded needs at least one replica");
+  Array<T> ys(replicas[0]->get_buffer_shape(xs.shape));
+  interp_array_into_sharded(replicas, xs, ys);
+  return ys;
+}
+
+// The ring evaluation over several devices: every replica streams its block through its own library-owned ring
+// of `n_slots` slots; `consume` is called concurrently from the shards' host threads (chunk.shard names the shard,
+// chunk.q_begin is the global flat index).
+template <class T>
+void interp_array_ring_sharded(const std::vector<const Interp1D<T>*>& replicas, const Array<T>& xs,
+                               size_t chunk_queries, unsigned n_slots,
+                               const std::function<void*(const RingChunk&)>& consume) {
+  const size_t n = replicas.size();
+  if (!n) throw Panic("interp_array_ring_sharded needs at least one replica");
+  std::vector<const ndi_interp1d*> hs(n);
+  std::vector<ndi_ring_desc> rings(n);
+  for (size_t i = 0; i < n; ++i) {
+    auto dev = std::dynamic_pointer_cast<detail::Device1D<T>>(replicas[i]->strategy);
+    if (!dev) throw Panic("interp_array_ring_sharded needs built-in device strategies (f32 / f64 data)");
+    hs[i] = dev->h;
+    rings[i] = ndi_ring_desc{};
+    rings[i].n_slots = n_slots;
+    rings[i].chunk_queries = chunk_queries;
+  }
+  ndi_eval_opts o{};
+  o.q_memspace = NDI_MEM_HOST; o.out_memspace = NDI_MEM_DEVICE;
+  o.path = std::dynamic_pointer_cast<detail::Device1D<T>>(replicas[0]->strategy)->path;
+  ndi_oob_info info{};
+  struct Ctx { const std::function<void*(const RingChunk&)>* fn; std::mutex mu; std::exception_ptr err; } ctx{&consume, {}, nullptr};
+  auto tramp = [](void* user, const ndi_ring_chunk* c) -> void* {
+    Ctx* cx = static_cast<Ctx*>(user);
+    {
+      std::lock_guard<std::mutex> g(cx->mu);
+      if (cx->err) return nullptr;
+    }
+    try { return (*cx->fn)(*c); } catch (...) {
+      std::lock_guard<std::mutex> g(cx->mu);
+      if (!cx->err) cx->err = std::current_exception();
+      return nullptr;
+    }
+  };
+  int st = ndi_interp1d_eval_ring_sharded(hs.data(), (uint32_t)n, xs.data.data(), xs.len(), nullptr, rings.data(), tramp,
+                                          &ctx, &o, &info);
+  if (ctx.err) std::rethrow_exception(ctx.err);
+  if (st != NDI_OK) detail::throw_eval(st, info);
+}
+
+template <class T>
+void interp_array_into_sharded(const std::vector<const Interp2D<T>*>& replicas, const Array<T>& xs, const Array<T>& ys,
+                               Array<T>& buffer) {
+  if (replicas.empty()) throw Panic("interp_array_sharded needs at least one replica");
+  if (xs.shape != ys.shape) throw Panic("`xs.shape()` and `ys.shape()` do not match");
+  const auto expect = replicas[0]->get_buffer_shape(xs.shape);
+  if (buffer.shape != expect)
+    throw Panic("incompatible shapes expected: " + detail::shape_str(expect) + ", got: " + detail::shape_str(buffer.shape));
+  const size_t n = replicas.size(), lanes = replicas[0]->lanes(), nq = xs.len();
+  std::vector<const ndi_interp2d*> hs(n);
+  std::vector<ndi_shard_io> io(n);
+  for (size_t i = 0; i < n; ++i) {
+    auto dev = std::dynamic_pointer_cast<detail::Device2D<T>>(replicas[i]->strategy);
+    if (!dev) throw Panic("interp_array_sharded needs built-in device strategies (f32 / f64 data)");
+    hs[i] = dev->h;
+    io[i] = ndi_shard_io{nullptr, nullptr, buffer.data.data() + shard_bounds(nq, (unsigned)i, (unsigned)n).first * lanes, nullptr};
+  }
+  ndi_eval_opts o{};
+  o.q_memspace = NDI_MEM_HOST; o.out_memspace = NDI_MEM_HOST;
+  ndi_oob_info info{};
+  int st = ndi_interp2d_eval_sharded(hs.data(), (uint32_t)n, xs.data.data(), ys.data.data(), nq, io.data(), lanes, &o, &info);
+  if (st != NDI_OK) detail::throw_eval(st, info);
+}
+template <class T>
+Array<T> interp_array_sharded(const std::vector<const Interp2D<T>*>& replicas, const Array<T>& xs, const Array<T>& ys) {
+  if (replicas.empty()) throw Panic("interp_array_sharded needs at least one replica");
+  Array<T> zs(replicas[0]->get_buffer_shape(xs.shape));
+  interp_array_into_sharded(replicas, xs, ys, zs);
+  return zs;
+}
 
 }  // namespace ndarray_interp

@@ -250,10 +250,17 @@ class Linear(Interp1DStrategyBuilder, _DeviceStrategy1D):
     def __init__(self):
         _DeviceStrategy1D.__init__(self)
         self._extrapolate = False
+        self._device_req = None
 
     @staticmethod
     def new() -> "Linear":
         return Linear()
+
+    def device(self, ordinal: int) -> "Linear":
+        """Build-side option of this mirror (device selection): the HIP device that holds the tables.
+        Default: the device of the data tensor, else LOCAL_RANK / device 0."""
+        self._device_req = int(ordinal)
+        return self
 
     def extrapolate(self, extrapolate: bool) -> "Linear":
         """does the strategy extrapolate? Default is `false` (linear.rs:23-26)"""
@@ -265,7 +272,7 @@ class Linear(Interp1DStrategyBuilder, _DeviceStrategy1D):
             # integer (and other non-f32/f64) element types: the reference's generic per-query path
             from .generic_host import HostLinear
             return HostLinear(_host(x), _host(data), self._extrapolate)
-        return self._create(x, data, extrapolate=self._extrapolate)
+        return self._create(x, data, extrapolate=self._extrapolate, device=self._device_req)
 
 
 # ---- boundary conditions (cubic_spline.rs:153-217) ---------------------------------------------
@@ -338,10 +345,16 @@ class CubicSpline(Interp1DStrategyBuilder):
     def __init__(self):
         self._extrapolate = False
         self._boundary = BoundaryCondition.NotAKnot  # default, cubic_spline.rs:724-729
+        self._device_req = None
 
     @staticmethod
     def new() -> "CubicSpline":
         return CubicSpline()
+
+    def device(self, ordinal: int) -> "CubicSpline":
+        """Build-side option of this mirror: the HIP device that holds the tables (see Linear.device)."""
+        self._device_req = int(ordinal)
+        return self
 
     def extrapolate(self, extrapolate: bool) -> "CubicSpline":
         self._extrapolate = bool(extrapolate)
@@ -354,7 +367,7 @@ class CubicSpline(Interp1DStrategyBuilder):
     def build(self, x, data) -> "CubicSplineStrategy":
         bc = self._boundary
         strat = CubicSplineStrategy()
-        kw = dict(extrapolate=self._extrapolate)
+        kw = dict(extrapolate=self._extrapolate, device=self._device_req)
         if bc.tag == "Periodic":
             kw["periodic"] = True
         elif bc.tag == "Individual":

@@ -50,12 +50,19 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
         self._extrapolate = False
         self._h = None
         self._device = 0
+        self._device_req = None
         self._np_dtype = None
         self._lanes = 1
 
     @staticmethod
     def new() -> "Bilinear":
         return Bilinear()
+
+    def device(self, ordinal: int) -> "Bilinear":
+        """Build-side option of this mirror: the HIP device that holds the grid (default: the data tensor's
+        device, else LOCAL_RANK / device 0)."""
+        self._device_req = int(ordinal)
+        return self
 
     def extrapolate(self, yes: bool) -> "Bilinear":
         self._extrapolate = bool(yes)
@@ -78,6 +85,8 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
             return Buf(_to_device(a, db.keep.device), dt)
 
         xb, yb = axis(x), axis(y)
+        if device is None:
+            device = self._device_req
         if device is None:
             device = db.device if db.memspace == _capi.MEM_DEVICE else _default_device()
         nx, ny = db.shape[0], db.shape[1]

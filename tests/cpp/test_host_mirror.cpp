@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 
 #include "../../ndarray-interp_amd/host/ndarray_interp.hpp"
 
@@ -255,6 +256,68 @@ static void device() {
       Interp1DBuilder<double>::new_(y).strategy(CubicSpline<double>::new_().boundary(BoundaryCondition::Individual(
           {1, 3}, {RowBoundary::Natural(), RowBoundary::Clamped(), RowBoundary::NotAKnot()}))).build(); },
       BuilderError::ShapeError));
+  }
+  {  // several replicas, one call: contiguous blocks of the batch per replica (benches/bench_interp1d.rs:49-79 is the
+     // reference's multi-worker shape); one replica per device when the box has several, else all on device 0
+    const size_t n = 60, L = 256, Q = 9001;
+    std::vector<double> xk(n), yv(n * L), qs(Q);
+    for (size_t i = 0; i < n; ++i) xk[i] = 0.1 * i + 0.013 * (i % 4);
+    for (size_t i = 0; i < n * L; ++i) yv[i] = std::cos(0.002 * i) + 0.25;
+    for (size_t i = 0; i < Q; ++i) qs[i] = xk[0] + (xk[n - 1] - xk[0]) * ((i * 7907u) % Q) / double(Q);
+    const int ndev = device_count();
+    CHECK(current_device() == 0);
+    CHECK(throws<DeviceError>([&] { set_current_device(ndev); }));
+    std::vector<Interp1D<double>> reps;
+    for (int r = 0; r < 3; ++r)
+      reps.push_back(Interp1DBuilder<double>::new_(Array<double>({n, L}, yv)).x(xk)
+                         .strategy(CubicSpline<double>::new_().device(ndev >= 3 ? r : 0)).build());
+    std::vector<const Interp1D<double>*> rp{&reps[0], &reps[1], &reps[2]};
+    CHECK(std::dynamic_pointer_cast<detail::Device1D<double>>(reps[2].strategy)->device == (ndev >= 3 ? 2 : 0));
+    auto whole = reps[0].interp_array(Array<double>::from_vec(qs));
+    auto sharded = interp_array_sharded(rp, Array<double>::from_vec(qs));
+    CHECK(sharded.shape == whole.shape && sharded.data == whole.data);
+    CHECK((shard_bounds(Q, 0, 3) == std::pair<size_t, size_t>{0, 3001}) && (shard_bounds(Q, 2, 3) == std::pair<size_t, size_t>{6001, 9001}));
+    // first error over the whole batch: failures in shards 2 and 1 -> the lower one, rows after it untouched
+    qs[7000] = -4.0; qs[4000] = 88.0;
+    Array<double> buf({Q, L}, -9.0);
+    try { interp_array_into_sharded(rp, Array<double>::from_vec(qs), buf); CHECK(false); }
+    catch (const InterpolateError& e) { CHECK(e.index == 4000 && e.value == 88.0 && std::string(e.what()) == "x = 88.0 is not in range"); }
+    CHECK(std::equal(buf.data.begin(), buf.data.begin() + 4000 * L, whole.data.begin()));
+    CHECK(std::all_of(buf.data.begin() + 4000 * L, buf.data.end(), [](double v) { return v == -9.0; }));
+    // ring, sharded: every chunk lands at its global position
+    qs[7000] = xk[3]; qs[4000] = xk[5];
+    auto whole2 = reps[1].interp_array(Array<double>::from_vec(qs));
+    std::vector<double> got(Q * L, -1.0);
+    std::mutex mu;
+    size_t rows = 0;
+    interp_array_ring_sharded<double>(rp, Array<double>::from_vec(qs), 1024, 2, [&](const RingChunk& c) -> void* {
+      CHECK(c.shard < 3 && c.q_begin >= shard_bounds(Q, c.shard, 3).first && c.q_begin + c.q_count <= shard_bounds(Q, c.shard, 3).second);
+      CHECK(hipMemcpy2DAsync(got.data() + c.q_begin * L, L * 8, c.out, c.row_stride * 8, L * 8, c.q_count, 2, c.stream) == 0);
+      CHECK(hipStreamSynchronize(c.stream) == 0);
+      std::lock_guard<std::mutex> g(mu);
+      rows += c.q_count;
+      return nullptr;
+    });
+    CHECK(rows == Q && got == whole2.data);
+    // a worker thread that owns a device: set_current_device once, then unchanged builder code
+    set_current_device(ndev - 1);
+    auto lin = Interp1DBuilder<double>::new_(arr({1, 2, 3})).build();
+    CHECK(std::dynamic_pointer_cast<detail::Device1D<double>>(lin.strategy)->device == ndev - 1);
+    CHECK(lin.interp_scalar(1.5) == 2.5);
+    set_current_device(0);
+    // 2-D
+    Array<double> g2({5, 4, 3});
+    for (size_t i = 0; i < g2.len(); ++i) g2[i] = 0.25 * double((i * 37) % 19);
+    std::vector<Interp2D<double>> r2;
+    for (int r = 0; r < 2; ++r)
+      r2.push_back(Interp2DBuilder<double>::new_(g2).strategy(Bilinear<double>::new_().device(ndev >= 2 ? r : 0)).build());
+    std::vector<const Interp2D<double>*> rp2{&r2[0], &r2[1]};
+    Array<double> qx({7}), qy({7});
+    for (size_t i = 0; i < 7; ++i) { qx[i] = 4.0 * i / 6.0; qy[i] = 3.0 * ((i * 5) % 7) / 6.0; }
+    auto w2 = r2[0].interp_array(qx, qy);
+    CHECK(interp_array_sharded(rp2, qx, qy).data == w2.data);
+    qy[5] = 3.5;
+    try { interp_array_sharded(rp2, qx, qy); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.index == 5 && e.axis == 1); }
   }
   {  // f32 is a first-class type (tests/cubic_spline_strat.rs:108-154)
     Array<float> d = Array<float>::from_vec({1.f, 2.f, 2.5f, 2.5f, 3.f, 2.f, 1.f, -2.f, 3.f, 5.f, 6.3f, 8.f});

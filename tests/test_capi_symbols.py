@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(pkg):
 
 def test_version_and_error_string(pkg):
     lib = pkg._capi.lib()
-    assert lib.ndi_version() == (0 << 16) | 2
+    assert lib.ndi_version() == (0 << 16) | 3
     assert isinstance(pkg._capi.last_error(), str)
 
 

@@ -248,6 +248,90 @@ def test_c4_share_chunked(pkg):
     assert [int(s.item()) for s in sums["bucketed"]] == [int(s.item()) for s in sums["gather"]]
 
 
+class _DeviceRows:
+    """A raw device pointer with a row pitch (a chunk of a library-owned ring) as a torch tensor."""
+
+    def __init__(self, ptr, rows, lanes, pitch_elems, dt):
+        isz = np.dtype(dt).itemsize
+        self.__cuda_array_interface__ = {"shape": (rows, lanes), "strides": (pitch_elems * isz, isz),
+                                         "typestr": np.dtype(dt).str, "data": (ptr, False), "version": 2}
+
+
+def test_target_default_geometry(pkg):
+    """The benchmarked geometry itself (bench.py defaults; north-star Target): 4096 knots x 4096 f64 lanes, 1e7
+    queries in 4 chunks of 2.5e6 through a 2-slot STRIPED ring of 2 x 81.9 GB -- caller-owned (`striped_ring()`)
+    and library-owned.  Per chunk: the int64 checksum of all 1.024e10 outputs is equal between the gather and the
+    bucketed formulation (grouped records, slice histograms and uint32 record indices at 2.5e6 queries per launch);
+    256 sampled rows per chunk equal the oracle bit for bit; knot queries return the data row exactly
+    (interp_array: src/interp1d/mod.rs:197-211)."""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    dev = torch.device("cuda:0")
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    n = L = 4096; Q = 10_000_000; chunk = 2_500_000; nchunks = 4
+    need = 2 * chunk * L * 8 + (6 << 30)
+    if free_b < need:
+        pytest.skip(f"needs {need / 1e9:.0f} GB of free device memory, {free_b / 1e9:.0f} GB available")
+    rng = np.random.default_rng(45)
+    x = knots("rand", n, rng, np.float64)
+    y = rng.uniform(0.0, 1.0, (n, L))
+    yd = torch.as_tensor(y, device=dev)
+    interp = pkg.Interp1DBuilder.new(yd).x(torch.as_tensor(x, device=dev)).strategy(pkg.CubicSpline.new()).build()
+    q = np.concatenate([np.random.default_rng([45, c]).uniform(x[0], x[-1], chunk) for c in range(nchunks)])
+    hit = rng.integers(0, n - 1, nchunks * 16).reshape(nchunks, 16)
+    for c in range(nchunks):
+        q[c * chunk:c * chunk + 16] = x[hit[c]]                 # 16 knot queries at the head of every chunk
+    q[Q - 1] = x[-1]                                            # and the right end of the axis as the very last query
+    qd = torch.as_tensor(q, device=dev)
+    st, a, b = oracle.cubic_build(x, y)
+    assert st == oracle.OK
+    sums, picks = {}, {}
+
+    def run(name, path, slots):
+        interp.strategy.path = path
+        sums[name], picks[name] = [], []
+
+        def consumer(c, rows):
+            if rows is None:                                    # library-owned ring: wrap the raw chunk
+                assert c.row_stride == 2 * L
+                rows = torch.as_tensor(_DeviceRows(c.out, c.q_count, L, c.row_stride, np.float64), device=dev)
+            assert c.q_count == chunk and c.row_stride == 2 * L and c.slot == c.index % 2
+            sums[name].append(rows.view(torch.int64).sum())     # stream-ordered device reduction of the whole chunk
+            sel = np.sort(np.random.default_rng([9, c.index]).choice(c.q_count, 256, replace=False))
+            picks[name].append((c.q_begin + sel, rows[torch.as_tensor(sel, device=dev)].clone()))
+            assert torch.equal(rows[:16], yd[torch.as_tensor(hit[c.index], device=dev)])
+            if c.index == nchunks - 1:
+                assert torch.equal(rows[chunk - 1], yd[n - 1])
+        if slots is None:
+            interp.interp_array_ring(qd, chunk, consumer, n_slots=2)
+        else:
+            interp.interp_array_ring(qd, chunk, consumer, slots=slots)
+        assert len(sums[name]) == nchunks
+        idx = np.concatenate([p[0] for p in picks[name]])
+        got = torch.cat([p[1] for p in picks[name]]).cpu().numpy()
+        _, _, ref = oracle.interp1d_cubic(x, y, a, b, q[idx])
+        assert np.array_equal(got, ref), name
+        return [int(s_.item()) for s_ in sums[name]]
+
+    ring = pkg.striped_ring(chunk, L, 2, np.float64, 0)
+    assert ring[0].stride(0) == 2 * L and ring[1].data_ptr() - ring[0].data_ptr() == L * 8
+    s_b = run("bucketed/striped_ring()", pkg.PATH_BUCKETED, ring)
+    assert pkg.profile_read(reset=False)["last_path"] == "bucketed"
+    s_g = run("gather/striped_ring()", pkg.PATH_GATHER, ring)
+    s_a = run("auto/striped_ring()", pkg.PATH_AUTO, ring)
+    assert s_b == s_g == s_a
+    del ring
+    picks.clear(); sums.clear()
+    torch.cuda.empty_cache()
+    s_own = run("bucketed/library-owned", pkg.PATH_BUCKETED, None)
+    assert s_own == s_b
+    interp.strategy.trim()                                      # hands the 164 GB back
+    interp.strategy.release()
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------
 # resident locator
 # ------------------------------------------------------------------------------------------------
@@ -368,41 +452,7 @@ def test_async_launch_with_converted_host_queries_and_strided_error_rows(pkg):
     assert np.array_equal(view[:2500], ref) and np.all(view[2500:] == -3.0) and np.all(big[:, 0, :] == -3.0)
 
 
-# ------------------------------------------------------------------------------------------------
-# several devices from one process (what a Rust caller does: one handle per device, one host thread each)
-# ------------------------------------------------------------------------------------------------
-def test_one_process_drives_every_device(pkg):
-    import torch
-    ndev = pkg.device_count()
-    if ndev < 2:
-        pytest.skip(f"needs >= 2 visible devices, this box has {ndev}")
-    rng = np.random.default_rng(41)
-    n, L, Q = 5000, 2048, 60_000                    # 5000 knots: dynamic LDS > 64 KiB in locate (per-device attribute)
-    x = knots("rand", n, rng, np.float64)
-    y = rng.uniform(0, 1, (n, L))
-    q = rng.uniform(x[0], x[-1], Q)
-    st, a, b = oracle.cubic_build(x, y)
-    pick = rng.integers(0, Q, 300)
-    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q[pick])
-    results, errors = {}, []
-
-    def drive(d):
-        try:
-            dev = torch.device(f"cuda:{d}")
-            interp = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
-                .strategy(pkg.CubicSpline.new()).build()
-            lo, hi = pkg.sharding.shard_bounds(Q, d, ndev)
-            out = interp.interp_array(torch.as_tensor(q, device=dev))       # whole batch on every device ...
-            results[d] = (out[torch.as_tensor(pick, device=dev)].cpu().numpy(), out[lo:hi].sum().item())
-        except Exception as e:  # noqa: BLE001
-            errors.append((d, repr(e)))
-    threads = [threading.Thread(target=drive, args=(d,)) for d in range(ndev)]
-    [t.start() for t in threads]
-    [t.join() for t in threads]
-    assert not errors, errors
-    for d in range(ndev):
-        assert np.array_equal(results[d][0], ref), d
-
+# (several devices from one process: tests/test_gpu_sharded.py)
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])

@@ -1,0 +1,314 @@
+"""GPU tests of the in-process sharded evaluation (ndi_interp{1,2}d_eval_sharded / _eval_ring_sharded): N handles,
+one flattened query array, one host thread per shard inside the library, the reference's first-error result over
+the whole batch (src/interp1d/mod.rs:326-343).  The multi-worker shape being matched is
+benches/bench_interp1d.rs:49-79.  Two (three) handles on device 0 exercise the threading, the per-handle scratch
+and the cross-shard first-error minimum on a 1-GPU box; with >= 2 devices the same tests also place one handle per
+device."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from test_gpu_parity import knots
+
+pytestmark = pytest.mark.gpu
+
+
+def _devices(pkg, n):
+    """Device ordinal of each of n replicas: one per visible device when there are enough, else all on device 0."""
+    nd = pkg.device_count()
+    return list(range(n)) if nd >= n else [0] * n
+
+
+def _replicas(pkg, x, y, devices, strat=None):
+    return [pkg.Interp1DBuilder.new(y).x(x).strategy((strat or pkg.CubicSpline.new)().device(d)).build()
+            for d in devices]
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("nshards", [2, 3])
+def test_sharded_equals_one_batch_and_oracle(pkg, dt, nshards):
+    import torch
+    rng = np.random.default_rng(71)
+    n, L, Q = 300, 1024, 20_011                          # 20011 = ragged blocks for 2 and 3 shards
+    x = knots("rand", n, rng, dt); y = rng.uniform(0, 1, (n, L)).astype(dt)
+    q = rng.uniform(x[0], x[-1], Q).astype(dt)
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+    devs = _devices(pkg, nshards)
+    reps = _replicas(pkg, x, y, devs)
+    # device outputs: one tensor per shard on the shard's device, blocks = shard_bounds
+    outs = pkg.sharding.interp_array_sharded(reps, q)
+    assert [int(o.device.index) for o in outs] == devs
+    bounds = [pkg.sharding.shard_bounds(Q, i, nshards) for i in range(nshards)]
+    assert [o.shape[0] for o in outs] == [hi - lo for lo, hi in bounds] and bounds[0][0] == 0 and bounds[-1][1] == Q
+    got = np.concatenate([o.cpu().numpy() for o in outs])
+    assert np.array_equal(got, ref)
+    # one host output array (what a Rust caller with host ndarrays passes), any query rank
+    out = np.full((Q, L), -7.0, dtype=dt)
+    assert pkg.sharding.interp_array_sharded(reps, q, out=out) is out
+    assert np.array_equal(out, ref)
+    # per-shard device-resident query blocks
+    blocks = [torch.as_tensor(q[lo:hi], device=f"cuda:{d}") for (lo, hi), d in zip(bounds, devs)]
+    outs = pkg.sharding.interp_array_sharded(reps, blocks)
+    assert np.array_equal(np.concatenate([o.cpu().numpy() for o in outs]), ref)
+    with pytest.raises(TypeError, match="shard_bounds"):
+        pkg.sharding.interp_array_sharded(reps, [blocks[0][:-1]] + blocks[1:])
+    # both formulations, and Linear
+    for r in reps:
+        r.strategy.path = pkg.PATH_GATHER
+    outs = pkg.sharding.interp_array_sharded(reps, q)
+    assert np.array_equal(np.concatenate([o.cpu().numpy() for o in outs]), ref)
+    lin = _replicas(pkg, x, y, devs, pkg.Linear.new)
+    _, _, refl = oracle.interp1d_linear(x, y, q)
+    assert np.array_equal(np.concatenate([o.cpu().numpy() for o in pkg.sharding.interp_array_sharded(lin, q)]), refl)
+
+
+def test_sharded_first_error_is_the_global_minimum(pkg):
+    """Failures in several shards: the lowest flat index of the WHOLE batch is reported, rows before it are
+    written, every later row -- in every shard -- stays untouched (interp1d/mod.rs:334-342)."""
+    rng = np.random.default_rng(72)
+    n, L, Q = 100, 512, 30_000
+    x = knots("rand", n, rng, np.float64); y = rng.uniform(0, 1, (n, L))
+    st, a, b = oracle.cubic_build(x, y)
+    reps = _replicas(pkg, x, y, _devices(pkg, 3))
+    q = rng.uniform(x[0], x[-1], Q)
+    q[25_000] = 9.0; q[12_345] = -2.5; q[19_999] = np.nan     # shards 2, 1, 1; shard 0 is clean
+    out = np.full((Q, L), -3.0)
+    with pytest.raises(pkg.InterpolateError.OutOfBounds, match=r"^x = -2\.5 is not in range") as ei:
+        pkg.sharding.interp_array_sharded(reps, q, out=out)
+    assert ei.value.index == 12_345 and ei.value.value == -2.5
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q[:12_345])
+    assert np.array_equal(out[:12_345], ref) and np.all(out[12_345:] == -3.0)
+    # the failing query is the first of a shard / the first of the batch: nothing of that shard (or at all) is produced
+    lo1 = pkg.sharding.shard_bounds(Q, 1, 3)[0]
+    for f in (lo1, 0):
+        q2 = rng.uniform(x[0], x[-1], Q); q2[f] = 5.0; q2[Q - 1] = 6.0
+        out[:] = -3.0
+        with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+            pkg.sharding.interp_array_sharded(reps, q2, out=out)
+        assert ei.value.index == f and np.all(out[f:] == -3.0)
+        if f:
+            assert np.array_equal(out[:f], oracle.interp1d_cubic(x, y, a, b, q2[:f])[2])
+    # extrapolating strategy: the only failure is a NaN query -> the reference's panic, at the global index
+    ex = [pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().extrapolate(True).device(d)).build()
+          for d in _devices(pkg, 2)]
+    q3 = rng.uniform(x[0] - 1, x[-1] + 1, Q); q3[22_222] = np.nan; q3[29_000] = np.nan
+    out[:] = -3.0
+    with pytest.raises(pkg.Panic, match="failed to convert NaN to usize") as ei:
+        pkg.sharding.interp_array_sharded(ex, q3, out=out)
+    assert ei.value.index == 22_222 and np.all(out[22_222:] == -3.0)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q3[:22_222], extrapolate=oracle.EXTRAPOLATE_YES)
+    assert np.array_equal(out[:22_222], ref)
+    # device outputs: rows at / after the failure are untouched there as well (prefilled by the caller)
+    import torch
+    lib, cap = pkg._capi.lib(), pkg._capi
+    devs = _devices(pkg, 3)
+    bounds = [pkg.sharding.shard_bounds(Q, i, 3) for i in range(3)]
+    bufs = [torch.full((hi - lo, L), -3.0, dtype=torch.float64, device=f"cuda:{d}") for (lo, hi), d in zip(bounds, devs)]
+    io = (cap.ShardIO * 3)()
+    for i in range(3):
+        io[i].out = bufs[i].data_ptr()
+    handles = (C.c_void_p * 3)(*[r.strategy._h for r in reps])
+    opts = cap.EvalOpts(); opts.out_memspace = cap.MEM_DEVICE
+    info = cap.OobInfo()
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    st = lib.ndi_interp1d_eval_sharded(handles, 3, q.ctypes.data, Q, io, L, C.byref(opts), C.byref(info))
+    assert st == cap.OUT_OF_BOUNDS and info.index == 12_345 and info.value == -2.5 and info.axis == 0
+    assert cap.last_error() == "x = -2.5 is not in range"
+    got = np.concatenate([b_.cpu().numpy() for b_ in bufs])
+    assert np.array_equal(got[:12_345], oracle.interp1d_cubic(x, y, a, b, q[:12_345])[2]) and np.all(got[12_345:] == -3.0)
+
+
+def test_sharded_raw_c_abi_contract(pkg):
+    """Argument checks of the sharded entry points, ndi_shard_bounds, an empty batch, one shard, more shards than
+    queries."""
+    rng = np.random.default_rng(73)
+    x = knots("rand", 40, rng, np.float64); y = rng.uniform(0, 1, (40, 8))
+    st, a, b = oracle.cubic_build(x, y)
+    reps = _replicas(pkg, x, y, [0, 0, 0, 0])
+    lib, cap = pkg._capi.lib(), pkg._capi
+    lo, hi = C.c_uint64(), C.c_uint64()
+    for nq, n in ((10, 3), (0, 2), (7, 7), (3, 5), (10_000_019, 8)):
+        prev = 0
+        for i in range(n):
+            lib.ndi_shard_bounds(nq, i, n, C.byref(lo), C.byref(hi))
+            assert (lo.value, hi.value) == pkg.sharding.shard_bounds(nq, i, n) and lo.value == prev
+            prev = hi.value
+        assert prev == nq
+    handles = (C.c_void_p * 4)(*[r.strategy._h for r in reps])
+    q = rng.uniform(x[0], x[-1], 3)
+    out = np.full((3, 8), -1.0)
+    io = (cap.ShardIO * 4)()
+    for i in range(4):
+        lo_, _ = pkg.sharding.shard_bounds(3, i, 4)
+        io[i].out = out.ctypes.data + lo_ * 8 * 8
+    opts = cap.EvalOpts(); info = cap.OobInfo()
+    # more shards than queries: the last shard is empty
+    assert lib.ndi_interp1d_eval_sharded(handles, 4, q.ctypes.data, 3, io, 8, C.byref(opts), C.byref(info)) == cap.OK
+    assert np.array_equal(out, oracle.interp1d_cubic(x, y, a, b, q)[2])
+    assert lib.ndi_interp1d_eval_sharded(handles, 4, q.ctypes.data, 0, io, 8, C.byref(opts), C.byref(info)) == cap.OK
+    assert lib.ndi_interp1d_eval_sharded(handles, 1, q.ctypes.data, 3, io, 8, C.byref(opts), C.byref(info)) == cap.OK
+    assert lib.ndi_interp1d_eval_sharded(handles, 0, q.ctypes.data, 3, io, 8, C.byref(opts), C.byref(info)) == cap.BAD_ARG
+    assert lib.ndi_interp1d_eval_sharded(None, 2, q.ctypes.data, 3, io, 8, C.byref(opts), C.byref(info)) == cap.BAD_ARG
+    assert lib.ndi_interp1d_eval_sharded(handles, 4, None, 3, io, 8, C.byref(opts), C.byref(info)) == cap.BAD_ARG
+    assert lib.ndi_interp1d_eval_sharded(handles, 4, q.ctypes.data, 3, None, 8, C.byref(opts), C.byref(info)) == cap.BAD_ARG
+    assert lib.ndi_interp1d_eval_sharded(handles, 4, q.ctypes.data, 3, io, 4, C.byref(opts), C.byref(info)) == cap.BAD_ARG
+    assert "out_row_stride" in cap.last_error()
+    twice = (C.c_void_p * 2)(reps[0].strategy._h, reps[0].strategy._h)
+    assert lib.ndi_interp1d_eval_sharded(twice, 2, q.ctypes.data, 3, io, 8, C.byref(opts), C.byref(info)) == cap.BAD_ARG
+    assert "share one handle" in cap.last_error()
+    other = pkg.Interp1DBuilder.new(y.astype(np.float32)).x(x.astype(np.float32)).build()
+    mixed = (C.c_void_p * 2)(reps[0].strategy._h, other.strategy._h)
+    assert lib.ndi_interp1d_eval_sharded(mixed, 2, q.ctypes.data, 3, io, 8, C.byref(opts), C.byref(info)) == cap.BAD_ARG
+    assert "replicas" in cap.last_error()
+
+
+def test_sharded_calls_from_concurrent_host_threads(pkg):
+    """Two host threads each issue sharded calls on their own replica sets at the same time (per-handle, per-thread
+    scratch; the library's worker threads are per call)."""
+    rng = np.random.default_rng(74)
+    x = knots("rand", 200, rng, np.float64); y = rng.uniform(0, 1, (200, 256))
+    st, a, b = oracle.cubic_build(x, y)
+    sets = [_replicas(pkg, x, y, _devices(pkg, 2)) for _ in range(2)]
+    qs = [rng.uniform(x[0], x[-1], 15_000 + 7 * k) for k in range(2)]
+    refs = [oracle.interp1d_cubic(x, y, a, b, q)[2] for q in qs]
+    bad = []
+
+    def work(k):
+        for _ in range(6):
+            out = np.empty_like(refs[k])
+            pkg.sharding.interp_array_sharded(sets[k], qs[k], out=out)
+            if not np.array_equal(out, refs[k]):
+                bad.append(k)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
+
+
+def test_sharded_ring(pkg):
+    """Every shard streams its block through its own ring; the consumer sees global query indices and the shard; the
+    first-error cut is global."""
+    import torch
+    rng = np.random.default_rng(75)
+    n, L, Q, chunk = 128, 1024, 31_003, 4096
+    x = knots("rand", n, rng, np.float64); y = rng.uniform(0, 1, (n, L))
+    st, a, b = oracle.cubic_build(x, y)
+    devs = _devices(pkg, 2)
+    reps = _replicas(pkg, x, y, devs)
+    q = rng.uniform(x[0], x[-1], Q)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+    slots = [pkg.striped_ring(chunk, L, 2, np.float64, d) for d in devs]
+    got = np.full_like(ref, -1.0)
+    seen = []
+    lock = threading.Lock()
+
+    def consumer(c, rows):
+        assert tuple(rows.shape) == (c.q_count, L) and rows.data_ptr() == c.out
+        with lock:
+            got[c.q_begin:c.q_begin + c.q_count] = rows.cpu().numpy()
+            seen.append((c.shard, c.index, c.q_begin, c.q_count))
+    pkg.sharding.interp_array_ring_sharded(reps, q, chunk_queries=chunk, consumer=consumer, slots=slots)
+    assert np.array_equal(got, ref)
+    for sh in range(2):
+        lo, hi = pkg.sharding.shard_bounds(Q, sh, 2)
+        mine = [s for s in seen if s[0] == sh]
+        assert [s[1] for s in mine] == list(range(len(mine)))                       # in order within a shard
+        assert [s[2] for s in mine] == list(range(lo, hi, chunk)) and sum(s[3] for s in mine) == hi - lo
+    # library-owned rings, device-resident per-shard queries
+    bounds = [pkg.sharding.shard_bounds(Q, i, 2) for i in range(2)]
+    blocks = [torch.as_tensor(q[lo:hi], device=f"cuda:{d}") for (lo, hi), d in zip(bounds, devs)]
+    total = {"rows": 0}
+
+    def counting(c, rows):
+        assert rows is None and c.row_stride == 3 * L
+        with lock:
+            total["rows"] += c.q_count
+    pkg.sharding.interp_array_ring_sharded(reps, blocks, chunk_queries=chunk, consumer=counting, n_slots=3)
+    assert total["rows"] == Q
+    # first error in shard 1 (and a later one in shard 0's... none): exactly the rows before it are handed out
+    q[20_000] = 77.0; q[30_000] = -1.0
+    got[:] = -1.0; seen.clear()
+    with pytest.raises(pkg.InterpolateError.OutOfBounds, match=r"^x = 77(\.0)? is not in range") as ei:
+        pkg.sharding.interp_array_ring_sharded(reps, q, chunk_queries=chunk, consumer=consumer, slots=slots)
+    assert ei.value.index == 20_000 and sum(s[3] for s in seen) == 20_000
+    assert np.array_equal(got[:20_000], ref[:20_000]) and np.all(got[20_000:] == -1.0)
+    # first error in shard 0: shard 1 hands out nothing at all
+    q[100] = 55.0
+    seen.clear()
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        pkg.sharding.interp_array_ring_sharded(reps, q, chunk_queries=chunk, consumer=consumer, slots=slots)
+    assert ei.value.index == 100 and seen == [(0, 0, 0, 100)]
+
+
+def test_sharded_2d_bilinear(pkg):
+    import torch
+    rng = np.random.default_rng(76)
+    nx, ny, Cn, Q = 70, 50, 16, 50_001
+    g = rng.random((nx, ny, Cn), dtype=np.float32)
+    x = knots("rand", nx, rng, np.float32); y = knots("jit", ny, rng, np.float32)
+    devs = _devices(pkg, 3)
+    reps = [pkg.Interp2DBuilder.new(g).x(x).y(y).strategy(pkg.Bilinear.new().device(d)).build() for d in devs]
+    qx = rng.uniform(x[0], x[-1], Q).astype(np.float32); qy = rng.uniform(y[0], y[-1], Q).astype(np.float32)
+    _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy)
+    outs = pkg.sharding.interp_array_sharded(reps, qx, qy)
+    assert np.array_equal(np.concatenate([o.cpu().numpy() for o in outs]), ref)
+    out = np.full((Q, Cn), -2.0, dtype=np.float32)
+    pkg.sharding.interp_array_sharded(reps, qx, qy, out=out)
+    assert np.array_equal(out, ref)
+    # ring, library-owned
+    got = np.zeros_like(ref)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy2DAsync.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                     C.c_void_p]
+
+    def consumer(c, rows):
+        host = np.empty((c.q_count, Cn), dtype=np.float32)
+        with torch.cuda.device(devs[c.shard]):
+            assert hip.hipMemcpy2DAsync(host.ctypes.data, Cn * 4, c.out, c.row_stride * 4, Cn * 4, c.q_count, 2,
+                                        c.stream) == 0
+            assert hip.hipStreamSynchronize(C.c_void_p(c.stream)) == 0
+        got[c.q_begin:c.q_begin + c.q_count] = host
+    pkg.sharding.interp_array_ring_sharded(reps, qx, qy, chunk_queries=8192, consumer=consumer, n_slots=2)
+    assert np.array_equal(got, ref)
+    # x of a later query fails in shard 0, y of an earlier... per query x is tested before y; across queries the
+    # lowest index wins whatever the axis (bilinear.rs:71-80 inside the loop of interp2d/mod.rs:297-306)
+    qy[30_000] = 99.0; qx[40_000] = -5.0; qx[30_000] = x[0]
+    out[:] = -2.0
+    with pytest.raises(pkg.InterpolateError.OutOfBounds, match=r"^y = 99(\.0)? is not in range") as ei:
+        pkg.sharding.interp_array_sharded(reps, qx, qy, out=out)
+    assert ei.value.index == 30_000 and ei.value.axis == 1
+    assert np.array_equal(out[:30_000], ref[:30_000]) and np.all(out[30_000:] == -2.0)
+    qx[30_000] = 1e9                                   # same query fails on both axes: x is reported
+    with pytest.raises(pkg.InterpolateError.OutOfBounds, match=r"^x = 1000000000(\.0)? is not in range") as ei:
+        pkg.sharding.interp_array_sharded(reps, qx, qy, out=out)
+    assert ei.value.index == 30_000 and ei.value.axis == 0
+
+
+def test_one_process_drives_every_device_sharded(pkg):
+    """>= 2 devices: one replica per device, contiguous shard_bounds blocks, ONE library call; the concatenation
+    equals the oracle.  (On a 1-GPU box the tests above cover the same code with all replicas on device 0.)"""
+    ndev = pkg.device_count()
+    if ndev < 2:
+        pytest.skip(f"needs >= 2 visible devices, this box has {ndev}")
+    rng = np.random.default_rng(41)
+    n, L, Q = 5000, 2048, 60_000                    # 5000 knots: dynamic LDS > 64 KiB in locate (per-device attribute)
+    x = knots("rand", n, rng, np.float64)
+    y = rng.uniform(0, 1, (n, L))
+    q = rng.uniform(x[0], x[-1], Q)
+    st, a, b = oracle.cubic_build(x, y)
+    reps = _replicas(pkg, x, y, list(range(ndev)))
+    outs = pkg.sharding.interp_array_sharded(reps, q)
+    assert [int(o.device.index) for o in outs] == list(range(ndev))
+    pick = np.sort(rng.integers(0, Q, 300))
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q[pick])
+    got = np.concatenate([o.cpu().numpy() for o in outs])
+    assert got.shape == (Q, L) and np.array_equal(got[pick], ref)
+    q[Q - 5] = np.inf
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        pkg.sharding.interp_array_sharded(reps, q)
+    assert ei.value.index == Q - 5

@@ -106,8 +106,9 @@ def test_two_rank_shards_equal_single_process(pkg):
 def test_two_rank_first_error_is_global_minimum(pkg):
     firsts, parts = _run("err")
     assert firsts == [5203, 5203]          # both ranks learn the reference's first failing index
-    # rank 1 owns query 5203 and re-raises its OutOfBounds (local index 199); rank 0 is told which query failed
-    assert LAST_OUTCOMES == ["ShardFailed:5203", "OutOfBounds:199"]
+    # rank 1 owns query 5203 and re-raises its OutOfBounds carrying the flat index of the whole batch (ADVICE r2:
+    # every rank names the same index, the one the reference's serial loop would); rank 0 is told which query failed
+    assert LAST_OUTCOMES == ["ShardFailed:5203", "OutOfBounds:5203"]
 
 
 def test_two_rank_panic_and_device_failure_do_not_hang(pkg):
@@ -115,11 +116,10 @@ def test_two_rank_panic_and_device_failure_do_not_hang(pkg):
     not leave the other rank blocked in the MIN all-reduce; the panic's index is the global first failure."""
     firsts, _ = _run("nan")
     assert firsts == [8000, 8000]
-    assert LAST_OUTCOMES[0] == "ShardFailed:8000" and LAST_OUTCOMES[1].startswith("Panic:")
+    assert LAST_OUTCOMES == ["ShardFailed:8000", "Panic:8000"]
     firsts, _ = _run("boom")
-    lo1 = pkg.sharding.shard_bounds(10007, 1, 2)[0]
-    assert firsts == [lo1, lo1]            # the failing rank reports its shard start
-    assert LAST_OUTCOMES == [f"ShardFailed:{lo1}", "RuntimeError:None"]
+    assert firsts == [pkg.sharding.DEVICE_FAILED] * 2   # a device failure outranks every query index on all ranks
+    assert LAST_OUTCOMES == ["ShardFailed:-1", "RuntimeError:None"]
 
 
 GPU_WORKER = r'''

@@ -717,18 +717,21 @@ __global__ __launch_bounds__(BLOCK) void bucket_count_kernel(const uint32_t* idx
 }
 
 // Single-workgroup exclusive scan of nb counters -> cursor[] (start offsets); n_valid = total.
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* counts, uint32_t nb,
-                                                           uint32_t* cursor, StatusBlock* status) {
-  __shared__ uint32_t part[1024];
+// TB = 256 when the kernel has to find room beside a running evaluation kernel (ring pipeline): a 4-wave workgroup
+// fits wherever one evaluation workgroup has just retired, a 16-wave one waits for a quarter of a CU to drain.
+template <int TB>
+__global__ __launch_bounds__(TB) void bucket_scan_kernel(const uint32_t* counts, uint32_t nb,
+                                                         uint32_t* cursor, StatusBlock* status) {
+  __shared__ uint32_t part[TB];
   const uint32_t tid = threadIdx.x;
-  const uint32_t per = (nb + 1023u) / 1024u;
+  const uint32_t per = (nb + (uint32_t)TB - 1u) / (uint32_t)TB;
   const uint32_t b0 = tid * per;
   uint32_t s = 0;
   for (uint32_t k = 0; k < per; ++k)
     if (b0 + k < nb) s += counts[b0 + k];
   part[tid] = s;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024u; off <<= 1) {  // Hillis-Steele inclusive scan
+  for (uint32_t off = 1; off < (uint32_t)TB; off <<= 1) {  // Hillis-Steele inclusive scan
     uint32_t v = (tid >= off) ? part[tid - off] : 0u;
     __syncthreads();
     part[tid] += v;
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* count
       cursor[b0 + k] = run;
       run += counts[b0 + k];
     }
-  if (tid == 1023u) status->n_valid = part[1023];
+  if (tid == (uint32_t)TB - 1u) status->n_valid = part[TB - 1];
 }
 
 template <class T>

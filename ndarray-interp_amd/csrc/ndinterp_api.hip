@@ -325,7 +325,11 @@ struct Workspace {
     if (!host_status) NDI_HIP(hipHostMalloc((void**)&host_status, sizeof(StatusBlock), hipHostMallocDefault));
   }
   hipStream_t side_stream() {
-    if (!side) NDI_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    if (!side) {   // highest priority: its small kernels are dispatched ahead of the evaluation's next workgroups
+      int lo = 0, hi = 0;
+      NDI_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      NDI_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
+    }
     return side;
   }
   hipEvent_t order_event() {
@@ -467,7 +471,7 @@ template <class T>
 static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, uint64_t nq,
                        uint32_t* idx, int64_t* idx64, T* t, unsigned long long* first_fail, int mode,
                        uint32_t* hist = nullptr, uint32_t nb = 0, uint64_t* slice_out = nullptr,
-                       uint32_t* blocks_out = nullptr) {
+                       uint32_t* blocks_out = nullptr, bool beside_eval = false) {
   LocateArgs<T> A{};
   A.pyr = pyr.view;
   A.q = q;
@@ -494,7 +498,9 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
     blocks = std::min<uint64_t>(blocks, (uint64_t)cu_count() * std::max<size_t>(1, (160 * 1024) / total));
   }
   if (hist) shmem += (size_t)nb * 4;
-  const unsigned threads = threads_for_lds(shmem);
+  // beside a running evaluation kernel (ring pipeline) a 4-wave workgroup finds room wherever one evaluation
+  // workgroup has retired; the 16-wave one that is best on an idle chip would wait for a quarter of a CU to drain
+  const unsigned threads = beside_eval ? 256u : threads_for_lds(shmem);
   uint64_t slice = (nq + blocks - 1) / blocks;
   slice = (slice + threads - 1) / threads * threads;   // whole 64-query batches per wave
   blocks = (nq + slice - 1) / slice;
@@ -510,6 +516,16 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Measurement knob (profiles/r03_ring_overlap.md): NDI_RING_OVERLAP=0 runs the ring's locate + group on the
+// evaluation stream instead of the side stream.  Read once.
+static bool ring_overlap() {
+  static const bool on = [] {
+    const char* e = std::getenv("NDI_RING_OVERLAP");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 
 static ndi_status check_ring_desc(const ndi_ring_desc* ring, uint64_t lanes, uint64_t* stride) {
   if (!ring || ring->n_slots == 0 || ring->chunk_queries == 0)
@@ -726,7 +742,8 @@ struct Interp1DImpl final : Interp1DBase {
     uint64_t LV = 0;
   };
 
-  Plan1 prep(hipStream_t s, Scratch& sc, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path) {
+  Plan1 prep(hipStream_t s, Scratch& sc, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path,
+             bool beside_eval = false) {
     Plan1 P;
     P.q = q; P.nq = nq; P.out = out; P.out_stride = out_stride;
     sc.idx.reserve(nq * sizeof(uint32_t));
@@ -772,11 +789,11 @@ struct Interp1DImpl final : Interp1DBase {
         uint64_t slice = 0;
         uint32_t blocks = 0;
         run_locate<T>(s, pyr, q, nq, sc.idx.as<uint32_t>(), nullptr, t_out,
-                      &st->first_fail[0], mode, sc.hist.as<uint32_t>(), nb, &slice, &blocks);
+                      &st->first_fail[0], mode, sc.hist.as<uint32_t>(), nb, &slice, &blocks, beside_eval);
         ProfScope ps(s, PC_GROUP);
         hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
                            sc.hist.as<uint32_t>(), blocks, nb, sc.counts.as<uint32_t>());
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, sc.counts.as<uint32_t>(), nb,
+        hipLaunchKernelGGL(bucket_scan_kernel<256>, dim3(1), dim3(256), 0, s, sc.counts.as<uint32_t>(), nb,
                            sc.cursor.as<uint32_t>(), st);
         allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter_kernel<T>), (int)(GROUP_MAX_BINS * 4));
         hipLaunchKernelGGL(group_scatter_kernel<T>, dim3(blocks), dim3(BLOCK), (size_t)nb * 4, s,
@@ -793,7 +810,7 @@ struct Interp1DImpl final : Interp1DBase {
         const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 2048));
         hipLaunchKernelGGL(bucket_count_kernel, dim3(g), dim3(BLOCK), 0, s, (const uint32_t*)sc.idx.as<uint32_t>(), nq,
                            (const StatusBlock*)st, sc.counts.as<uint32_t>());
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, sc.counts.as<uint32_t>(), nb,
+        hipLaunchKernelGGL(bucket_scan_kernel<256>, dim3(1), dim3(256), 0, s, sc.counts.as<uint32_t>(), nb,
                            sc.cursor.as<uint32_t>(), st);
         hipLaunchKernelGGL(bucket_scatter_kernel<T>, dim3(g), dim3(BLOCK), 0, s, (const uint32_t*)sc.idx.as<uint32_t>(),
                            sval, nq, (const StatusBlock*)st, sc.cursor.as<uint32_t>(), sc.perm.as<uint4>());
@@ -1123,7 +1140,7 @@ struct Interp1DImpl final : Interp1DBase {
       for (uint32_t i = 0; i < ring->n_slots; ++i) R.slots[i] = (char*)ring_own.buf.p + (size_t)i * stride * sizeof(T);
       R.pitch = (uint64_t)ring->n_slots * stride;
     }
-    R.side = ws.side_stream();
+    R.side = ring_overlap() ? ws.side_stream() : s;
     for (Scratch& sc : ws.sc) sc.ensure_events();
     // the side stream starts after everything already enqueued on s (the query upload)
     NDI_HIP(hipEventRecord(ws.order_event(), s));
@@ -1146,7 +1163,7 @@ struct Interp1DImpl final : Interp1DBase {
       Plan1 P = R.plan0;
       if (k > 0) {
         if (k >= 2) NDI_HIP(hipStreamWaitEvent(R.side, sc.eval_done, 0));   // chunk k-2 has released the set
-        P = prep(R.side, sc, q + off, cq, (T*)R.slots[slot], R.pitch, o.path);
+        P = prep(R.side, sc, q + off, cq, (T*)R.slots[slot], R.pitch, o.path, R.side != s);
         NDI_HIP(hipEventRecord(sc.prep_done, R.side));
       }
       NDI_HIP(hipStreamWaitEvent(s, sc.prep_done, 0));
@@ -1403,7 +1420,7 @@ struct Interp2DImpl final : Interp2DBase {
                          sx, sy, nty, nb, sc.t.as<uint32_t>(), sc.hist.as<uint32_t>());
       hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
                          sc.hist.as<uint32_t>(), (uint32_t)blocks, nb, sc.counts.as<uint32_t>());
-      hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, sc.counts.as<uint32_t>(), nb,
+      hipLaunchKernelGGL(bucket_scan_kernel<256>, dim3(1), dim3(256), 0, s, sc.counts.as<uint32_t>(), nb,
                          sc.cursor.as<uint32_t>(), st);
       hipLaunchKernelGGL(group_scatter2d_kernel<T>, dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
                          (const uint32_t*)sc.t.as<uint32_t>(), (const uint32_t*)sc.idx.as<uint32_t>(),
@@ -1710,7 +1727,7 @@ struct Interp2DImpl final : Interp2DBase {
       for (uint32_t i = 0; i < ring->n_slots; ++i) R.slots[i] = (char*)ring_own.buf.p + (size_t)i * stride * sizeof(T);
       R.pitch = (uint64_t)ring->n_slots * stride;
     }
-    R.side = ws.side_stream();
+    R.side = ring_overlap() ? ws.side_stream() : s;
     for (Scratch& sc : ws.sc) sc.ensure_events();
     NDI_HIP(hipEventRecord(ws.order_event(), s));
     NDI_HIP(hipStreamWaitEvent(R.side, ws.order_event(), 0));

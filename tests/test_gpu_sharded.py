@@ -55,7 +55,7 @@ def test_sharded_equals_one_batch_and_oracle(pkg, dt, nshards):
     outs = pkg.sharding.interp_array_sharded(reps, blocks)
     assert np.array_equal(np.concatenate([o.cpu().numpy() for o in outs]), ref)
     with pytest.raises(TypeError, match="shard_bounds"):
-        pkg.sharding.interp_array_sharded(reps, [blocks[0][:-1]] + blocks[1:])
+        pkg.sharding.interp_array_sharded(reps, blocks[:-1] + [blocks[-1][:-1]])
     # both formulations, and Linear
     for r in reps:
         r.strategy.path = pkg.PATH_GATHER

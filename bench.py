@@ -78,11 +78,15 @@ def cpu_baseline(x, y, q_all, budget_s=20.0):
     build_s = time.perf_counter() - t0
     assert st == oracle.OK
     res = {}
-    for label, threads in (("1t", 1), ("all", min(16, os.cpu_count() or 1))):  # 16 = one GPU's CPU share
+    ncpu = os.cpu_count() or 1
+    legs = [("1t", 1, budget_s / 2), ("all", ncpu, budget_s / 2)]       # 1 thread and all host cores
+    if ncpu > 16:
+        legs.append(("share", 16, budget_s / 4))                        # 16 threads = one GPU's share of the box
+    for label, threads, budget in legs:
         blk = 2048 if threads == 1 else 512 * threads
         out = np.zeros((blk, lanes))
         done, t_used, pos = 0, 0.0, 0
-        while t_used < budget_s / 2:
+        while t_used < budget:
             if pos + blk > q_all.size:
                 pos = 0
             t0 = time.perf_counter()
@@ -93,6 +97,7 @@ def cpu_baseline(x, y, q_all, budget_s=20.0):
             pos += blk
         res[label] = (done * lanes / t_used / 1e6, done, threads)
     res["flags"] = flags
+    res["host_cores"] = ncpu
     return res, build_s
 
 
@@ -205,6 +210,102 @@ def extra_workload(args, pkg, torch, dev, rank, world):
                       "stages_ms_per_step": {k: round(prof[k + "_ms"] / args.steps, 4) for k in ("locate", "group", "eval")}}))
 
 
+def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
+    """One secondary 2-D leg: random-knot axes, uniform in-range queries, device-resident output; HIP-event kernel
+    time from the library's profile, wall-clock end to end (search + evaluation)."""
+    rng = np.random.default_rng(42)
+    x = np.unique(rng.uniform(0, 1, 2 * nx).astype(np.float32))[:nx]
+    y = np.unique(rng.uniform(0, 1, 2 * nx).astype(np.float32))[:nx]
+    g = torch.rand((nx, nx, C), dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+    interp = pkg.Interp2DBuilder.new(g).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
+    del g
+    torch.cuda.empty_cache()
+    qx = torch.as_tensor(np.random.default_rng(123).uniform(x[0], x[-1], nq).astype(np.float32), device=dev)
+    qy = torch.as_tensor(np.random.default_rng(96).uniform(y[0], y[-1], nq).astype(np.float32), device=dev)
+    out = torch.empty((nq, C), dtype=torch.float32, device=dev)
+    step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
+    for _ in range(warmup):
+        step()
+    interp.strategy.finish()
+    pkg.profile_enable(True); pkg.profile_read(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    interp.strategy.finish()
+    el = time.perf_counter() - t0
+    prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
+    kms = prof["eval_ms"] / max(1, prof["eval_launches"])
+    alg = nq * C * 20 + nq * 8                                   # SURVEY 8(d): 5 x 4 B per point + the query pair
+    res = {"workload": f"2D Bilinear, {nx}x{nx} grid x {C} channels f32, {nq} queries, random knots",
+           "kernel": "eval_bilinear_kernel", "kernel_ms": round(kms, 4),
+           "frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
+           "locate_ms": round(prof["locate_ms"] / max(1, prof["locate_launches"]), 4),
+           "ms_per_step": round(el / steps * 1e3, 4), "Mpoints_s": round(nq * C * steps / el / 1e6, 1)}
+    if probe:      # the same access mix without searches / knots / arithmetic: the memory system's ceiling on this box
+        pms = interp.strategy.probe_ceiling(out, reps=7)
+        res["access_mix_ceiling_ms"] = round(pms, 4)
+        res["frac_of_measured_ceiling"] = round(pms / kms, 4)
+    interp.strategy.release()
+    del interp, qx, qy, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def secondary_legs(pkg, torch, dev):
+    """Short legs for the other BASELINE configs, run AFTER the timed Target region (never inside it): C3
+    (configs[2]), C5's per-GPU share (configs[4]) and C1 (configs[0], the reference's CPU-runnable case, host arrays
+    in and out through the C ABI next to the CPU port).  Mirrors benches/bench_interp2d.rs:12-131 and
+    benches/bench_interp1d.rs:33-37."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    import oracle
+    sec = {"c3": bilinear_leg(pkg, torch, dev, 2048, 64, 10_000_000),
+           "c5_share": bilinear_leg(pkg, torch, dev, 8192, 16, 12_500_000, probe=True)}
+    n, nq = 1024, 10_000
+    rng = np.random.default_rng(42)
+    yv = rng.uniform(0, 1, n); q = np.random.default_rng(123).uniform(0, n - 1, nq)
+    x = np.arange(n, dtype=np.float64)
+    ref = oracle.interp1d_linear(x, yv, q)[2][:, 0]
+    reps = 300
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.interp1d_linear(x, yv, q)
+    cpu_us = (time.perf_counter() - t0) / reps * 1e6
+    interp = pkg.Interp1DBuilder.new(yv).build()
+    cap = pkg._capi
+    out = np.zeros(nq); opts = cap.EvalOpts(); info = cap.OobInfo()
+    fn, h = cap.lib().ndi_interp1d_eval, interp.strategy._h
+    cargs = (h, q.ctypes.data, nq, out.ctypes.data, 1, ctypes.byref(opts), ctypes.byref(info))
+    for _ in range(30):
+        assert fn(*cargs) == 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn(*cargs)
+    gpu_us = (time.perf_counter() - t0) / reps * 1e6
+    sec["c1"] = {"workload": "1D Linear, 1024 f64 knots (index axis), scalar data, 1e4 queries, host arrays in and out",
+                 "gpu_us": round(gpu_us, 1), "cpu_us": round(cpu_us, 1), "bit_exact": bool(np.array_equal(out, ref)),
+                 "gpu_path": "C ABI host to host (H2D, fused search+evaluate launch, D2H, one sync)",
+                 "cpu_path": "oracle port, 1 thread"}
+    return sec
+
+
+def gather_ranks(torch, dist, world, rank, ms_per_step, kernel_ms, my_dev, cdev):
+    """Self-verification of an N > 1 line: every rank's own clock, kernel time and device, gathered after the timed
+    region, so that a reader can see the backend saw `world` ranks, on which devices, and which rank was slowest."""
+    per = torch.zeros((world, 2), dtype=torch.float64, device=cdev)
+    per[rank, 0], per[rank, 1] = ms_per_step, kernel_ms
+    dist.all_reduce(per, op=dist.ReduceOp.SUM)
+    devs = [None] * world
+    dist.all_gather_object(devs, my_dev)
+    per = per.cpu().numpy()
+    return {"world": dist.get_world_size(), "backend": dist.get_backend(),
+            "per_rank_ms": [round(float(v), 4) for v in per[:, 0]],
+            "per_rank_kernel_ms": [round(float(v), 4) for v in per[:, 1]],
+            "slowest_rank": int(np.argmax(per[:, 0])), "devices": devs,
+            "distinct_devices": len({(d["uuid"], d["ordinal"]) for d in devs})}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without an external launcher: start N fresh rank processes -- before this
     process has made any GPU call -- with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, wait for them and
@@ -219,13 +320,30 @@ def self_launch(args):
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(args.gpus)]
+    # poll all ranks: the first one that fails takes its siblings down (they would otherwise sit in RCCL init or
+    # a collective waiting for it) and its exit code is ours
+    deadline = time.time() + 3000
     rc = 0
-    for p in procs:
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = abs(r) or 1
+        if time.time() > deadline:
+            rc = 124
+        if live and rc == 0:
+            time.sleep(0.05)
+    for p in live:
+        p.terminate()
+    for p in live:
         try:
-            rc = max(rc, abs(p.wait(timeout=3000)))
+            p.wait(timeout=20)
         except subprocess.TimeoutExpired:
             p.kill()
-            rc = max(rc, 124)
     return rc
 
 
@@ -284,18 +402,28 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
     pkg.profile_read(reset=True)
     seen.update(chunks=0, rows=0)
     fence()
+    step_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        ts = time.perf_counter()
+        step()                       # returns after the step's last kernel has completed (one sync inside)
+        step_s.append(time.perf_counter() - ts)
     fence()
     elapsed = time.perf_counter() - t0
     prof = pkg.profile_read(reset=True)
     pkg.profile_enable(False)
     assert seen["chunks"] == nchunks * args.steps and seen["rows"] == nq * args.steps, seen
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    my_elapsed = elapsed
+    my_kernel_ms = prof["eval_ms"] / max(1, prof["eval_launches"])
+    props = torch.cuda.get_device_properties(dev)
+    my_dev = {"rank": rank, "ordinal": dev.index, "uuid": str(getattr(props, "uuid", "")), "name": props.name}
+    cdev = dev if args.backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    ranks = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ranks = gather_ranks(torch, dist, world, rank, my_elapsed / args.steps * 1e3, my_kernel_ms, my_dev, cdev)
     elapsed = float(t.item())
     points_per_step = nq * lanes
     value = world * points_per_step * args.steps / elapsed / 1e6
@@ -319,12 +447,14 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
             traffic = json.load(open(tpath)).get(f"{prof['last_path']}_bytes_per_launch_chunk2500000")
         except Exception:
             traffic = None
-    phys = traffic if traffic else comp_bytes
-    achieved = phys / (kernel_ms * 1e-3) / 1e9
+    achieved = comp_bytes / (kernel_ms * 1e-3) / 1e9
     line = {
         "metric": "interp_array Mpoints/s (queries x lanes), 1D cubic f64",
         "value": round(value, 1), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        # `value` is the wall-clock MEAN over the timed steps (max over ranks); the median of rank 0's per-step
+        # wall times is reported next to it (the mean is the conservative side)
+        "ms_per_step_median": round(float(np.median(step_s)) * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"Target: 1D CubicSpline NotAKnot, {n} knots x {lanes} lanes f64, {nq} queries per GPU "
@@ -338,12 +468,15 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
                                    "placement": "first allocation of the process, no selection"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "bytes_basis": "PMC traffic per launch (profiles/traffic.json)" if traffic else
-                                    "compulsory bytes per launch (output + tables + query records, once)",
+                     # `traffic` is NOT measured by this run: it is the PMC figure of the same workload from the
+                     # committed profiles/traffic.json.  achieved / frac are the COMPUTED compulsory bytes of one
+                     # launch divided by this run's kernel time.
+                     "traffic_source": "stored (profiles/traffic.json, rocprofv3 --pmc of this workload)" if traffic else None,
+                     "bytes_basis": "compulsory bytes per launch (output + tables + query records, once)",
                      "kernel": "eval_bucketed_kernel" if bucketed else "eval_rows_kernel",
                      "kernel_ms": round(kernel_ms, 4), "launches": prof["eval_launches"],
                      "compulsory_bytes_per_launch": int(comp_bytes),
-                     "compulsory_frac": round(comp_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "stored_traffic_frac": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      # SURVEY 8(d)'s gather-model bytes / time / peak: > 1 on the bucketed path because that
                      # formulation removes the per-query table re-reads the model assumes -- not a hardware fraction
@@ -353,6 +486,8 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
                                "eval": round(prof["eval_ms"] / args.steps, 4)},
         "build_ms": round(build_ms, 2),
     }
+    if ranks is not None:
+        line["ranks"] = ranks
 
     # sanity: sampled rows of every chunk against the CPU oracle (one extra pass, rows gathered on the device)
     if not args.no_check:
@@ -381,7 +516,9 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         line["gather_formulation"] = {
             "kernel": "eval_rows_kernel", "kernel_ms": round(gms, 4),
             "algorithmic_GBs": round(alg_bytes / (gms * 1e-3) / 1e9, 1),
-            "frac_of_peak": round(alg_bytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            # algorithmic bytes / time / peak: may exceed 1 (part of the 384 MiB table set is served on-die), so it
+            # is a ratio of the SURVEY 8(d) model to the peak, not a hardware fraction; the read share below is
+            "algorithmic_ratio_to_peak": round(alg_bytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "read_only_frac_of_peak": round(pts * 32 / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "Mpoints_s": round(pts / (gms * 1e-3) / 1e6, 1)}
         interp.strategy.path = paths[args.path]
@@ -414,6 +551,12 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
                              "spread_separate": round(max(other_ms) / min(other_ms) - 1, 4) if other_ms else None}
         torch.cuda.empty_cache()
 
+    if world == 1 and not args.no_secondary:
+        interp.strategy.release()
+        del ring, qd, interp, yd, xd
+        torch.cuda.empty_cache()
+        line["secondary"] = secondary_legs(pkg, torch, dev)
+
     if world == 1 and not args.no_cpu_baseline:
         res, build_s = cpu_baseline(x, y, q)
         v1, done1, _ = res["1t"]
@@ -421,8 +564,11 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         line["cpu_baseline"] = {"value": round(v1, 1), "unit": "Mpoints/s", "cores": 1, "kind": "port",
                                 "sample": f"{done1} queries x {lanes} lanes of the same workload (~10 s), oracle/ serial "
                                           "loop in blocks of 2048 queries (the reference is single-threaded)",
+                                "host_cores": res["host_cores"],
                                 "all_cores": {"value": round(vall, 1), "cores": threads,
                                               "sample": f"{doneall} queries (~10 s), contiguous query blocks per thread"},
+                                "per_gpu_share": ({"value": round(res["share"][0], 1), "cores": 16,
+                                                   "sample": f"{res['share'][1]} queries (~5 s)"} if "share" in res else None),
                                 "build_s": round(build_s, 2), "compiler_flags": res["flags"]}
     print(json.dumps(line), flush=True)
 
@@ -445,6 +591,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the sampled-rows check against the CPU oracle")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the extra pass with the gather formulation")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C5-share / C1 legs after the timed region")
     ap.add_argument("--ring-layout", choices=["striped", "separate"], default="striped",
                     help="target: striped = one allocation, slots interleaved row by row (recommended); separate = one "
                          "buffer per slot")
@@ -481,12 +628,17 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
             dist.barrier()
+        if os.environ.get("NDI_BENCH_FAIL_RANK") == str(rank):       # test hook: this rank dies before the collective
+            raise SystemExit(3)
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        ranks = None
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ranks = gather_ranks(torch, dist, world, rank, 1.0 + rank, 0.5 + rank,
+                                 {"rank": rank, "ordinal": local_rank, "uuid": f"rehearsal-{rank}", "name": "none"}, "cpu")
         if rank == 0:
             print(json.dumps({"rehearsal": True, "n_gpus": world, "max_over_ranks": float(t.item()),
-                              "local_rank": local_rank}), flush=True)
+                              "local_rank": local_rank, "ranks": ranks}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -500,16 +652,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     pkg = load_package()
-    try:
-        if args.workload == "target":
-            run_target(args, pkg, torch, dist, dev, rank, world)
-        else:
-            sys.path.insert(0, ROOT)
-            extra_workload(args, pkg, torch, dev, rank, world)
-    finally:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+    if args.workload == "target":
+        run_target(args, pkg, torch, dist, dev, rank, world)
+    else:
+        sys.path.insert(0, ROOT)
+        extra_workload(args, pkg, torch, dev, rank, world)
+    # success path only: a rank that raised above exits non-zero without entering another collective (its peers
+    # may be inside a different one), and self_launch() takes the siblings down
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

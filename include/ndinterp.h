@@ -357,6 +357,15 @@ typedef struct ndi_profile {
 void ndi_profile_enable(int32_t on);
 ndi_status ndi_profile_read(ndi_profile* out, int32_t reset);
 
+/* Measurement aid for the 2-D gather (Bilinear::interp_into, bilinear.rs:83-97): runs the evaluation kernel's memory
+ * access mix alone -- per query one uniformly random cell of the handle's own grid, the four corner vectors with
+ * the kernel's lane mapping, the output row stored; no searches, knots or query values -- `reps` times and returns
+ * the median launch duration in *ms.  `out`: device buffer T[nq][out_row_stride] (overwritten with meaningless
+ * values).  The ceiling the memory system sets for this gather on this box: bench.py reports the evaluation
+ * kernel against it next to the fraction of the HBM spec peak. */
+ndi_status ndi_interp2d_probe_ceiling(const ndi_interp2d* h, uint64_t nq, void* out, uint64_t out_row_stride,
+                                      void* stream, int32_t reps, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,7 @@ SYMBOLS = {
     "ndi_version": (C.c_uint32, []),
     "ndi_profile_enable": (None, [C.c_int32]),
     "ndi_profile_read": (C.c_int, [C.POINTER(Profile), C.c_int32]),
+    "ndi_interp2d_probe_ceiling": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _P, C.c_int32, C.POINTER(C.c_double)]),
 }
 
 _lib = None

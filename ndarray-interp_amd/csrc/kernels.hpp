@@ -1096,6 +1096,36 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
   }
 }
 
+// Measurement aid (ndi_interp2d_probe_ceiling): the memory access mix of eval_bilinear_kernel and nothing else --
+// per item one pre-generated uniformly random cell, the four corner vectors from the handle's own grid with the
+// kernel's lane mapping, a token amount of arithmetic, the output vector stored -- no searches, no knots, no query
+// values.  Its time is the ceiling the memory system sets for this gather on this box and this table.
+template <class T, int VEC>
+__global__ __launch_bounds__(BLOCK) void probe_gather_kernel(const T* data, uint64_t nx, uint64_t ny, uint64_t row_cells,
+                                                             uint64_t cell_elems, uint64_t lanes, uint64_t nq,
+                                                             uint64_t seed, T* out, uint64_t out_stride) {
+  using V = typename VecT<T, VEC>::type;
+  const uint32_t LV = (uint32_t)(lanes / VEC);
+  const uint64_t items = nq * LV;
+  const uint64_t ncx = nx - 1, ncy = ny - 1;
+  for (uint64_t it = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; it < items; it += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t q = it / LV;
+    const uint32_t v = (uint32_t)(it - q * LV);
+    uint64_t z = (q + seed) * 0x9E3779B97F4A7C15ull;   // splitmix64: the cell of query q
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const uint64_t xi = (z >> 32) % ncx, yi = (z & 0xffffffffu) % ncy;
+    const V* z11 = reinterpret_cast<const V*>(data + (xi * row_cells + yi) * cell_elems);
+    const V* z21 = reinterpret_cast<const V*>(data + ((xi + 1) * row_cells + yi) * cell_elems);
+    const V a11 = z11[v], a12 = z11[LV + v], a21 = z21[v], a22 = z21[LV + v];
+    const T tx = T(0.25), ty = T(0.75);
+    const V z1 = (a21 - a11) * tx + a11;
+    const V z2 = (a22 - a12) * tx + a12;
+    reinterpret_cast<V*>(out + q * out_stride)[v] = (z2 - z1) * ty + z1;
+  }
+}
+
 // 2-D counterpart of eval_small_kernel: both searches and the bilinear evaluation in one launch, one query per
 // thread (lanes <= SMALL_LANES), output into a staging buffer owned by the host side.
 template <class T>

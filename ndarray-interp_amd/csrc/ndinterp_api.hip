@@ -1303,6 +1303,7 @@ struct Interp2DBase {
                                ndi_ring_consumer consume, void* user, const ndi_eval_opts* opts,
                                ndi_oob_info* info) = 0;
   virtual ndi_status trim() = 0;
+  virtual ndi_status probe_ceiling(uint64_t nq, void* out, uint64_t out_stride, void* stream, int reps, double* ms) = 0;
 };
 
 template <class T>
@@ -1800,6 +1801,40 @@ struct Interp2DImpl final : Interp2DBase {
     ring_produce(s, ws, qx, qy, limit, R, consume, user, o, 0, 0);
     if (ff == NO_FAIL) return NDI_OK;
     return report(qx_, qy_, o.q_memspace, fx, fy, 0, info);
+  }
+
+  // Median time of `reps` launches of probe_gather_kernel over nq queries (see kernels.hpp).
+  ndi_status probe_ceiling(uint64_t nq, void* out, uint64_t out_stride, void* stream, int reps, double* ms) override {
+    DeviceGuard dg(device);
+    constexpr int VN = Wide<T>::N;
+    if (!out || !ms || nq == 0 || reps < 1) return fail(NDI_BAD_ARG, "probe needs an output buffer, nq >= 1, reps >= 1");
+    if (out_stride < lanes) return fail(NDI_BAD_ARG, "out_row_stride < lanes");
+    if (lanes % VN || out_stride % VN || !aligned16(out))
+      return fail(NDI_UNSUPPORTED, "the probe covers the vectorised layout only (lanes a multiple of %d)", VN);
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t items = nq * (lanes / VN);
+    const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((items + BLOCK - 1) / BLOCK, 32768));
+    hipEvent_t a, b;
+    NDI_HIP(hipEventCreate(&a));
+    NDI_HIP(hipEventCreate(&b));
+    std::vector<float> ts;
+    for (int r = 0; r <= reps; ++r) {   // the first launch is a warm-up
+      NDI_HIP(hipEventRecord(a, s));
+      hipLaunchKernelGGL((probe_gather_kernel<T, VN>), dim3(g), dim3(BLOCK), 0, s, (const T*)data.as<T>(), nx, ny,
+                         pair_packed ? ny - 1 : ny, pair_packed ? 2 * lanes : lanes, lanes, nq,
+                         (uint64_t)(12345 + r), (T*)out, out_stride);
+      NDI_HIP(hipGetLastError());
+      NDI_HIP(hipEventRecord(b, s));
+      NDI_HIP(hipEventSynchronize(b));
+      float t = 0.f;
+      NDI_HIP(hipEventElapsedTime(&t, a, b));
+      if (r) ts.push_back(t);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    std::sort(ts.begin(), ts.end());
+    *ms = ts[ts.size() / 2];
+    return NDI_OK;
   }
 
   ndi_status trim() override {
@@ -2500,6 +2535,14 @@ NDI_API ndi_status ndi_interp2d_trim(const ndi_interp2d* h) {
   if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
   NDI_TRY
   return h->impl->trim();
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp2d_probe_ceiling(const ndi_interp2d* h, uint64_t nq, void* out, uint64_t out_row_stride,
+                                              void* stream, int32_t reps, double* ms) {
+  if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
+  NDI_TRY
+  return h->impl->probe_ceiling(nq, out, out_row_stride, stream, reps, ms);
   NDI_CATCH
 }
 

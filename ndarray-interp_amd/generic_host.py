@@ -28,16 +28,47 @@ def _div(a, b, integer: bool):
     return q if (a < 0) == (b < 0) else -q
 
 
-def calc_frac(p1, p2, x, integer: bool):
+class _IntRange:
+    """Every intermediate of the integer path must be representable in the element type T, as in the reference's
+    `T` arithmetic: a Rust debug build panics with "attempt to subtract / multiply / add with overflow" (a release
+    build wraps; results that only exist through wrapping are not reproduced -- the panic is)."""
+
+    def __init__(self, dt):
+        info = np.iinfo(dt)
+        self.lo, self.hi = int(info.min), int(info.max)
+
+    def check(self, v: int, op: str) -> int:
+        if v < self.lo or v > self.hi:
+            raise Panic(f"attempt to {op} with overflow")
+        return v
+
+
+def calc_frac(p1, p2, x, integer: bool, rng: "_IntRange | None" = None):
     """Linear::calc_frac (linear.rs:29-36): m = (y2 - y1) / (x2 - x1); m * (x - x1) + y1."""
     (x1, y1), (x2, y2) = p1, p2
-    m = _div(y2 - y1, x2 - x1, integer)
-    return m * (x - x1) + y1
+    if not integer or rng is None:
+        m = _div(y2 - y1, x2 - x1, integer)
+        return m * (x - x1) + y1
+    dy = rng.check(y2 - y1, "subtract")
+    dx = rng.check(x2 - x1, "subtract")
+    m = rng.check(_div(dy, dx, True), "divide")          # i32::MIN / -1
+    d = rng.check(x - x1, "subtract")
+    return rng.check(rng.check(m * d, "multiply") + y1, "add")
 
 
 def _scalar(v, dt):
-    """Element-type arithmetic: Python ints for integer types (exact), numpy scalars otherwise."""
-    return int(v) if _is_int(dt) else np.dtype(dt).type(v)
+    """Element-type arithmetic: Python ints for integer types (exact, range-checked by the caller), numpy scalars
+    otherwise.  A query that is not a value of the integer element type (2.7 for i32 data) is a type error in
+    the reference (the query type IS the element type), so it is refused here instead of being truncated."""
+    if not _is_int(dt):
+        return np.dtype(dt).type(v)
+    if isinstance(v, (float, np.floating)) and float(v) != int(v):
+        raise TypeError(f"query {v!r} is not a value of the element type {np.dtype(dt)}")
+    iv = int(v)
+    info = np.iinfo(dt)
+    if iv < info.min or iv > info.max:
+        raise TypeError(f"query {v!r} is out of range for the element type {np.dtype(dt)}")
+    return iv
 
 
 def lower_index(knots, x, integer: bool) -> int:
@@ -71,6 +102,7 @@ class HostLinear:
     def __init__(self, x, data, extrapolate: bool):
         self._dt = np.asarray(data).dtype
         self._int = _is_int(self._dt)
+        self._rng = _IntRange(self._dt) if self._int else None
         self._x = [_scalar(v, self._dt) for v in np.asarray(x).reshape(-1)]
         self._rows = np.asarray(data).reshape(len(self._x), -1)
         self._extrapolate = bool(extrapolate)
@@ -84,7 +116,8 @@ class HostLinear:
         y1, y2 = self._rows[i], self._rows[i + 1]
         res = np.empty(y1.size, dtype=self._dt)
         for l in range(res.size):
-            res[l] = calc_frac((k[i], _scalar(y1[l], self._dt)), (k[i + 1], _scalar(y2[l], self._dt)), x, self._int)
+            res[l] = calc_frac((k[i], _scalar(y1[l], self._dt)), (k[i + 1], _scalar(y2[l], self._dt)), x, self._int,
+                               self._rng)
         target[...] = res.reshape(target.shape)      # target may be a strided view
 
     # trait default: the reference's serial query loop, stopping at the first Err (interp1d/mod.rs:326-343)
@@ -107,6 +140,7 @@ class HostBilinear:
         d = np.asarray(data)
         self._dt = d.dtype
         self._int = _is_int(self._dt)
+        self._rng = _IntRange(self._dt) if self._int else None
         self._x = [_scalar(v, self._dt) for v in np.asarray(x).reshape(-1)]
         self._y = [_scalar(v, self._dt) for v in np.asarray(y).reshape(-1)]
         self._grid = d.reshape(len(self._x), len(self._y), -1)
@@ -125,9 +159,9 @@ class HostBilinear:
         res = np.empty(g.shape[2], dtype=self._dt)
         for l in range(res.size):
             z11, z12, z21, z22 = s(g[xi, yi, l]), s(g[xi, yi + 1, l]), s(g[xi + 1, yi, l]), s(g[xi + 1, yi + 1, l])
-            z1 = calc_frac((x1, z11), (x2, z21), x, self._int)           # bilinear.rs:88-97
-            z2 = calc_frac((x1, z12), (x2, z22), x, self._int)
-            res[l] = calc_frac((y1, z1), (y2, z2), y, self._int)
+            z1 = calc_frac((x1, z11), (x2, z21), x, self._int, self._rng)           # bilinear.rs:88-97
+            z2 = calc_frac((x1, z12), (x2, z22), x, self._int, self._rng)
+            res[l] = calc_frac((y1, z1), (y2, z2), y, self._int, self._rng)
         target[...] = res.reshape(target.shape)
 
     def interp_array_into(self, interpolator, xs_flat, ys_flat, out2d, **_kw):

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <exception>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -176,10 +177,27 @@ size_t lower_index_generic(const std::vector<T>& k, T x) {
   return lo;
 }
 // Linear::calc_frac (linear.rs:29-36) with the element type's own arithmetic (integer division truncates)
+// Integer T: every intermediate must be representable in T, as in the reference's `T` arithmetic -- a Rust debug
+// build panics with "attempt to subtract / multiply / add with overflow" (a release build wraps; values that only
+// exist through wrapping are not reproduced, the panic is).  Same behaviour as generic_host.py.
 template <class T>
 T calc_frac(T x1, T y1, T x2, T y2, T x) {
-  const T m = (y2 - y1) / (x2 - x1);
-  return m * (x - x1) + y1;
+  if constexpr (std::is_integral_v<T>) {
+    T dy, dx, d, p, r;
+    if (__builtin_sub_overflow(y2, y1, &dy) || __builtin_sub_overflow(x2, x1, &dx))
+      throw Panic("attempt to subtract with overflow");
+    if (dx == 0) throw Panic("attempt to divide by zero");
+    if constexpr (std::is_signed_v<T>)
+      if (dy == std::numeric_limits<T>::min() && dx == T(-1)) throw Panic("attempt to divide with overflow");
+    const T m = dy / dx;
+    if (__builtin_sub_overflow(x, x1, &d)) throw Panic("attempt to subtract with overflow");
+    if (__builtin_mul_overflow(m, d, &p)) throw Panic("attempt to multiply with overflow");
+    if (__builtin_add_overflow(p, y1, &r)) throw Panic("attempt to add with overflow");
+    return r;
+  } else {
+    const T m = (y2 - y1) / (x2 - x1);
+    return m * (x - x1) + y1;
+  }
 }
 template <class T>
 std::string debug_value(T v) {

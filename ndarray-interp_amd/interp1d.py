@@ -60,6 +60,7 @@ class _DeviceStrategy1D(Interp1DStrategy):
         self._device = 0
         self._np_dtype = None
         self._lanes = 1
+        self._inflight = []
 
     # -- build ------------------------------------------------------------------------------
     def _create(self, x, data, *, extrapolate, periodic=False, left=(0, 0.0), right=(0, 0.0),
@@ -121,8 +122,9 @@ class _DeviceStrategy1D(Interp1DStrategy):
         opts.q_memspace = qb.memspace
         opts.path = self.path
         opts.async_launch = int(bool(async_launch))
-        # an async batch reads the query array until finish(): keep our (possibly converted) copy alive
-        self._inflight = qb if async_launch else None
+        # an async batch reads the query array until finish(): keep every (possibly converted) copy alive
+        if async_launch:
+            self._inflight.append(qb)
         if is_torch(out2d):
             if not out2d.is_cuda:
                 raise TypeError("torch output buffers must live on the device; use numpy for host buffers")
@@ -146,7 +148,7 @@ class _DeviceStrategy1D(Interp1DStrategy):
         """Completes `async_launch` evaluations on the current stream and raises their error, if any."""
         info = _capi.OobInfo()
         st = _capi.lib().ndi_interp1d_finish(self._h, current_stream_ptr(self._device), C.byref(info))
-        self._inflight = None
+        self._inflight.clear()
         if st != _capi.OK:
             raise_eval(st, info)
 
@@ -546,9 +548,12 @@ class Interp1D:
         done = nq
         try:
             self.strategy.interp_array_into(self, _host(xs_flat), tmp, **kw)
-        except InterpolateError.OutOfBounds as e:
-            done = e.index if e.index is not None else 0   # rows before the failing query are written,
-            raise                                          # later rows stay untouched (interp1d/mod.rs:334-342)
+        except (InterpolateError.OutOfBounds, Panic) as e:
+            done = e.index if getattr(e, "index", None) is not None else 0   # rows before the failing query are
+            raise                                          # written, later rows stay untouched (interp1d/mod.rs:334-342)
+        except BaseException:
+            done = 0                                       # device failure: nothing in tmp can be trusted
+            raise
         finally:
             if done and len(xs.shape) == 0:
                 buffer[...] = tmp[0].reshape(buffer.shape)

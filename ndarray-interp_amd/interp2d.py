@@ -53,6 +53,7 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
         self._device_req = None
         self._np_dtype = None
         self._lanes = 1
+        self._inflight = []
 
     @staticmethod
     def new() -> "Bilinear":
@@ -125,7 +126,8 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
         if qx.memspace != qy.memspace:
             raise TypeError("xs and ys must live in the same memory space")
         _check_out_dtype(out2d, self._np_dtype)
-        self._inflight = (qx, qy) if async_launch else None   # read until finish()
+        if async_launch:                      # every async batch reads its query arrays until finish():
+            self._inflight.append((qx, qy))   # keep all (possibly converted) copies alive, not only the last
         opts = _capi.EvalOpts()
         opts.q_memspace = qx.memspace
         opts.path = self.path
@@ -152,12 +154,23 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
     def finish(self):
         info = _capi.OobInfo()
         st = _capi.lib().ndi_interp2d_finish(self._h, current_stream_ptr(self._device), C.byref(info))
-        self._inflight = None
+        self._inflight.clear()
         if st != _capi.OK:
             raise_eval(st, info)
 
     def trim(self):
         _capi.lib().ndi_interp2d_trim(self._h)
+
+    def probe_ceiling(self, out2d, reps=5) -> float:
+        """ms of the evaluation kernel's memory access mix alone on this handle's grid (ndi_interp2d_probe_ceiling);
+        `out2d`: a device tensor (nq, lanes) that is overwritten."""
+        ms = C.c_double()
+        st = _capi.lib().ndi_interp2d_probe_ceiling(self._h, out2d.shape[0], out2d.data_ptr(), out2d.stride(0),
+                                                    current_stream_ptr(self._device), int(reps), C.byref(ms))
+        if st != _capi.OK:
+            from .errors import DeviceError
+            raise DeviceError(_capi.last_error())
+        return ms.value
 
     def interp_array_ring(self, xs_flat, ys_flat, chunk_queries, consumer=None, *, slots=None, n_slots=2):
         """ndi_interp2d_eval_ring; see `_DeviceStrategy1D.interp_array_ring`."""
@@ -327,9 +340,12 @@ class Interp2D:
         done = nq
         try:
             self.strategy.interp_array_into(self, xf, yf, tmp, **kw)
-        except InterpolateError.OutOfBounds as e:
-            done = e.index if e.index is not None else 0   # rows before the failing query are written,
-            raise                                          # later rows stay untouched (interp2d/mod.rs:297-306)
+        except (InterpolateError.OutOfBounds, Panic) as e:
+            done = e.index if getattr(e, "index", None) is not None else 0   # rows before the failing query are
+            raise                                          # written, later rows stay untouched (interp2d/mod.rs:297-306)
+        except BaseException:
+            done = 0                                       # device failure: nothing in tmp can be trusted
+            raise
         finally:
             if done and len(xs.shape) == 0:
                 buffer[...] = tmp[0].reshape(buffer.shape)

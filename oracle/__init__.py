@@ -60,7 +60,9 @@ def use_native() -> str:
     global _lib
     import platform
     import tempfile
-    out = os.path.join(tempfile.gettempdir(), f"liboracle_native_{platform.node()}.so")
+    # a private directory (mode 0700, unique name): nothing else can replace the file between the compile and the
+    # dlopen, and concurrent ranks / tests never overwrite a library another process has mapped
+    out = os.path.join(tempfile.mkdtemp(prefix="liboracle_native_"), f"liboracle_native_{platform.node()}.so")
     try:
         subprocess.run(["g++", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC",
                         "-fvisibility=hidden", "-pthread", "-shared", "-o", out, os.path.join(_HERE, "oracle.cpp")],

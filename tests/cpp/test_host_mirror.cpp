@@ -55,6 +55,17 @@ static void host_only() {
   CHECK(monotonic_prop<double>({1.1, 2.0, 3.123, 3.123, 4.5}) == Monotonic::Rising);
   CHECK(monotonic_prop<float>({5.8f, 4.1f, 3.1f, 3.1f, 2.0f}) == Monotonic::Falling);
   CHECK(monotonic_prop<double>({1, 1, 1}) == Monotonic::NotMonotonic);
+  {  // integer overflow = the reference's debug-build panic (tests/golden/reference_integer_vectors.json,
+     // derived_integer_overflow): u32 descending values, i32 difference / product out of range
+    auto ud = Interp1DBuilder<unsigned>::new_(Array<unsigned>::from_vec({10u, 4u})).x({0u, 2u}).build();
+    CHECK(throws<Panic>([&] { ud.interp_scalar(1u); }));
+    auto uu = Interp1DBuilder<unsigned>::new_(Array<unsigned>::from_vec({4u, 10u})).x({0u, 2u}).build();
+    CHECK(uu.interp_scalar(1u) == 7u);
+    auto big = Interp1DBuilder<int>::new_(Array<int>::from_vec({-2000000000, 2000000000})).x({0, 1}).build();
+    CHECK(throws<Panic>([&] { big.interp_scalar(1); }));
+    auto ex = Interp1DBuilder<int>::new_(Array<int>::from_vec({0, 60000})).x({0, 1}).strategy(Linear<int>::new_().extrapolate(true)).build();
+    CHECK(throws<Panic>([&] { ex.interp_scalar(60000); }));
+  }
   // ---- integer element types: the reference's generic per-query path, no device ----
   {  // tests/interp2d.rs:29-47 (i32 data, default axes / i32 x axis), :63-82 (out of bounds, x before y)
     Array<int> d({3, 4}, std::vector<int>{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12});

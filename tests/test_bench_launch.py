@@ -24,6 +24,22 @@ def test_bench_self_launches_two_ranks():
     assert r.returncode == 0, r.stderr
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["max_over_ranks"] == 2.0
+    # the N > 1 line verifies itself: world size, backend, every rank's clock and device
+    rk = line["ranks"]
+    assert rk["world"] == 2 and rk["backend"] == "gloo" and rk["per_rank_ms"] == [1.0, 2.0]
+    assert rk["per_rank_kernel_ms"] == [0.5, 1.5] and rk["slowest_rank"] == 1 and rk["distinct_devices"] == 2
+    assert [d["rank"] for d in rk["devices"]] == [0, 1]
+
+
+def test_bench_a_failing_rank_takes_the_others_down():
+    """a rank that dies must not leave its siblings (and the driver) waiting in a collective."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["NDI_BENCH_FAIL_RANK"] = "1"
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-rehearsal"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 120
 
 
 def test_bench_runs_under_an_external_launcher():
@@ -40,4 +56,26 @@ def test_bench_single_rank_rehearsal():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch-rehearsal"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert _one_json_line(r.stdout)["n_gpus"] == 1
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["ranks"] is None
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_line_carries_ranks():
+    """The real N = 2 code path on a 1-GPU box (gloo, both ranks on device 0, a small Target-shaped workload): the
+    JSON line carries `ranks` with both ranks' clocks, kernel times and the device they ran on."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--device-override", "0", "--knots", "512", "--lanes", "1024", "--queries", "400000",
+                        "--chunk", "100000", "--steps", "3", "--warmup", "1", "--placement-probe", "0",
+                        "--no-gather-leg"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _one_json_line(r.stdout)
+    rk = line["ranks"]
+    assert line["n_gpus"] == 2 and rk["world"] == 2 and rk["backend"] == "gloo" and len(rk["per_rank_ms"]) == 2
+    assert all(v > 0 for v in rk["per_rank_ms"] + rk["per_rank_kernel_ms"])
+    assert [d["ordinal"] for d in rk["devices"]] == [0, 0] and rk["distinct_devices"] == 1
+    assert line["ms_per_step"] >= max(rk["per_rank_ms"]) * 0.999 and line["check"]["bit_exact"]

@@ -134,6 +134,26 @@ def test_integer_linear_truncating_division(pkg):
         pkg.Interp1DBuilder.new(np.array([1, 2, 3])).strategy(pkg.CubicSpline.new()).build()
 
 
+def test_integer_overflow_panics_like_a_rust_debug_build(pkg):
+    """intermediates of the integer path live in the element type T (linear.rs:29-36); an overflow is
+    the reference's debug-build panic, never a silently wrong value, and a non-integral query is refused."""
+    for c in _intvec()["derived_integer_overflow"]:
+        dt = np.dtype(c["dtype"])
+        strat = pkg.Linear.new().extrapolate(bool(c.get("extrapolate", False)))
+        interp = pkg.Interp1DBuilder.new(np.array(c["data"], dtype=dt)).x(np.array(c["x"], dtype=dt)).strategy(strat).build()
+        if "panic" in c:
+            with pytest.raises(pkg.Panic, match=c["panic"]):
+                interp.interp_scalar(c["query"])
+            with pytest.raises(pkg.Panic, match=c["panic"]):
+                interp.interp_array(np.array([c["query"]], dtype=dt))
+        else:
+            assert interp.interp_scalar(c["query"]) == c["expect"]
+    interp = pkg.Interp1DBuilder.new(np.array([0, 10, 20], dtype=np.int32)).build()
+    with pytest.raises(TypeError, match="not a value of the element type int32"):
+        interp.interp_scalar(1.7)
+    assert interp.interp_scalar(1.0) == 10          # an integral float is the same value
+
+
 def test_integer_builder_errors(pkg):
     """tests/interp1d.rs:122-140, tests/interp2d.rs:281-329 with their i32 arrays."""
     v = _intvec()

@@ -66,6 +66,27 @@ def synth_target_queries(x, nq, chunk, rank):
     return np.concatenate(parts)
 
 
+def usable_cores():
+    """Cores this process may actually run on: the affinity mask, capped by a cgroup CPU quota when there is one
+    (a GPU box hands each job a share of a large host: os.cpu_count() alone overstates it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(x, y, q_all, budget_s=20.0):
     """The CPU port (oracle/, -ffp-contract=off) timed on this box's host cores on a bounded sample of the
     same workload: blocks of 2048 queries into a reused output block until ~budget_s of CPU work."""
@@ -78,9 +99,9 @@ def cpu_baseline(x, y, q_all, budget_s=20.0):
     build_s = time.perf_counter() - t0
     assert st == oracle.OK
     res = {}
-    ncpu = os.cpu_count() or 1
-    legs = [("1t", 1, budget_s / 2), ("all", ncpu, budget_s / 2)]       # 1 thread and all host cores
-    if ncpu > 16:
+    ncpu, usable = os.cpu_count() or 1, usable_cores()
+    legs = [("1t", 1, budget_s / 2), ("all", usable, budget_s / 2)]     # 1 thread and all host cores
+    if usable > 16:                                                     # this process may use (affinity / cgroup quota)
         legs.append(("share", 16, budget_s / 4))                        # 16 threads = one GPU's share of the box
     for label, threads, budget in legs:
         blk = 2048 if threads == 1 else 512 * threads
@@ -97,7 +118,7 @@ def cpu_baseline(x, y, q_all, budget_s=20.0):
             pos += blk
         res[label] = (done * lanes / t_used / 1e6, done, threads)
     res["flags"] = flags
-    res["host_cores"] = ncpu
+    res["host_cores"], res["usable_cores"] = ncpu, usable
     return res, build_s
 
 
@@ -564,7 +585,7 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         line["cpu_baseline"] = {"value": round(v1, 1), "unit": "Mpoints/s", "cores": 1, "kind": "port",
                                 "sample": f"{done1} queries x {lanes} lanes of the same workload (~10 s), oracle/ serial "
                                           "loop in blocks of 2048 queries (the reference is single-threaded)",
-                                "host_cores": res["host_cores"],
+                                "host_cores": res["host_cores"], "usable_cores": res["usable_cores"],
                                 "all_cores": {"value": round(vall, 1), "cores": threads,
                                               "sample": f"{doneall} queries (~10 s), contiguous query blocks per thread"},
                                 "per_gpu_share": ({"value": round(res["share"][0], 1), "cores": 16,

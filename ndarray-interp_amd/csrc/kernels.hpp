@@ -17,7 +17,7 @@
 //   eval_bucketed_kernel   BUCKETED formulation: grouped order, operand rows held in registers across a
 //                          group, output streamed; XCD-aware chunk order
 //   eval_bilinear_kernel   2-D (bilinear.rs:83-97), plain or pair-packed grid (pack_pairs_kernel);
-//                          tile_hist_kernel + group_scatter2d_kernel give the optional tile-grouped order
+//                          locate2_kernel's tile histogram + group_scatter2d_kernel give the tile-grouped order
 //   spline_build_*         batched Thomas solve, one lane of the trailing axes per thread, shared (or
 //                          per-lane selected) elimination factors          (cubic_spline.rs:310-368, 409-721)
 //
@@ -381,6 +381,10 @@ struct Locate2Args {
   int mode;
   uint64_t slice;
   BucketIndex<T> bx, by;   // bucket indices, staged behind the two pyramids when non-null
+  // tile-grouped order (2-D BUCKETED): workgroup b also leaves the histogram of its slice over the tiles of
+  // 2^sx x 2^sy cells in hist[b][nb] (LDS atomics, as locate_kernel does for the 1-D intervals)
+  uint32_t* hist;
+  uint32_t nb, sx, sy, nty;
 };
 
 template <class T>
@@ -413,6 +417,16 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
     if (wx) lutx = (lds_u16)(smem_raw + off);
     if (wy) luty = (lds_u16)(smem_raw + off + (size_t)wx * 4u);
   }
+  uint32_t* s_hist = nullptr;
+  if (A.hist) {   // [x pyramid | y pyramid | x lut | y lut | tile histogram]
+    size_t off = ((size_t)(nxa + nya) * sizeof(T) + 15u) & ~(size_t)15u;
+    if (A.bx.lut) off += (size_t)((A.bx.m + 2u) / 2u) * 4u;
+    if (A.by.lut) off += (size_t)((A.by.m + 2u) / 2u) * 4u;
+    off = (off + 15u) & ~(size_t)15u;
+    s_hist = reinterpret_cast<uint32_t*>(smem_raw + off);
+    for (uint32_t i = tid; i < A.nb; i += blockDim.x) s_hist[i] = 0u;
+    __syncthreads();
+  }
   const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
   const uint32_t lane = tid & 63u;
   const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
@@ -439,6 +453,12 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
     if (bady) atomicMin(&A.first_fail[1], (unsigned long long)qi);
     A.xi[qi] = ix;
     A.yi[qi] = iy;
+    if (s_hist) atomicAdd(&s_hist[(ix >> A.sx) * A.nty + (iy >> A.sy)], 1u);
+  }
+  if (s_hist) {
+    __syncthreads();
+    uint32_t* dst = A.hist + (uint64_t)blockIdx.x * A.nb;
+    for (uint32_t i = tid; i < A.nb; i += blockDim.x) dst[i] = s_hist[i];
   }
 }
 
@@ -924,9 +944,13 @@ struct Eval2Args {
   // pack_pairs_kernel): row_cells = ny - 1, cell_elems = 2 * lanes.  z12 is always z11 + lanes.
   uint64_t row_cells, cell_elems;
   const StatusBlock* status;
-  // tile-grouped order (nullptr: query order): per grouped position the query's record
-  const uint4* rec_i;    // {query index, xi, yi, 0}
-  const T* rec_q;        // {qx, qy} pairs
+  // tile-grouped order (nullptr: query order): per grouped position the query's record (group_scatter2d_kernel)
+  const uint4* rec_i;    // {query index, xi, yi, 0}, or the compact {query index, xi | yi << 16, qx, qy} (f32)
+  const T* rec_q;        // {qx, qy} pairs; nullptr with compact records
+  // eval_bilinear_tiles_kernel: bin_start[b] = first grouped position of tile b (exclusive scan of the tile counts),
+  // tiles of 2^ts x 2^ts cells, ntx x nty of them, `chunk` grouped positions per unit of work
+  const uint32_t* bin_start;
+  uint32_t nb, ts, nty, chunk;
 };
 
 template <class T, bool LDS>
@@ -934,36 +958,18 @@ struct KnotPtr { using type = const T*; };
 template <class T>
 struct KnotPtr<T, true> { using type = const __attribute__((address_space(3))) T*; };
 
-// 2-D grouping key: the tile (2^sx x 2^sy cells) a query's cell falls in.  One workgroup per contiguous
-// query slice; leaves the keys and the slice's tile histogram (same layout as locate_kernel's).
-__global__ __launch_bounds__(1024) void tile_hist_kernel(const uint32_t* xi, const uint32_t* yi, uint64_t nq,
-                                                         uint64_t slice, uint32_t sx, uint32_t sy, uint32_t nty,
-                                                         uint32_t nb, uint32_t* key, uint32_t* hist) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem_raw);
-  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_hist[i] = 0u;
-  __syncthreads();
-  const uint64_t q_begin = (uint64_t)blockIdx.x * slice;
-  uint64_t q_end = q_begin + slice;
-  if (q_end > nq) q_end = nq;
-  for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += blockDim.x) {
-    const uint32_t k = (xi[qi] >> sx) * nty + (yi[qi] >> sy);
-    key[qi] = k;
-    atomicAdd(&s_hist[k], 1u);
-  }
-  __syncthreads();
-  uint32_t* dst = hist + (uint64_t)blockIdx.x * nb;
-  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) dst[i] = s_hist[i];
-}
-
-// Places every query's record at its tile-grouped position (block-local cursors in LDS, see
-// group_scatter_kernel): sequential reads in query order, one 16-byte and one 2*sizeof(T) write per query.
-template <class T>
-__global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* key, const uint32_t* xi,
-                                                                const uint32_t* yi, const T* qx, const T* qy,
-                                                                uint64_t nq, uint64_t slice,
+// 2-D grouping (tile-grouped order): locate2_kernel leaves one tile histogram per query slice (the key of a query
+// is the tile of 2^sx x 2^sy cells its cell falls in); group_offsets_kernel / bucket_scan_kernel turn them into
+// start offsets as in the 1-D case; this kernel re-reads each slice and places every query's record at its grouped
+// position with block-local LDS cursors.  COMPACT (f32, both axes < 65536 knots): one self-contained 16-byte record
+// {query index, xi | yi << 16, bits(qx), bits(qy)} -- the evaluation then reads ONE sequential 16-byte stream and
+// never touches xi / yi / qx / qy by query index; otherwise {query index, xi, yi} + a {qx, qy} pair per position.
+template <class T, bool COMPACT>
+__global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* xi, const uint32_t* yi, const T* qx,
+                                                                const T* qy, uint64_t nq, uint64_t slice,
                                                                 const uint32_t* slice_off, const uint32_t* base,
-                                                                uint32_t nb, uint4* rec_i, T* rec_q) {
+                                                                uint32_t nb, uint32_t sx, uint32_t sy, uint32_t nty,
+                                                                uint4* rec_i, T* rec_q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem_raw);
   const uint32_t* off = slice_off + (uint64_t)blockIdx.x * nb;
@@ -973,10 +979,17 @@ __global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* k
   uint64_t q_end = q_begin + slice;
   if (q_end > nq) q_end = nq;
   for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += blockDim.x) {
-    const uint32_t pos = atomicAdd(&cur[key[qi]], 1u);
-    rec_i[pos] = make_uint4((uint32_t)qi, xi[qi], yi[qi], 0u);
-    rec_q[2 * (uint64_t)pos] = qx[qi];
-    rec_q[2 * (uint64_t)pos + 1] = qy[qi];
+    const uint32_t ix = xi[qi], iy = yi[qi];
+    const T x = qx[qi], y = qy[qi];
+    const uint32_t pos = atomicAdd(&cur[(ix >> sx) * nty + (iy >> sy)], 1u);
+    if constexpr (COMPACT && sizeof(T) == 4) {
+      rec_i[pos] = make_uint4((uint32_t)qi, ix | (iy << 16), __builtin_bit_cast(uint32_t, x),
+                              __builtin_bit_cast(uint32_t, y));
+    } else {
+      rec_i[pos] = make_uint4((uint32_t)qi, ix, iy, 0u);
+      rec_q[2 * (uint64_t)pos] = x;
+      rec_q[2 * (uint64_t)pos + 1] = y;
+    }
   }
 }
 
@@ -1039,7 +1052,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
   if (A.status->first_fail[1] < limit) limit = A.status->first_fail[1];
   if (limit > A.nq) limit = A.nq;
   // grouped order covers every query (rows at/after the first failure are skipped one by one)
-  const uint64_t span = A.rec_i ? A.nq : limit;
+  const uint64_t span = limit;
   const uint64_t ntiles = (span + tile_q - 1) / tile_q;
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint64_t q0 = tile * tile_q;
@@ -1057,20 +1070,10 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
         const uint32_t ql = live[k] ? it / LV : 0u;
         v[k] = live[k] ? it - ql * LV : 0u;
         qi[k] = q0 + ql;
-        if (A.rec_i) {
-          const uint4 r = A.rec_i[qi[k]];
-          x[k] = A.rec_q[2 * qi[k]];
-          y[k] = A.rec_q[2 * qi[k] + 1];
-          qi[k] = r.x;
-          xi[k] = r.y;
-          yi[k] = r.z;
-          if (qi[k] >= limit) live[k] = false;
-        } else {
-          xi[k] = A.xi[qi[k]];
-          yi[k] = A.yi[qi[k]];
-          x[k] = A.qx[qi[k]];
-          y[k] = A.qy[qi[k]];
-        }
+        xi[k] = A.xi[qi[k]];
+        yi[k] = A.yi[qi[k]];
+        x[k] = A.qx[qi[k]];
+        y[k] = A.qy[qi[k]];
       }
       T x1[UNR], x2[UNR], y1[UNR], y2[UNR];
       V a11[UNR], a12[UNR], a21[UNR], a22[UNR];
@@ -1090,9 +1093,143 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
         const V z1 = frac_v<T, V, APPROX>(x1[k], a11[k], x2[k], a21[k], x[k]);
         const V z2 = frac_v<T, V, APPROX>(x1[k], a12[k], x2[k], a22[k], x[k]);
         V* o = reinterpret_cast<V*>(A.out + qi[k] * A.out_stride);
-        if (live[k]) o[v[k]] = frac_v<T, V, APPROX>(y1[k], z1, y2[k], z2, y[k]);
+        // written once, never re-read by the kernel: non-temporal (C3 -3 %, C5 share -4 %: profiles/r03_c3_grouped.md)
+        if (live[k]) __builtin_nontemporal_store(frac_v<T, V, APPROX>(y1[k], z1, y2[k], z2, y[k]), o + v[k]);
       }
     }
+  }
+}
+
+// TILE-GROUPED 2-D evaluation (ndi_path BUCKETED / AUTO for long batches on large grids).  The queries have been
+// grouped by the tile of 2^ts x 2^ts cells their cell falls in (locate2_kernel's LDS histogram, group_offsets /
+// bucket_scan, group_scatter2d_kernel), so the grouped positions [bin_start[b], bin_start[b+1]) all need corner rows
+// from the same (2^ts + 1)^2 grid points.  A workgroup takes `chunk` consecutive grouped positions, and for every
+// tile the chunk overlaps it copies the tile's grid points and knots into LDS ONCE (coalesced 16-byte loads of
+// (2^ts + 1) contiguous row segments) and evaluates the tile's queries out of LDS: every grid value is read from
+// memory once per (tile, chunk) instead of four times per query -- at C3 (2.4 queries per cell) 1.2 GB instead of
+// 10.4 GB.  (Ordering the queries by tile alone and letting L2 do the re-use was measured first: the fabric still
+// saw 5.2 GB -- concurrent misses on a line are not merged -- and the kernel stayed latency-bound at 1.45-1.65 ms;
+// profiles/r03_c3_grouped.md.)  Results are bit-identical: same operands, same operation order (bilinear.rs:88-97).
+// LV = lanes / VEC vectors per row must divide BLOCK.  XCD-aware chunk order as in eval_bucketed_kernel.
+template <class T, int VEC, int TB>
+__global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A) {
+  using V = typename VecT<T, VEC>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ uint32_t s_b0;
+  __shared__ uint4 s_rec[TB];
+  __shared__ T s_rq[2 * TB];   // {qx, qy} of non-compact records (f64, or an axis with more than 65536 knots)
+  const uint32_t S = 1u << A.ts, S1 = S + 1u;
+  const uint32_t LV = (uint32_t)(A.lanes / VEC);
+  V* s_tile = reinterpret_cast<V*>(smem_raw);                              // [S1][S1][LV]
+  T* s_kx = reinterpret_cast<T*>(smem_raw + (size_t)S1 * S1 * LV * sizeof(V));   // [S1]
+  T* s_ky = s_kx + S1;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t qpt = TB / LV;                 // queries per trip
+  const uint32_t ql = tid / LV, v = tid - ql * LV;
+  unsigned long long limit = A.status->first_fail[0];
+  if (A.status->first_fail[1] < limit) limit = A.status->first_fail[1];
+  if (limit > A.nq) limit = A.nq;
+  const uint64_t n_pos = A.nq;                     // every query is grouped; rows at / after the first failure are skipped
+  const uint64_t nchunks = (n_pos + A.chunk - 1) / A.chunk;
+  const uint64_t per = (nchunks + 7) / 8;
+  const bool xcd = (gridDim.x & 7u) == 0u;
+  const uint64_t c_first = xcd ? (uint64_t)(blockIdx.x >> 3) : (uint64_t)blockIdx.x;
+  const uint64_t c_step = xcd ? (uint64_t)(gridDim.x >> 3) : (uint64_t)gridDim.x;
+  const uint64_t c_span = xcd ? per : nchunks;
+  const uint64_t c_base = xcd ? (uint64_t)(blockIdx.x & 7u) * per : 0;
+  for (uint64_t cl = c_first; cl < c_span; cl += c_step) {
+    const uint64_t c = c_base + cl;
+    if (c >= nchunks) break;
+    const uint64_t p0 = c * A.chunk;
+    const uint64_t p1 = (p0 + A.chunk < n_pos) ? p0 + A.chunk : n_pos;
+    if (tid == 0) {   // the tile that holds position p0: the last b with bin_start[b] <= p0
+      uint32_t lo = 0, hi = A.nb;   // invariant bin_start[lo] <= p0 (bin_start[0] = 0)
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)A.bin_start[mid] <= p0) lo = mid; else hi = mid;
+      }
+      s_b0 = lo;
+    }
+    __syncthreads();
+    const uint32_t b0 = s_b0;
+    for (uint32_t b = b0; b < A.nb; ++b) {
+      const uint64_t bs = const_load(A.bin_start, b);
+      const uint64_t be = (b + 1u < A.nb) ? (uint64_t)const_load(A.bin_start, b + 1u) : n_pos;
+      if (bs >= p1) break;
+      const uint64_t lo = bs > p0 ? bs : p0, hi = be < p1 ? be : p1;
+      if (lo >= hi) continue;                       // empty tile (workgroup-uniform)
+      const uint32_t tx = b / A.nty, ty = b - tx * A.nty;
+      const uint64_t gx0 = (uint64_t)tx << A.ts, gy0 = (uint64_t)ty << A.ts;
+      const uint32_t rows = (uint32_t)((A.nx - gx0 < S1) ? A.nx - gx0 : S1);     // grid points of the tile
+      const uint32_t cols = (uint32_t)((A.ny - gy0 < S1) ? A.ny - gy0 : S1);
+      __syncthreads();                              // the previous tile is no longer being read
+      {
+        const uint32_t row_vecs = cols * LV;        // one contiguous segment per grid row
+        const uint32_t items = rows * row_vecs;
+        for (uint32_t it = tid; it < items; it += TB) {
+          const uint32_t r = it / row_vecs, j = it - r * row_vecs;
+          const V* src = reinterpret_cast<const V*>(A.data + ((gx0 + r) * A.ny + gy0) * A.lanes);
+          s_tile[(size_t)r * S1 * LV + j] = src[j];
+        }
+        if (tid < rows) s_kx[tid] = A.xk[gx0 + tid];
+        if (tid >= 64u && tid - 64u < cols) s_ky[tid - 64u] = A.yk[gy0 + (tid - 64u)];
+      }
+      __syncthreads();
+      // The tile's records are brought in 256 at a time (one coalesced 16-byte load per thread) and handed to the
+      // 16-lane groups through LDS; the next block's loads are in flight while the current block is evaluated, so a
+      // workgroup pays one memory latency per 256 queries instead of one per trip.
+      bool compact = false;
+      if constexpr (std::is_same<T, float>::value) compact = A.rec_q == nullptr;
+      uint64_t pb = lo;
+      uint4 r_in = make_uint4(0u, 0u, 0u, 0u);
+      T rx_in = T(0), ry_in = T(0);
+      if (pb + tid < hi) {
+        r_in = A.rec_i[pb + tid];
+        if (!compact) { rx_in = A.rec_q[2 * (pb + tid)]; ry_in = A.rec_q[2 * (pb + tid) + 1]; }
+      }
+      while (pb < hi) {
+        const uint32_t cnt = (hi - pb < (uint64_t)TB) ? (uint32_t)(hi - pb) : (uint32_t)TB;
+        __syncthreads();                            // the previous block's records are no longer being read
+        s_rec[tid] = r_in;
+        if (!compact) { s_rq[2 * tid] = rx_in; s_rq[2 * tid + 1] = ry_in; }
+        __syncthreads();                            // (also: the tile staged above is complete)
+        const uint64_t nxt = pb + TB;
+        if (nxt + tid < hi) {
+          r_in = A.rec_i[nxt + tid];
+          if (!compact) { rx_in = A.rec_q[2 * (nxt + tid)]; ry_in = A.rec_q[2 * (nxt + tid) + 1]; }
+        }
+        for (uint32_t j = ql; j < cnt; j += qpt) {
+          const uint4 r = s_rec[j];
+          uint32_t xi, yi;
+          T x, y;
+          if (compact) {
+            if constexpr (std::is_same<T, float>::value) {
+              x = __builtin_bit_cast(float, r.z);
+              y = __builtin_bit_cast(float, r.w);
+            }
+            xi = r.y & 0xffffu;
+            yi = r.y >> 16;
+          } else {
+            x = s_rq[2 * j];
+            y = s_rq[2 * j + 1];
+            xi = r.y;
+            yi = r.z;
+          }
+          const uint64_t qi = r.x;
+          if (qi >= limit) continue;
+          const uint32_t lx = xi - (uint32_t)gx0, ly = yi - (uint32_t)gy0;
+          const V* z11 = s_tile + ((size_t)lx * S1 + ly) * LV + v;
+          const V a11 = z11[0], a12 = z11[LV], a21 = z11[(size_t)S1 * LV], a22 = z11[(size_t)S1 * LV + LV];
+          const T x1 = s_kx[lx], x2 = s_kx[lx + 1u], y1 = s_ky[ly], y2 = s_ky[ly + 1u];
+          const V z1 = frac_v<T, V>(x1, a11, x2, a21, x);   // bilinear.rs:88-97
+          const V z2 = frac_v<T, V>(x1, a12, x2, a22, x);
+          V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
+          __builtin_nontemporal_store(frac_v<T, V>(y1, z1, y2, z2, y), o + v);
+        }
+        pb = nxt;
+      }
+    }
+    __syncthreads();                                // s_b0 is rewritten by the next chunk
   }
 }
 

@@ -1320,6 +1320,8 @@ struct Interp2DImpl final : Interp2DBase {
   // launch_eval() = the bilinear kernel reading that set.
   struct Plan2 {
     enum Kind { SMALL, GATHER, TILED } kind = GATHER;
+    bool compact = false;   // TILED: self-contained 16-byte records (group_scatter2d_kernel<T, true>)
+    uint32_t ts = 0, nty = 0, nb = 0;   // TILED: tile shift, tiles per grid row, number of tiles
     const T* qx = nullptr;
     const T* qy = nullptr;
     uint64_t nq = 0;
@@ -1328,7 +1330,7 @@ struct Interp2DImpl final : Interp2DBase {
   };
 
   Plan2 prep(hipStream_t s, Scratch& sc, const T* qx, const T* qy, uint64_t nq, T* out, uint64_t out_stride,
-             int path) {
+             int path, bool beside_eval = false) {
     Plan2 P;
     P.qx = qx; P.qy = qy; P.nq = nq; P.out = out; P.out_stride = out_stride;
     sc.idx.reserve(nq * sizeof(uint32_t));
@@ -1350,6 +1352,57 @@ struct Interp2DImpl final : Interp2DBase {
       ps.done();
       return P;
     }
+    // BUCKETED for 2-D = tile grouping: the queries are ordered by the tile of 2^ts x 2^ts cells they fall in and
+    // eval_bilinear_tiles_kernel evaluates tile by tile out of LDS, so every grid value is read from memory once
+    // per tile instead of four times per query.  It pays when a tile sees several queries per cell (C3: 2.4) and
+    // cannot when the batch touches less data than the tiles hold (C5's share: 0.19 queries per cell): AUTO
+    // decides by queries per cell (auto_tiles).  Needs vector rows whose length divides the workgroup, the plain
+    // grid layout, a tile that fits LDS and a tile histogram that fits next to the pyramids in locate2_kernel.
+    constexpr int VNp = Wide<T>::N;
+    const bool vec_ok_p = (lanes % VNp == 0) && (out_stride % VNp == 0) && aligned16(out);
+    const uint64_t LVp = vec_ok_p ? lanes / VNp : 0;
+    static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+    size_t both_l = both;
+    const bool use_lut = lut_env && nq >= 4096 && both <= LDS_STAGE_LIMIT;
+    if (use_lut) {
+      px.ensure_bucket_index();
+      py.ensure_bucket_index();
+      if ((px.lut_bytes || py.lut_bytes) && both + px.lut_bytes + py.lut_bytes <= LDS_STAGE_LIMIT)
+        both_l = both + px.lut_bytes + py.lut_bytes;
+    }
+    auto ntiles_of = [&](uint64_t pts, uint32_t sh) { return (uint32_t)(((pts - 1) + ((uint64_t)1 << sh) - 1) >> sh); };
+    auto tile_bytes = [&](uint32_t sh) {
+      const size_t s1 = ((size_t)1 << sh) + 1;
+      return s1 * s1 * lanes * sizeof(T) + 2 * s1 * sizeof(T) + 16;
+    };
+    uint32_t ts = 0, nty = 0, nb = 0;
+    bool shape_ok = false;
+    if (vec_ok_p && !pair_packed && LVp >= 1 && LVp <= 1024 && 1024 % LVp == 0 && both <= LDS_STAGE_LIMIT &&
+        nx < (1ull << 31) && ny < (1ull << 31)) {
+      static const int ts_env = [] { const char* e = std::getenv("NDI_TILE_TS"); return e ? std::atoi(e) : -1; }();
+      // the largest tile that leaves room for two workgroups per CU, else the largest that fits at all
+      for (size_t budget : {(size_t)76 * 1024, (size_t)118 * 1024}) {   // + 24-32 KiB of static LDS per workgroup
+        for (int sh = 6; sh >= 1 && !shape_ok; --sh) {
+          if (ts_env >= 0 && sh != ts_env) continue;
+          const uint64_t bins = (uint64_t)ntiles_of(nx, sh) * ntiles_of(ny, sh);
+          if (tile_bytes(sh) <= budget && bins <= GROUP_MAX_BINS &&
+              ((both_l + 15) & ~(size_t)15) + (size_t)bins * 4 <= LDS_STAGE_LIMIT) {
+            ts = (uint32_t)sh;
+            nty = ntiles_of(ny, sh);
+            nb = (uint32_t)bins;
+            shape_ok = true;
+          }
+        }
+        if (shape_ok) break;
+      }
+    }
+    const bool can_tile = shape_ok && nq >= 2 && nq < 0xffffffffull;
+    bool tiled = false;
+    if (path == NDI_PATH_BUCKETED) tiled = can_tile;
+    else if (path == NDI_PATH_AUTO) tiled = can_tile && auto_tiles(nq);
+    const uint32_t sx = ts, sy = ts;
+    g_last_path.store(tiled ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
+    uint64_t slice = 0, blocks = 0;
     if (both <= LDS_STAGE_LIMIT) {   // both axes in one launch
       Locate2Args<T> LA{};
       LA.px = px.view; LA.py = py.view;
@@ -1359,79 +1412,72 @@ struct Interp2DImpl final : Interp2DBase {
       LA.mode = mode;
       LA.bx = BucketIndex<T>{nullptr, 0, T(0)};
       LA.by = LA.bx;
-      static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
-      size_t both_l = both;
-      if (lut_env && nq >= 4096) {
-        px.ensure_bucket_index();
-        py.ensure_bucket_index();
-      }
-      if (lut_env && (px.lut_bytes || py.lut_bytes) && nq >= 4096 &&
-          both + px.lut_bytes + py.lut_bytes <= LDS_STAGE_LIMIT) {
+      if (both_l != both) {
         LA.bx = px.bidx;      // [x pyramid | y pyramid | x lut | y lut]; an axis whose formula guess is exact has none
         LA.by = py.bidx;
-        both_l = both + px.lut_bytes + py.lut_bytes;
       }
-      const unsigned threads = threads_for_lds(both_l);
-      uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, 2048));
-      if (LA.bx.lut)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
-        blocks = std::min<uint64_t>(blocks, (uint64_t)cu_count() * std::max<size_t>(1, (160 * 1024) / both_l));
-      uint64_t slice = (nq + blocks - 1) / blocks;
+      size_t shmem = both_l;
+      if (tiled) {
+        sc.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
+        LA.hist = sc.hist.as<uint32_t>();
+        LA.nb = nb; LA.sx = sx; LA.sy = sy; LA.nty = nty;
+        shmem = ((both_l + 15) & ~(size_t)15) + (size_t)nb * 4;
+      }
+      const unsigned threads = beside_eval ? 256u : threads_for_lds(shmem);
+      blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, tiled ? GROUP_MAX_BLOCKS : 2048));
+      if (LA.bx.lut || LA.by.lut || tiled)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
+        blocks = std::min<uint64_t>(blocks, (uint64_t)cu_count() * std::max<size_t>(1, (160 * 1024) / shmem));
+      slice = (nq + blocks - 1) / blocks;
       slice = (slice + threads - 1) / threads * threads;
       blocks = (nq + slice - 1) / slice;
       LA.slice = slice;
       allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T>), (int)LDS_STAGE_LIMIT);
-      launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), both_l, locate2_kernel<T>, LA);
+      launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate2_kernel<T>, LA);
     } else {
       run_locate<T>(s, px, qx, nq, sc.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
       run_locate<T>(s, py, qy, nq, sc.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);
     }
-    // BUCKETED for 2-D = tile grouping: queries are ordered by the tile of cells they fall in, so the
-    // corner rows of a tile are fetched from HBM once and re-served by L2 / Infinity Cache.  Measured on
-    // C3: the evaluation gets 17 % faster but placing the grouped records costs more
-    // than that, so AUTO keeps the gather order; the grouped order stays available as an explicit choice.
-    bool tiled = false;
-    if (path == NDI_PATH_BUCKETED) tiled = nq >= 2 && nq < 0xffffffffull;
-    uint32_t sx = 5, sy = 5;   // 32 x 32 cells per tile, grown until the histogram fits LDS
-    auto tiles = [&](uint32_t cells, uint32_t sh) { return (uint32_t)(((uint64_t)cells + (1u << sh) - 1) >> sh); };
-    while ((uint64_t)tiles((uint32_t)nx - 1, sx) * tiles((uint32_t)ny - 1, sy) > GROUP_MAX_BINS) {
-      if (sx <= sy) ++sx; else ++sy;
-    }
-    g_last_path.store(tiled ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
     if (tiled) {
       P.kind = Plan2::TILED;
-      const uint32_t nty = tiles((uint32_t)ny - 1, sy);
-      const uint32_t nb = tiles((uint32_t)nx - 1, sx) * nty;
-      uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 4095) / 4096, GROUP_MAX_BLOCKS));
-      uint64_t slice = (nq + blocks - 1) / blocks;
-      slice = (slice + BLOCK - 1) / BLOCK * BLOCK;
-      blocks = (nq + slice - 1) / slice;
-      // the two grouping kernels are latency-bound chains (load -> LDS atomic -> scattered store): many waves per CU
-      const unsigned gthreads = slice >= 4096 ? 1024u : (unsigned)BLOCK;
-      sc.t.reserve(nq * sizeof(uint32_t));      // keys
-      sc.perm.reserve(nq * sizeof(uint4));            // grouped records {qi, xi, yi}
-      sc.recq.reserve(nq * 2 * sizeof(T));            // grouped {qx, qy}
-      sc.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
+      P.ts = ts; P.nty = nty; P.nb = nb;
+      P.compact = std::is_same<T, float>::value && nx <= 65536 && ny <= 65536;
+      // the scatter is a latency-bound chain (load -> LDS atomic -> scattered store): many waves per CU
+      const unsigned gthreads = beside_eval ? 256u : (slice >= 4096 ? 1024u : (unsigned)BLOCK);
+      sc.perm.reserve(nq * sizeof(uint4));            // grouped records
+      if (!P.compact) sc.recq.reserve(nq * 2 * sizeof(T));
       sc.counts.reserve((size_t)nb * sizeof(uint32_t));
       sc.cursor.reserve((size_t)nb * sizeof(uint32_t));
-      allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T>), (int)(GROUP_MAX_BINS * 4));
-      allow_dynamic_lds(reinterpret_cast<const void*>(&tile_hist_kernel), (int)(GROUP_MAX_BINS * 4));
+      allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T, true>), (int)(GROUP_MAX_BINS * 4));
+      allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T, false>), (int)(GROUP_MAX_BINS * 4));
       ProfScope ps(s, PC_GROUP);
-      hipLaunchKernelGGL(tile_hist_kernel, dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
-                         (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), nq, slice,
-                         sx, sy, nty, nb, sc.t.as<uint32_t>(), sc.hist.as<uint32_t>());
       hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
                          sc.hist.as<uint32_t>(), (uint32_t)blocks, nb, sc.counts.as<uint32_t>());
       hipLaunchKernelGGL(bucket_scan_kernel<256>, dim3(1), dim3(256), 0, s, sc.counts.as<uint32_t>(), nb,
                          sc.cursor.as<uint32_t>(), st);
-      hipLaunchKernelGGL(group_scatter2d_kernel<T>, dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
-                         (const uint32_t*)sc.t.as<uint32_t>(), (const uint32_t*)sc.idx.as<uint32_t>(),
-                         (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq, slice,
-                         (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(), nb,
-                         sc.perm.as<uint4>(), sc.recq.as<T>());
+      if (P.compact)
+        hipLaunchKernelGGL((group_scatter2d_kernel<T, true>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
+                           (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
+                           slice, (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(),
+                           nb, sx, sy, nty, sc.perm.as<uint4>(), (T*)nullptr);
+      else
+        hipLaunchKernelGGL((group_scatter2d_kernel<T, false>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
+                           (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
+                           slice, (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(),
+                           nb, sx, sy, nty, sc.perm.as<uint4>(), sc.recq.as<T>());
       NDI_HIP(hipGetLastError());
       ps.done();
     }
     return P;
+  }
+
+  // AUTO for 2-D: tile-grouped order when the batch has enough queries per grid cell to pay for staging every
+  // tile once (C3 grid, profiles/r03_c3_grouped.jsonl: 1.4 queries per cell +10 % time, 2.4: -6 %, 4.8: -20 %,
+  // 9.5: -26 %; crossover near 2) and the grid is far larger than what the caches hold anyway.
+  bool auto_tiles(uint64_t nq) const {
+    static const double thr = [] { const char* e = std::getenv("NDI_TILE_QPC"); return e ? std::atof(e) : 2.2; }();
+    const double cells = (double)(nx - 1) * (double)(ny - 1);
+    const size_t grid_bytes = (size_t)nx * ny * lanes * sizeof(T);
+    return (double)nq >= thr * cells && grid_bytes >= ((size_t)256 << 20) && lanes * sizeof(T) >= 64;
   }
 
   void launch_eval(hipStream_t s, Scratch& sc, const Plan2& P) {
@@ -1476,9 +1522,24 @@ struct Interp2DImpl final : Interp2DBase {
     A.status = st;
     A.rec_i = nullptr;
     A.rec_q = nullptr;
+    constexpr int VNt = Wide<T>::N;
     if (P.kind == Plan2::TILED) {
       A.rec_i = sc.perm.as<uint4>();
-      A.rec_q = sc.recq.as<T>();
+      A.rec_q = P.compact ? nullptr : sc.recq.as<T>();
+      A.bin_start = sc.cursor.as<uint32_t>();
+      A.nb = P.nb; A.ts = P.ts; A.nty = P.nty;
+      static const int chunk_env = [] { const char* e = std::getenv("NDI_TILE_CHUNK"); return e ? std::atoi(e) : 0; }();
+      A.chunk = chunk_env > 0 ? (uint32_t)chunk_env : 8192u;   // grouped positions per unit of work (sweep: r03_c3_grouped.md)
+      const size_t s1 = ((size_t)1 << P.ts) + 1;
+      const size_t shm = s1 * s1 * lanes * sizeof(T) + 2 * s1 * sizeof(T) + 16;
+      const uint64_t nchunks = (nq + A.chunk - 1) / A.chunk;
+      const uint64_t resident = (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (shm + 64)));
+      const unsigned gx = (unsigned)((std::max<uint64_t>(1, std::min<uint64_t>(nchunks, resident * 4)) + 7) / 8 * 8);
+      constexpr int TTB = 1024;
+      allow_dynamic_lds(reinterpret_cast<const void*>(&eval_bilinear_tiles_kernel<T, VNt, TTB>),
+                        (int)(160 * 1024 - TTB * (16 + 2 * sizeof(T)) - 512));
+      launch1<T>(s, PC_EVAL, dim3(gx), dim3(TTB), shm, eval_bilinear_tiles_kernel<T, VNt, TTB>, A);
+      return;
     }
     constexpr int VN = Wide<T>::N;
     const bool vec_ok = (lanes % VN == 0) && (P.out_stride % VN == 0) && aligned16(P.out);
@@ -1749,7 +1810,7 @@ struct Interp2DImpl final : Interp2DBase {
       Plan2 P = R.plan0;
       if (k > 0) {
         if (k >= 2) NDI_HIP(hipStreamWaitEvent(R.side, sc.eval_done, 0));
-        P = prep(R.side, sc, qx + off, qy + off, cq, (T*)R.slots[slot], R.pitch, o.path);
+        P = prep(R.side, sc, qx + off, qy + off, cq, (T*)R.slots[slot], R.pitch, o.path, R.side != s);
         NDI_HIP(hipEventRecord(sc.prep_done, R.side));
       }
       NDI_HIP(hipStreamWaitEvent(s, sc.prep_done, 0));

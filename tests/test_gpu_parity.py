@@ -989,3 +989,63 @@ def test_bilinear_large_batch_knots_in_lds(pkg, dt):
         interp.interp_array_into(torch.as_tensor(qx, device="cuda:0"), torch.as_tensor(qy, device="cuda:0"), buf)
     assert ei.value.index == 1_000_000
     assert np.array_equal(buf[:1_000_000].cpu().numpy(), ref[:1_000_000]) and bool((buf[1_000_000:] == -2.0).all())
+
+
+@pytest.mark.parametrize("dt,nx,ny,C", [
+    (np.float32, 70, 50, 32),       # LV = 8
+    (np.float32, 33, 17, 32),       # a single row / column of tiles
+    (np.float32, 130, 257, 64),     # C3's row length, ragged last tiles in both directions
+    (np.float32, 21, 2000, 20),     # LV = 5 does not divide the workgroup -> the gather order
+    (np.float64, 100, 90, 32),      # LV = 16, f64 records ({qx, qy} beside the 16-byte record)
+    (np.float64, 65, 66, 34),       # LV = 17 -> the gather order
+    (np.float64, 40, 30, 3),        # odd trailing axis: no vector rows -> the gather order
+    (np.float32, 300, 300, 16),     # <= 64 bytes per grid point: pair-packed layout -> the gather order
+    (np.float32, 40, 40, 512),      # long rows: a smaller tile (2^ts + 1)^2 x 2 KiB must fit LDS
+])
+def test_bilinear_tile_grouped_lds(pkg, dt, nx, ny, C):
+    """ndi_path BUCKETED for 2-D: queries grouped by tile, every tile staged once in LDS
+    (eval_bilinear_tiles_kernel).  Bit-identical to the oracle and to the gather order, incl. grid-point hits, the
+    last cells of both axes, extrapolation, and the first-error cut; shapes the tiled kernel does not cover take the
+    gather order."""
+    import torch
+    rng = np.random.default_rng(nx * 7 + ny * 3 + C)
+    vn = {np.float32: 4, np.float64: 2}[dt]
+    tiled_ok = C * np.dtype(dt).itemsize > 64 and C % vn == 0 and 1024 % (C // vn) == 0
+    expect = "bucketed" if tiled_ok else "gather"
+    x = knots("rand", nx, rng, dt); y = knots("jit", ny, rng, dt)
+    g = rng.uniform(0, 1, (nx, ny, C)).astype(dt)
+    Q = 40_000
+    qx = rng.uniform(x[0], x[-1], Q).astype(dt); qy = rng.uniform(y[0], y[-1], Q).astype(dt)
+    gi = rng.integers(0, nx - 1, 500); gj = rng.integers(0, ny - 1, 500)
+    qx[:500] = x[gi]; qy[:500] = y[gj]                                   # grid-point hits (left ends: t = 0 is exact)
+    qx[500:503] = [x[-1], x[0], x[-1]]; qy[500:503] = [y[-1], y[-1], y[0]]  # corners: the last cells of both axes
+    interp = pkg.Interp2DBuilder.new(g).x(x).y(y).build()
+    _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy)
+    interp.strategy.path = pkg.PATH_BUCKETED
+    got = interp.interp_array(qx, qy)
+    assert pkg.profile_read(reset=False)["last_path"] == expect
+    check_equal(got, ref, f"tiled {nx}x{ny}x{C}")
+    assert np.array_equal(got[:500], g[gi, gj])
+    # device-resident queries and output, strided output rows
+    outd = torch.full((Q, 2 * C), -5.0, dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda:0")
+    interp.strategy.interp_array_into(interp, torch.as_tensor(qx, device="cuda:0"), torch.as_tensor(qy, device="cuda:0"),
+                                      outd[:, :C])
+    assert np.array_equal(outd[:, :C].cpu().numpy(), ref) and bool((outd[:, C:] == -5.0).all())
+    # extrapolation: queries outside the axes use the end cells
+    ex = pkg.Interp2DBuilder.new(g).x(x).y(y).strategy(pkg.Bilinear.new().extrapolate(True)).build()
+    ex.strategy.path = pkg.PATH_BUCKETED
+    sx, sy = x[-1] - x[0], y[-1] - y[0]
+    qx2 = rng.uniform(x[0] - sx, x[-1] + sx, Q).astype(dt); qy2 = rng.uniform(y[0] - sy, y[-1] + sy, Q).astype(dt)
+    _, _, _, ref2 = oracle.interp2d_bilinear(x, y, g, qx2, qy2, True)
+    check_equal(ex.interp_array(qx2, qy2), ref2, f"tiled extrapolate {nx}x{ny}x{C}")
+    # first error: rows before it written, later rows untouched (interp2d/mod.rs:297-306)
+    qy[31_000] = y[-1] + 1; qx[35_000] = x[0] - 1
+    buf = np.full((Q, C), -3.0, dtype=dt)
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        interp.interp_array_into(qx, qy, buf)
+    assert (ei.value.index, ei.value.axis) == (31_000, 1)
+    assert np.array_equal(buf[:31_000], ref[:31_000]) and np.all(buf[31_000:] == -3.0)
+    # skewed batch: every query in one cell (one tile holds everything; many workgroups stage the same tile)
+    qx3 = rng.uniform(x[3], x[4], Q).astype(dt); qy3 = rng.uniform(y[5], y[6], Q).astype(dt)
+    _, _, _, ref3 = oracle.interp2d_bilinear(x, y, g, qx3, qy3)
+    check_equal(interp.interp_array(qx3, qy3), ref3, f"tiled skewed {nx}x{ny}x{C}")

@@ -233,7 +233,9 @@ def extra_workload(args, pkg, torch, dev, rank, world):
 
 def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
     """One secondary 2-D leg: random-knot axes, uniform in-range queries, device-resident output; HIP-event kernel
-    time from the library's profile, wall-clock end to end (search + evaluation)."""
+    time from the library's profile, wall-clock end to end (search [+ grouping] + evaluation).  Measured with the
+    formulation AUTO picks and, when that is the tile-grouped order, with the gather order as well (the gather
+    order is the one SURVEY 8(d)'s bytes-per-point model describes)."""
     rng = np.random.default_rng(42)
     x = np.unique(rng.uniform(0, 1, 2 * nx).astype(np.float32))[:nx]
     y = np.unique(rng.uniform(0, 1, 2 * nx).astype(np.float32))[:nx]
@@ -245,28 +247,46 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
     qy = torch.as_tensor(np.random.default_rng(96).uniform(y[0], y[-1], nq).astype(np.float32), device=dev)
     out = torch.empty((nq, C), dtype=torch.float32, device=dev)
     step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
-    for _ in range(warmup):
-        step()
-    interp.strategy.finish()
-    pkg.profile_enable(True); pkg.profile_read(reset=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    interp.strategy.finish()
-    el = time.perf_counter() - t0
-    prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
-    kms = prof["eval_ms"] / max(1, prof["eval_launches"])
     alg = nq * C * 20 + nq * 8                                   # 5 x 4 B per point + the query pair
-    res = {"workload": f"2D Bilinear, {nx}x{nx} grid x {C} channels f32, {nq} queries, random knots",
-           "kernel": "eval_bilinear_kernel", "kernel_ms": round(kms, 4),
-           "frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
-           "locate_ms": round(prof["locate_ms"] / max(1, prof["locate_launches"]), 4),
-           "ms_per_step": round(el / steps * 1e3, 4), "Mpoints_s": round(nq * C * steps / el / 1e6, 1)}
+
+    def measure(path):
+        interp.strategy.path = path
+        for _ in range(warmup):
+            step()
+        interp.strategy.finish()
+        pkg.profile_enable(True); pkg.profile_read(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        interp.strategy.finish()
+        el = time.perf_counter() - t0
+        prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
+        kms = prof["eval_ms"] / max(1, prof["eval_launches"])
+        tiled = prof["last_path"] == "bucketed"
+        r = {"path": "tile-grouped" if tiled else "gather",
+             "kernel": "eval_bilinear_tiles_kernel" if tiled else "eval_bilinear_kernel", "kernel_ms": round(kms, 4),
+             "locate_ms": round(prof["locate_ms"] / max(1, prof["locate_launches"]), 4),
+             "group_ms": round(prof["group_ms"] / steps, 4),
+             "ms_per_step": round(el / steps * 1e3, 4), "Mpoints_s": round(nq * C * steps / el / 1e6, 1)}
+        if tiled:   # every grid value once + output + records: the bytes this formulation has to move
+            comp = nx * nx * C * 4 + nq * C * 4 + nq * 16
+            r["compulsory_bytes_per_launch"] = comp
+            r["frac"] = round(comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            r["bound"] = "VALU (12 IEEE f32 divisions per output vector), not HBM: profiles/r03_c3_grouped.md"
+        else:
+            r["algorithmic_bytes_per_launch"] = alg
+            r["frac"] = round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        return r
+
+    res = {"workload": f"2D Bilinear, {nx}x{nx} grid x {C} channels f32, {nq} queries, random knots"}
+    res.update(measure(pkg.PATH_AUTO))
+    if res["path"] != "gather":
+        res["gather_order"] = measure(pkg.PATH_GATHER)
     if probe:      # the same access mix without searches / knots / arithmetic: the memory system's ceiling on this box
         pms = interp.strategy.probe_ceiling(out, reps=7)
         res["access_mix_ceiling_ms"] = round(pms, 4)
-        res["frac_of_measured_ceiling"] = round(pms / kms, 4)
+        res["frac_of_measured_ceiling"] = round(pms / res["kernel_ms"], 4)
     interp.strategy.release()
     del interp, qx, qy, out
     torch.cuda.empty_cache()

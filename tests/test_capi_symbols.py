@@ -27,6 +27,13 @@ def test_header_symbols_are_exported(pkg):
     assert sorted(pkg._capi.SYMBOLS) == names
 
 
+def test_integration_md_binds_every_export():
+    """INTEGRATION.md's Rust `extern "C"` block declares every symbol of the header (and nothing else)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rust = sorted(set(re.findall(r"pub fn (ndi_[a-z0-9_]+)\(", text)))
+    assert rust == _declared_symbols()
+
+
 def test_version_and_error_string(pkg):
     lib = pkg._capi.lib()
     assert lib.ndi_version() == (0 << 16) | 3

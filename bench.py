@@ -273,7 +273,7 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
             comp = nx * nx * C * 4 + nq * C * 4 + nq * 16
             r["compulsory_bytes_per_launch"] = comp
             r["frac"] = round(comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            r["bound"] = "VALU (12 IEEE f32 divisions per output vector), not HBM: profiles/r03_c3_grouped.md"
+            r["bound"] = "arithmetic + tile staging, not HBM: DESIGN.md 4.4, profiles/r03_c3_grouped.md"
         else:
             r["algorithmic_bytes_per_launch"] = alg
             r["frac"] = round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -1100,6 +1100,73 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
   }
 }
 
+// Correctly rounded division of many numerators by ONE divisor (the per-query knot spacing shared by all channels
+// of a row): r = RN(1 / d) is formed once with the IEEE division, then every quotient costs one multiplication and
+// four FMAs -- all available as packed 2 x f32 instructions -- instead of the ~10-instruction IEEE sequence with its
+// quarter-rate reciprocal:
+//     q0 = RN(n r);  e0 = n - d q0 (exact, FMA);  q1 = RN(q0 + e0 r);  e1 = n - d q1 (exact);  q = RN(q1 + e1 r).
+// q0 is within 2^-23 |n / d| of the quotient, so q1 is a faithful rounding of it, and for a faithful q1 and a
+// correctly rounded reciprocal the last step yields RN(n / d) exactly (Markstein's theorem; Muller et al., Handbook
+// of Floating-Point Arithmetic, "division with an FMA") -- provided no intermediate under- or overflows.  The guard
+// keeps divisor and numerators inside an exponent window in which every product and residual is a normal number;
+// it is ONE test per vector: the smallest magnitude of the components >= N_LO (an exact zero therefore takes the
+// IEEE path: flat data lose the speed-up, never the result) and the sum of the magnitudes <= N_HI (a NaN or an
+// infinity makes the sum fail).  Outside the window the lane does the IEEE division.  The explicit FMAs compute
+// exact residuals; they are not contractions of the reference's expression, whose operation order (linear.rs:33-35)
+// is unchanged: m = RN(n / d), then RN(RN(m (x - x1)) + y1).  Pinned against the IEEE path of the gather kernel on
+// all 6.4e8 outputs of C3 (test_full_size_c3_bilinear) and by test_bilinear_tile_grouped_lds (values far outside
+// the window included).
+template <class T>
+struct DivWindow;
+template <>
+struct DivWindow<float> {
+  static constexpr float N_LO = 0x1p-60f, N_HI = 0x1p60f, D_LO = 0x1p-40f, D_HI = 0x1p40f;
+};
+template <>
+struct DivWindow<double> {
+  static constexpr double N_LO = 0x1p-500, N_HI = 0x1p500, D_LO = 0x1p-400, D_HI = 0x1p400;
+};
+template <class T>
+struct SharedDivisor {
+  T d, r;
+  bool ok;
+};
+template <class T>
+__device__ __forceinline__ SharedDivisor<T> shared_divisor(T d) {
+  SharedDivisor<T> s;
+  s.d = d;
+  s.r = T(1) / d;
+  s.ok = (d >= DivWindow<T>::D_LO) && (d <= DivWindow<T>::D_HI);
+  return s;
+}
+__device__ __forceinline__ bool nums_in_window(flt4 n) {
+  const float lo = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
+  const float sum = (fabsf(n.x) + fabsf(n.y)) + (fabsf(n.z) + fabsf(n.w));
+  return (lo >= DivWindow<float>::N_LO) & (sum <= DivWindow<float>::N_HI);
+}
+__device__ __forceinline__ bool nums_in_window(dbl2 n) {
+  const double lo = fmin(fabs(n.x), fabs(n.y));
+  const double sum = fabs(n.x) + fabs(n.y);
+  return (lo >= DivWindow<double>::N_LO) & (sum <= DivWindow<double>::N_HI);
+}
+template <class T, class V>
+__device__ __forceinline__ V div_shared(V n, const SharedDivisor<T>& s) {
+  const V d = V(s.d), r = V(s.r);
+  const V q0 = n * r;
+  const V e0 = __builtin_elementwise_fma(-q0, d, n);
+  const V q1 = __builtin_elementwise_fma(e0, r, q0);
+  const V e1 = __builtin_elementwise_fma(-q1, d, n);
+  V q = __builtin_elementwise_fma(e1, r, q1);
+  if (__builtin_expect(!(s.ok & nums_in_window(n)), 0)) q = n / s.d;   // outside the window: the IEEE division
+  return q;
+}
+// Linear::calc_frac (linear.rs:29-36) with the divisor's reciprocal shared across the row
+template <class T, class V>
+__device__ __forceinline__ V frac_shared(T x1, V y1, const SharedDivisor<T>& dx, V y2, T x) {
+  const V m = div_shared<T, V>(y2 - y1, dx);
+  return m * (x - x1) + y1;
+}
+
 // TILE-GROUPED 2-D evaluation (ndi_path BUCKETED / AUTO for long batches on large grids).  The queries have been
 // grouped by the tile of 2^ts x 2^ts cells their cell falls in (locate2_kernel's LDS histogram, group_offsets /
 // bucket_scan, group_scatter2d_kernel), so the grouped positions [bin_start[b], bin_start[b+1]) all need corner rows
@@ -1123,6 +1190,8 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
   V* s_tile = reinterpret_cast<V*>(smem_raw);                              // [S1][S1][LV]
   T* s_kx = reinterpret_cast<T*>(smem_raw + (size_t)S1 * S1 * LV * sizeof(V));   // [S1]
   T* s_ky = s_kx + S1;
+  T* s_rx = s_ky + S1;   // RN(1 / (kx[i+1] - kx[i])) per interval of the tile, 0 when the spacing is outside the
+  T* s_ry = s_rx + S1;   // divisor window (then the IEEE division is used)
   const uint32_t tid = threadIdx.x;
   const uint32_t qpt = TB / LV;                 // queries per trip
   const uint32_t ql = tid / LV, v = tid - ql * LV;
@@ -1173,6 +1242,17 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
         }
         if (tid < rows) s_kx[tid] = A.xk[gx0 + tid];
         if (tid >= 64u && tid - 64u < cols) s_ky[tid - 64u] = A.yk[gy0 + (tid - 64u)];
+        // one IEEE reciprocal per knot interval of the tile (instead of one per division and lane)
+        if (tid >= 128u && tid - 128u + 1u < rows) {
+          const uint32_t i = tid - 128u;
+          const SharedDivisor<T> sd = shared_divisor<T>(A.xk[gx0 + i + 1u] - A.xk[gx0 + i]);
+          s_rx[i] = sd.ok ? sd.r : T(0);
+        }
+        if (tid >= 192u && tid - 192u + 1u < cols) {
+          const uint32_t i = tid - 192u;
+          const SharedDivisor<T> sd = shared_divisor<T>(A.yk[gy0 + i + 1u] - A.yk[gy0 + i]);
+          s_ry[i] = sd.ok ? sd.r : T(0);
+        }
       }
       __syncthreads();
       // The tile's records are brought in 256 at a time (one coalesced 16-byte load per thread) and handed to the
@@ -1221,10 +1301,13 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
           const V* z11 = s_tile + ((size_t)lx * S1 + ly) * LV + v;
           const V a11 = z11[0], a12 = z11[LV], a21 = z11[(size_t)S1 * LV], a22 = z11[(size_t)S1 * LV + LV];
           const T x1 = s_kx[lx], x2 = s_kx[lx + 1u], y1 = s_ky[ly], y2 = s_ky[ly + 1u];
-          const V z1 = frac_v<T, V>(x1, a11, x2, a21, x);   // bilinear.rs:88-97
-          const V z2 = frac_v<T, V>(x1, a12, x2, a22, x);
           V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
-          __builtin_nontemporal_store(frac_v<T, V>(y1, z1, y2, z2, y), o + v);
+          SharedDivisor<T> dx, dy;
+          dx.d = x2 - x1; dx.r = s_rx[lx]; dx.ok = dx.r > T(0);
+          dy.d = y2 - y1; dy.r = s_ry[ly]; dy.ok = dy.r > T(0);
+          const V z1 = frac_shared<T, V>(x1, a11, dx, a21, x);   // bilinear.rs:88-97
+          const V z2 = frac_shared<T, V>(x1, a12, dx, a22, x);
+          __builtin_nontemporal_store(frac_shared<T, V>(y1, z1, dy, z2, y), o + v);
         }
         pb = nxt;
       }

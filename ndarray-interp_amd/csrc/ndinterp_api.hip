@@ -1373,7 +1373,7 @@ struct Interp2DImpl final : Interp2DBase {
     auto ntiles_of = [&](uint64_t pts, uint32_t sh) { return (uint32_t)(((pts - 1) + ((uint64_t)1 << sh) - 1) >> sh); };
     auto tile_bytes = [&](uint32_t sh) {
       const size_t s1 = ((size_t)1 << sh) + 1;
-      return s1 * s1 * lanes * sizeof(T) + 2 * s1 * sizeof(T) + 16;
+      return s1 * s1 * lanes * sizeof(T) + 4 * s1 * sizeof(T) + 16;
     };
     uint32_t ts = 0, nty = 0, nb = 0;
     bool shape_ok = false;
@@ -1471,10 +1471,10 @@ struct Interp2DImpl final : Interp2DBase {
   }
 
   // AUTO for 2-D: tile-grouped order when the batch has enough queries per grid cell to pay for staging every
-  // tile once (C3 grid, profiles/r03_c3_grouped.jsonl: 1.4 queries per cell +10 % time, 2.4: -6 %, 4.8: -20 %,
-  // 9.5: -26 %; crossover near 2) and the grid is far larger than what the caches hold anyway.
+  // tile once (C3 grid, profiles/r03_c3_grouped.jsonl: 1.4 queries per cell -3 % time, 1.9: -11 %, 2.4 (C3): -18 %,
+  // 4.8: -31 %; below 1 the gather order wins) and the grid is far larger than what the caches hold anyway.
   bool auto_tiles(uint64_t nq) const {
-    static const double thr = [] { const char* e = std::getenv("NDI_TILE_QPC"); return e ? std::atof(e) : 2.2; }();
+    static const double thr = [] { const char* e = std::getenv("NDI_TILE_QPC"); return e ? std::atof(e) : 1.5; }();
     const double cells = (double)(nx - 1) * (double)(ny - 1);
     const size_t grid_bytes = (size_t)nx * ny * lanes * sizeof(T);
     return (double)nq >= thr * cells && grid_bytes >= ((size_t)256 << 20) && lanes * sizeof(T) >= 64;
@@ -1531,7 +1531,7 @@ struct Interp2DImpl final : Interp2DBase {
       static const int chunk_env = [] { const char* e = std::getenv("NDI_TILE_CHUNK"); return e ? std::atoi(e) : 0; }();
       A.chunk = chunk_env > 0 ? (uint32_t)chunk_env : 8192u;   // grouped positions per unit of work (sweep: r03_c3_grouped.md)
       const size_t s1 = ((size_t)1 << P.ts) + 1;
-      const size_t shm = s1 * s1 * lanes * sizeof(T) + 2 * s1 * sizeof(T) + 16;
+      const size_t shm = s1 * s1 * lanes * sizeof(T) + 4 * s1 * sizeof(T) + 16;
       const uint64_t nchunks = (nq + A.chunk - 1) / A.chunk;
       const uint64_t resident = (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (shm + 64)));
       const unsigned gx = (unsigned)((std::max<uint64_t>(1, std::min<uint64_t>(nchunks, resident * 4)) + 7) / 8 * 8);

@@ -1049,3 +1049,51 @@ def test_bilinear_tile_grouped_lds(pkg, dt, nx, ny, C):
     qx3 = rng.uniform(x[3], x[4], Q).astype(dt); qy3 = rng.uniform(y[5], y[6], Q).astype(dt)
     _, _, _, ref3 = oracle.interp2d_bilinear(x, y, g, qx3, qy3)
     check_equal(interp.interp_array(qx3, qy3), ref3, f"tiled skewed {nx}x{ny}x{C}")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_bilinear_tiles_shared_divisor_window(pkg, dt):
+    """The tile kernel divides by the per-query knot spacing with a shared reciprocal + exact-residual FMA
+    corrections inside an exponent window and with the IEEE division outside it (kernels.hpp div_shared).  Grid
+    values and knot spacings chosen to sit inside, at the edges of and far outside the window -- exact zeros (flat
+    regions), denormal-sized and huge differences, mixed signs, a tiny and a huge knot spacing -- must give the
+    oracle's bits, as the gather kernel (IEEE divisions throughout) does."""
+    rng = np.random.default_rng(91)
+    nx, ny, C = 70, 60, 32
+    fin = np.finfo(dt)
+    x = np.cumsum(rng.uniform(0.5, 1.5, nx)).astype(dt)
+    y = np.cumsum(rng.uniform(0.5, 1.5, ny)).astype(dt)
+    # knot spacings outside the divisor window: one tiny, one huge interval per axis
+    x[20:] += dt(1e-30) - (x[20] - x[19]); x[40:] += dt(1e30 if dt == np.float32 else 1e250)
+    y[10:] = y[10:] - (y[10] - y[9]) + dt(3e-25 if dt == np.float32 else 1e-200)
+    x = np.unique(x); y = np.unique(y)
+    nx, ny = x.size, y.size
+    g = rng.uniform(-1, 1, (nx, ny, C)).astype(dt)
+    scales = np.array([1.0, fin.tiny * 4, fin.tiny / 8, 1e-22, 1e22, fin.max / 64, 0.0, 1.0], dtype=dt)
+    g *= scales[rng.integers(0, scales.size, (nx, ny, 1))]          # per grid point: normal, tiny, denormal, huge, zero
+    g[5:12, 5:12, :] = dt(0.75)                                     # a flat region: every difference is an exact zero
+    g[30:33, 20:23, ::2] = -g[30:33, 20:23, ::2]
+    Q = 60_000
+    ix = rng.integers(0, nx - 1, Q); iy = rng.integers(0, ny - 1, Q)
+    tx = rng.uniform(0, 1, Q).astype(dt); ty = rng.uniform(0, 1, Q).astype(dt)
+    qx = (x[ix] + (x[ix + 1] - x[ix]) * tx).astype(dt); qy = (y[iy] + (y[iy + 1] - y[iy]) * ty).astype(dt)
+    qx = np.clip(qx, x[0], x[-1]); qy = np.clip(qy, y[0], y[-1])
+    qx[:2000] = x[ix[:2000]]; qy[2000:4000] = y[iy[2000:4000]]      # on knots: t = 0 exactly
+    with np.errstate(all="ignore"):
+        _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy)
+    interp = pkg.Interp2DBuilder.new(g).x(x).y(y).build()
+    got = {}
+    for name, path in (("gather", pkg.PATH_GATHER), ("tiles", pkg.PATH_BUCKETED)):
+        interp.strategy.path = path
+        got[name] = interp.interp_array(qx, qy)
+    assert pkg.profile_read(reset=False)["last_path"] == "bucketed"
+    for name, arr in got.items():
+        assert np.array_equal(arr.view(np.uint32 if dt == np.float32 else np.uint64),
+                              ref.view(np.uint32 if dt == np.float32 else np.uint64)) or \
+            np.array_equal(arr, ref, equal_nan=True), name
+    # bit for bit between the two device formulations, NaN payloads and zero signs included
+    bits = np.uint32 if dt == np.float32 else np.uint64
+    same = got["gather"].view(bits) == got["tiles"].view(bits)
+    both_nan = np.isnan(got["gather"]) & np.isnan(got["tiles"])
+    assert np.all(same | both_nan)
+    assert np.isfinite(ref).mean() > 0.5                            # the case is not degenerate

@@ -257,7 +257,9 @@ ndi_status ndi_interp2d_eval_ring(const ndi_interp2d* h, const void* qx, const v
  * knots / data / strategy; normally one per device, built with ndi_interp{1,2}d_create and desc.device = d), the
  * flattened query array is split into contiguous blocks -- shard i owns [lo_i, hi_i) = ndi_shard_bounds(nq, i,
  * n_shards), block sizes differ by at most one -- and every shard is evaluated by its own host thread on its
- * handle's device (shard 0 on the calling thread).  No device-to-device traffic, no collective.
+ * handle's device: shard 0 on the calling thread, shard i > 0 on the i-th persistent worker thread the library keeps
+ * for that calling thread (so a handle's per-thread scratch is reused from call to call, and concurrent sharded calls
+ * from different host threads do not share workers).  No device-to-device traffic, no collective.
  *
  * First-error semantics are the reference's serial loop (src/interp1d/mod.rs:326-343, src/interp2d/mod.rs:287-307)
  * over the WHOLE batch: every shard range-checks its block first, the shards agree on the minimum failing flat

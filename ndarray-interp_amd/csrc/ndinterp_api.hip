@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -123,7 +124,7 @@ struct Range {
 // per-kernel event profiling (ndi_profile_*)
 // ---------------------------------------------------------------------------------------------
 enum ProfCat : int { PC_EVAL = 0, PC_LOCATE = 1, PC_GROUP = 2 };
-struct ProfRec { hipEvent_t a, b; int cat; };
+struct ProfRec { hipEvent_t a, b; int cat; int dev; };
 static std::atomic<int> g_prof_on{0};
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_recs;
@@ -131,16 +132,37 @@ static ndi_profile g_prof_acc{};
 static std::atomic<int> g_last_path{0};
 
 static const char* const PROF_NAMES[3] = {"ndi:evaluate", "ndi:locate", "ndi:group"};
+// Timing events are recycled (creating two events per launch costs the host ~0.1 ms per ring step, and the host
+// path of chunk 0 is exposed): finished records hand their events back to this pool (g_prof_mu held).  Events
+// belong to a device: the pool is keyed by it.
+static std::map<int, std::vector<hipEvent_t>> g_prof_pool;
+static hipEvent_t prof_event_locked(int dev) {
+  auto& pool = g_prof_pool[dev];
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  NDI_HIP(hipEventCreate(&e));
+  return e;
+}
 struct ProfScope {
   hipStream_t s;
   ProfRec r{};
+  int dev = 0;
   bool on;
   Range range;   // host-side enqueue range of the stage (the kernels inside carry their own names)
   ProfScope(hipStream_t stream, int cat) : s(stream), on(g_prof_on.load() != 0), range(PROF_NAMES[cat]) {
     if (!on) return;
     r.cat = cat;
-    NDI_HIP(hipEventCreate(&r.a));
-    NDI_HIP(hipEventCreate(&r.b));
+    NDI_HIP(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> g(g_prof_mu);
+      r.a = prof_event_locked(dev);
+      r.b = prof_event_locked(dev);
+    }
+    r.dev = dev;
     NDI_HIP(hipEventRecord(r.a, s));
   }
   void done() {
@@ -150,7 +172,12 @@ struct ProfScope {
     g_prof_recs.push_back(r);
     if (g_prof_recs.size() >= 4096) fold_finished_locked();   // profiling left on and never read: stay bounded
   }
-  // Adds the records whose kernels have finished to the running totals and frees their events (g_prof_mu held).
+  static void account_locked(const ProfRec& r, float ms) {
+    if (r.cat == PC_EVAL) { g_prof_acc.eval_launches++; g_prof_acc.eval_ms += ms; }
+    else if (r.cat == PC_LOCATE) { g_prof_acc.locate_launches++; g_prof_acc.locate_ms += ms; }
+    else { g_prof_acc.group_launches++; g_prof_acc.group_ms += ms; }
+  }
+  // Adds the records whose kernels have finished to the running totals and recycles their events (g_prof_mu held).
   static void fold_finished_locked() {
     size_t keep = 0;
     for (size_t i = 0; i < g_prof_recs.size(); ++i) {
@@ -161,13 +188,9 @@ struct ProfScope {
         continue;
       }
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-        if (r.cat == PC_EVAL) { g_prof_acc.eval_launches++; g_prof_acc.eval_ms += ms; }
-        else if (r.cat == PC_LOCATE) { g_prof_acc.locate_launches++; g_prof_acc.locate_ms += ms; }
-        else { g_prof_acc.group_launches++; g_prof_acc.group_ms += ms; }
-      }
-      (void)hipEventDestroy(r.a);
-      (void)hipEventDestroy(r.b);
+      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) account_locked(r, ms);
+      g_prof_pool[r.dev].push_back(r.a);
+      g_prof_pool[r.dev].push_back(r.b);
     }
     g_prof_recs.resize(keep);
   }
@@ -2031,7 +2054,8 @@ static ndi_status create_locator(int device, const void* knots, uint64_t n, int 
 // ---------------------------------------------------------------------------------------------
 // The reference's multi-worker shape is one interpolator driven from many threads over contiguous blocks of the
 // query array (benches/bench_interp1d.rs:49-79).  Here shard i of n evaluates the block shard_range(nq, i, n) on
-// handles[i]'s device.  The reference's first-error result (interp1d/mod.rs:326-343) is reproduced across shards:
+// handles[i]'s device (shard 0 on the calling thread, the others on the caller's persistent workers).  The
+// reference's first-error result (interp1d/mod.rs:326-343) is reproduced across shards:
 // every shard range-checks its block first, the minimum global failing index F is agreed on at a host barrier, and
 // only the rows [0, F) are produced -- later rows are never written.  No device-to-device traffic.
 static void shard_range(uint64_t nq, uint32_t i, uint32_t n, uint64_t* lo, uint64_t* hi) {
@@ -2067,6 +2091,77 @@ struct ShardOutcome {
   ndi_status st = NDI_OK;
   std::string msg;
 };
+
+// The worker threads of sharded calls are persistent and belong to the CALLING thread (thread_local): shard i of
+// every sharded call a host thread makes runs on the same worker, so the per-(stream, thread) scratch of a handle is
+// found again on the next call instead of being allocated and later evicted (hipMalloc / hipFree per call), and two
+// host threads issuing sharded calls at the same time never wait for each other's workers (the shards of one call
+// meet at a barrier: they must all be running).  Workers are joined when their owner thread exits.
+class ShardWorkers {
+  struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, stop = false;
+  };
+  std::vector<std::unique_ptr<Worker>> w_;
+  static void loop(Worker* w) {
+    std::unique_lock<std::mutex> l(w->m);
+    for (;;) {
+      w->cv.wait(l, [w] { return w->has_job || w->stop; });
+      if (w->stop) return;
+      std::function<void()> job = std::move(w->job);
+      l.unlock();
+      job();          // the shard bodies catch everything
+      l.lock();
+      w->has_job = false;
+      w->cv.notify_all();
+    }
+  }
+
+ public:
+  ShardWorkers() = default;
+  ShardWorkers(const ShardWorkers&) = delete;
+  ShardWorkers& operator=(const ShardWorkers&) = delete;
+  ~ShardWorkers() {
+    for (auto& w : w_) {
+      {
+        std::lock_guard<std::mutex> g(w->m);
+        w->stop = true;
+      }
+      w->cv.notify_all();
+      if (w->th.joinable()) w->th.join();
+    }
+  }
+  void ensure(size_t n) {
+    while (w_.size() < n) {
+      w_.emplace_back(new Worker());
+      Worker* w = w_.back().get();
+      w->th = std::thread(loop, w);
+    }
+  }
+  void start(size_t i, std::function<void()> f) {
+    Worker* w = w_[i].get();
+    {
+      std::lock_guard<std::mutex> g(w->m);
+      w->job = std::move(f);
+      w->has_job = true;
+    }
+    w->cv.notify_all();
+  }
+  void wait(size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+      Worker* w = w_[i].get();
+      std::unique_lock<std::mutex> l(w->m);
+      w->cv.wait(l, [w] { return !w->has_job; });
+    }
+  }
+};
+static ShardWorkers& shard_workers() {
+  static thread_local ShardWorkers p;
+  return p;
+}
 
 // Shard: constructed on the worker thread (the scratch lease is keyed by the thread), pre() = upload + range
 // pre-pass (+ the ring's speculative first chunk), run(limit) = produce the shard's first `limit` rows.
@@ -2112,11 +2207,11 @@ static void run_shards(const Job& job, uint32_t n, std::vector<ShardOutcome>& ou
     }
     if (!arrived) bar.wait();
   };
-  std::vector<std::thread> th;
-  th.reserve(n);
-  for (uint32_t i = 1; i < n; ++i) th.emplace_back(work, i);
+  ShardWorkers& pool = shard_workers();
+  pool.ensure(n - 1);
+  for (uint32_t i = 1; i < n; ++i) pool.start(i - 1, [&work, i] { work(i); });
   work(0);   // shard 0 runs on the calling thread
-  for (auto& t : th) t.join();
+  pool.wait(n - 1);
   F[0] = fx.load();
   F[1] = fy.load();
 }
@@ -2695,11 +2790,9 @@ NDI_API ndi_status ndi_profile_read(ndi_profile* out, int32_t reset) {
     NDI_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
     NDI_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-    if (r.cat == ndi::PC_EVAL) { ndi::g_prof_acc.eval_launches++; ndi::g_prof_acc.eval_ms += ms; }
-    else if (r.cat == ndi::PC_LOCATE) { ndi::g_prof_acc.locate_launches++; ndi::g_prof_acc.locate_ms += ms; }
-    else { ndi::g_prof_acc.group_launches++; ndi::g_prof_acc.group_ms += ms; }
-    (void)hipEventDestroy(r.a);
-    (void)hipEventDestroy(r.b);
+    ndi::ProfScope::account_locked(r, ms);
+    ndi::g_prof_pool[r.dev].push_back(r.a);
+    ndi::g_prof_pool[r.dev].push_back(r.b);
   }
   ndi::g_prof_recs.clear();
   ndi::g_prof_acc.last_path = ndi::g_last_path.load();

@@ -190,6 +190,22 @@ def test_sharded_calls_from_concurrent_host_threads(pkg):
     assert not bad
 
 
+def test_sharded_calls_reuse_their_scratch(pkg):
+    """Shard i of every sharded call a host thread makes runs on the same persistent worker thread, so each handle
+    keeps ONE scratch set however many calls are made (no allocation / eviction per call)."""
+    rng = np.random.default_rng(77)
+    x = knots("rand", 100, rng, np.float64); y = rng.uniform(0, 1, (100, 512))
+    st, a, b = oracle.cubic_build(x, y)
+    reps = _replicas(pkg, x, y, _devices(pkg, 3))
+    lib = pkg._capi.lib()
+    for k in range(12):
+        q = rng.uniform(x[0], x[-1], 9000 + k)
+        out = np.empty((q.size, 512))
+        pkg.sharding.interp_array_sharded(reps, q, out=out)
+        assert np.array_equal(out, oracle.interp1d_cubic(x, y, a, b, q)[2])
+        assert [lib.ndi_interp1d_scratch_sets(r.strategy._h) for r in reps] == [1, 1, 1]
+
+
 def test_sharded_ring(pkg):
     """Every shard streams its block through its own ring; the consumer sees global query indices and the shard; the
     first-error cut is global."""

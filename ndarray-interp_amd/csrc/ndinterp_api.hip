@@ -1070,6 +1070,60 @@ struct Interp1DImpl final : Interp1DBase {
     return NDI_OK;
   }
 
+  // Host arrays in and out, short trailing axes, small batch (the reference's own bench shapes: 1e4 queries on scalar
+  // data): ZERO-COPY.  The queries are copied into the workspace's pinned buffer with a plain memcpy, the fused
+  // search + evaluation kernel reads them and writes the rows straight through the host mapping of that buffer (a
+  // hipHostMalloc allocation is device-accessible), and one synchronisation later the rows are memcpy'd to the
+  // caller -- no H2D / D2H copy commands at all, only the 32-byte status read-back.  Saves two DMA round trips per
+  // call (C1: 48.7 -> see DESIGN.md 4.2).  Rows at / after the first failing query are not copied out.
+  static constexpr size_t ZERO_COPY_LIMIT = 1u << 20;   // queries + rows
+  bool zero_copy_fits(uint64_t nq, int q_space, int out_space) const {
+    return q_space == NDI_MEM_HOST && out_space == NDI_MEM_HOST && lanes <= (uint64_t)SMALL_LANES &&
+           pyr.lds_bytes <= LDS_STAGE_LIMIT && nq * (lanes + 1) * sizeof(T) <= ZERO_COPY_LIMIT;
+  }
+  ndi_status eval_small_zero_copy(hipStream_t s, Workspace& ws, const T* q_host, uint64_t nq, T* out,
+                                  uint64_t out_stride, ndi_oob_info* info) {
+    const size_t q_bytes = ((nq * sizeof(T)) + 255) & ~(size_t)255, row_bytes = lanes * sizeof(T);
+    ws.ensure_pin(std::max<size_t>(q_bytes + nq * row_bytes, 8ull << 20));
+    ws.ensure_status();
+    T* pq = reinterpret_cast<T*>(ws.pin);
+    T* po = reinterpret_cast<T*>((char*)ws.pin + q_bytes);
+    std::memcpy(pq, q_host, nq * sizeof(T));
+    g_last_path.store(NDI_PATH_GATHER);
+    allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_CUBIC>), (int)LDS_STAGE_LIMIT);
+    allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small_kernel<T, ST_LINEAR>), (int)LDS_STAGE_LIMIT);
+    StatusBlock* st = ws.sc[0].status.as<StatusBlock>();
+    NDI_HIP(hipMemsetAsync(st, 0xFF, 2 * sizeof(unsigned long long), s));
+    EvalSmallArgs<T> A{};
+    A.pyr = pyr.view;
+    A.data = data.as<T>();
+    A.ca = ca.as<T>();
+    A.cb = cb.as<T>();
+    A.q = pq;
+    A.out = po;
+    A.nq = nq;
+    A.out_stride = lanes;
+    A.lanes = (uint32_t)lanes;
+    A.mode = mode;
+    A.first_fail = &st->first_fail[0];
+    A.prechecked = 0;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+    const size_t shmem = (pyr.lds_bytes + 15) & ~(size_t)15;
+    if (strategy == NDI_CUBIC_SPLINE) launch1<T>(s, PC_EVAL, dim3(grid), dim3(BLOCK), shmem, eval_small_kernel<T, ST_CUBIC>, A);
+    else launch1<T>(s, PC_EVAL, dim3(grid), dim3(BLOCK), shmem, eval_small_kernel<T, ST_LINEAR>, A);
+    NDI_HIP(hipMemcpyAsync(ws.host_status, st, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    NDI_HIP(hipStreamSynchronize(s));
+    const unsigned long long ff = ws.host_status->first_fail[0];
+    const uint64_t good = (ff == NO_FAIL) ? nq : (uint64_t)ff;
+    if (good) {
+      if (out_stride == lanes) std::memcpy(out, po, good * row_bytes);
+      else
+        for (uint64_t r = 0; r < good; ++r) std::memcpy(out + r * out_stride, (const char*)po + r * row_bytes, row_bytes);
+    }
+    if (ff != NO_FAIL) return report(q_host, NDI_MEM_HOST, ff, 0, info);
+    return NDI_OK;
+  }
+
   // interp_array_into on staged (device) queries; q_orig / q_space name the caller's array for error reports.
   ndi_status eval_body(hipStream_t s, Workspace& ws, const T* q, const void* q_orig, int q_space, uint64_t nq,
                        void* out_, uint64_t out_stride, const ndi_eval_opts& o, ndi_oob_info* info) {
@@ -1117,6 +1171,8 @@ struct Interp1DImpl final : Interp1DBase {
     if (!q_ || !out_) return fail(NDI_BAD_ARG, "null query / output pointer");
     SpaceLease lease(spaces, s);
     Workspace& ws = lease.ws;
+    if (zero_copy_fits(nq, o.q_memspace, o.out_memspace))
+      return eval_small_zero_copy(s, ws, (const T*)q_, nq, (T*)out_, out_stride, info);
     const T* q = stage_queries(s, ws, q_, nq, o.q_memspace);
     return eval_body(s, ws, q, q_, o.q_memspace, nq, out_, out_stride, o, info);
   }
@@ -1721,6 +1777,57 @@ struct Interp2DImpl final : Interp2DBase {
     return NDI_OK;
   }
 
+  // Zero-copy small batches, host arrays in and out (see Interp1DImpl::eval_small_zero_copy).
+  static constexpr size_t ZERO_COPY_LIMIT = 1u << 20;
+  bool zero_copy_fits(uint64_t nq, int q_space, int out_space) const {
+    return q_space == NDI_MEM_HOST && out_space == NDI_MEM_HOST && lanes <= (uint64_t)SMALL_LANES &&
+           ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15) <= LDS_STAGE_LIMIT &&
+           nq * (lanes + 2) * sizeof(T) <= ZERO_COPY_LIMIT;
+  }
+  ndi_status eval_small_zero_copy(hipStream_t s, Workspace& ws, const T* qx_host, const T* qy_host, uint64_t nq,
+                                  T* out, uint64_t out_stride, ndi_oob_info* info) {
+    const size_t q_bytes = ((nq * sizeof(T)) + 255) & ~(size_t)255, row_bytes = lanes * sizeof(T);
+    ws.ensure_pin(std::max<size_t>(2 * q_bytes + nq * row_bytes, 8ull << 20));
+    ws.ensure_status();
+    T* pqx = reinterpret_cast<T*>(ws.pin);
+    T* pqy = reinterpret_cast<T*>((char*)ws.pin + q_bytes);
+    T* po = reinterpret_cast<T*>((char*)ws.pin + 2 * q_bytes);
+    std::memcpy(pqx, qx_host, nq * sizeof(T));
+    std::memcpy(pqy, qy_host, nq * sizeof(T));
+    g_last_path.store(NDI_PATH_GATHER);
+    allow_dynamic_lds(reinterpret_cast<const void*>(&eval_small2d_kernel<T>), (int)LDS_STAGE_LIMIT);
+    StatusBlock* st = ws.sc[0].status.as<StatusBlock>();
+    NDI_HIP(hipMemsetAsync(st, 0xFF, 2 * sizeof(unsigned long long), s));
+    EvalSmall2Args<T> A{};
+    A.px = px.view; A.py = py.view;
+    A.data = data.as<T>();
+    A.qx = pqx; A.qy = pqy;
+    A.out = po;
+    A.nq = nq;
+    A.out_stride = lanes;
+    A.row_cells = pair_packed ? ny - 1 : ny;
+    A.cell_elems = pair_packed ? 2 * lanes : lanes;
+    A.lanes = (uint32_t)lanes;
+    A.mode = mode;
+    A.first_fail = &st->first_fail[0];
+    A.prechecked = 0;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+    const size_t shmem = (px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15;
+    launch1<T>(s, PC_EVAL, dim3(grid), dim3(BLOCK), shmem, eval_small2d_kernel<T>, A);
+    NDI_HIP(hipMemcpyAsync(ws.host_status, st, sizeof(StatusBlock), hipMemcpyDeviceToHost, s));
+    NDI_HIP(hipStreamSynchronize(s));
+    const unsigned long long fx = ws.host_status->first_fail[0], fy = ws.host_status->first_fail[1];
+    const unsigned long long ff = std::min(fx, fy);
+    const uint64_t good = (ff == NO_FAIL) ? nq : (uint64_t)ff;
+    if (good) {
+      if (out_stride == lanes) std::memcpy(out, po, good * row_bytes);
+      else
+        for (uint64_t r = 0; r < good; ++r) std::memcpy(out + r * out_stride, (const char*)po + r * row_bytes, row_bytes);
+    }
+    if (ff != NO_FAIL) return report(qx_host, qy_host, NDI_MEM_HOST, fx, fy, 0, info);
+    return NDI_OK;
+  }
+
   ndi_status eval_body(hipStream_t s, Workspace& ws, const T* qx, const T* qy, const void* qx_orig,
                        const void* qy_orig, int q_space, uint64_t nq, void* out_, uint64_t out_stride,
                        const ndi_eval_opts& o, ndi_oob_info* info) {
@@ -1771,6 +1878,8 @@ struct Interp2DImpl final : Interp2DBase {
     if (!qx_ || !qy_ || !out_) return fail(NDI_BAD_ARG, "null query / output pointer");
     SpaceLease lease(spaces, s);
     Workspace& ws = lease.ws;
+    if (zero_copy_fits(nq, o.q_memspace, o.out_memspace))
+      return eval_small_zero_copy(s, ws, (const T*)qx_, (const T*)qy_, nq, (T*)out_, out_stride, info);
     const T *qx, *qy;
     stage_queries(s, ws, qx_, qy_, nq, o.q_memspace, &qx, &qy);
     return eval_body(s, ws, qx, qy, qx_, qy_, o.q_memspace, nq, out_, out_stride, o, info);

@@ -2111,6 +2111,7 @@ struct LocatorBase {
   virtual ~LocatorBase() = default;
   int dtype = 0, device = 0;
   virtual ndi_status eval(const void* q, uint64_t nq, int64_t* out_idx, int memspace, void* stream) = 0;
+  bool one_shot = false;   // built for a single search (ndi_get_lower_index_batch): no pinned buffer is set up
 };
 
 template <class T>
@@ -2125,6 +2126,20 @@ struct LocatorImpl final : LocatorBase {
     hipStream_t s = (hipStream_t)stream;
     const T* qdev = (const T*)q;
     int64_t* odev = out_idx;
+    if (memspace == NDI_MEM_HOST && !one_shot && nq * (sizeof(T) + sizeof(int64_t)) <= ((size_t)1 << 20)) {
+      // small host batch: zero-copy through the pinned buffer's host mapping (see eval_small_zero_copy)
+      SpaceLease lease(spaces, s);
+      Workspace& ws = lease.ws;
+      const size_t q_bytes = ((nq * sizeof(T)) + 255) & ~(size_t)255;
+      ws.ensure_pin(std::max<size_t>(q_bytes + nq * sizeof(int64_t), 8ull << 20));
+      T* pq = reinterpret_cast<T*>(ws.pin);
+      int64_t* po = reinterpret_cast<int64_t*>((char*)ws.pin + q_bytes);
+      std::memcpy(pq, q, nq * sizeof(T));
+      run_locate<T>(s, pyr, pq, nq, nullptr, po, nullptr, nullptr, EX_YES);
+      NDI_HIP(hipStreamSynchronize(s));
+      std::memcpy(out_idx, po, nq * sizeof(int64_t));
+      return NDI_OK;
+    }
     if (memspace == NDI_MEM_HOST) {
       SpaceLease lease(spaces, s);
       Workspace& ws = lease.ws;
@@ -2854,6 +2869,7 @@ NDI_API ndi_status ndi_get_lower_index_batch(int32_t dtype, int32_t device, cons
   ndi_locator* loc = nullptr;
   ndi_status st = ndi_locator_create(dtype, device, knots, n, memspace, &loc);
   if (st != NDI_OK) return st;
+  loc->impl->one_shot = true;   // pinning a buffer costs more than the two small copies it would save
   st = ndi_locator_eval(loc, q, nq, out_idx, memspace, nullptr);
   ndi_locator_destroy(loc);
   return st;

@@ -166,6 +166,14 @@ void ndi_interp1d_destroy(ndi_interp1d* h);
 ndi_status ndi_interp2d_create(const ndi_interp2d_desc* desc, ndi_interp2d** out);
 void ndi_interp2d_destroy(ndi_interp2d* h);
 
+/* A replica of a built interpolator on `device` (any device, the handle's own included): the device-resident knots /
+ * data / spline tables are copied device to device (between two GPUs: over xGMI) -- the caller's arrays are not
+ * uploaded again and CubicSpline::build's Thomas solve (cubic_spline.rs:754-771) is not repeated.  What the sharded
+ * calls below take as `handles`: knots / coefficients replicated per device.  The replica is independent of the
+ * original (destroy each with ndi_interp{1,2}d_destroy). */
+ndi_status ndi_interp1d_clone(const ndi_interp1d* h, int32_t device, ndi_interp1d** out);
+ndi_status ndi_interp2d_clone(const ndi_interp2d* h, int32_t device, ndi_interp2d** out);
+
 /* CubicSplineStrategy{a, b} (cubic_spline.rs:94-102): copies the coefficient tables,
  * each T[(n-1) * lanes], to `a_out` / `b_out` (either may be NULL). */
 ndi_status ndi_interp1d_coefficients(const ndi_interp1d* h, void* a_out, void* b_out,

@@ -87,6 +87,8 @@ SYMBOLS = {
     "ndi_interp1d_destroy": (None, [_P]),
     "ndi_interp2d_create": (C.c_int, [C.POINTER(Interp2DDesc), C.POINTER(_P)]),
     "ndi_interp2d_destroy": (None, [_P]),
+    "ndi_interp1d_clone": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
+    "ndi_interp2d_clone": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
     "ndi_interp1d_coefficients": (C.c_int, [_P, _P, _P, C.c_int32]),
     "ndi_interp1d_eval": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(EvalOpts), C.POINTER(OobInfo)]),
     "ndi_interp2d_eval": (C.c_int, [_P, _P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(EvalOpts), C.POINTER(OobInfo)]),

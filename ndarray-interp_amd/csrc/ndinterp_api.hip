@@ -577,6 +577,7 @@ struct Interp1DBase {
                                void* user, const ndi_eval_opts* opts, ndi_oob_info* info) = 0;
   virtual ndi_status trim() = 0;
   virtual uint64_t scratch_sets() = 0;
+  virtual ndi_status clone_to(int dev, Interp1DBase** out) = 0;
 };
 
 template <class T>
@@ -1303,6 +1304,31 @@ struct Interp1DImpl final : Interp1DBase {
 
   uint64_t scratch_sets() override { return spaces.size(); }
 
+  // A replica on another (or the same) device: the knot pyramid is rebuilt from the host copy, data and the spline
+  // tables are copied device to device (over xGMI between two GPUs) -- no second upload of the caller's arrays, no
+  // second Thomas solve.
+  ndi_status clone_to(int dev, Interp1DBase** out) override {
+    std::unique_ptr<Interp1DImpl<T>> h(new Interp1DImpl<T>());
+    h->dtype = dtype; h->device = dev; h->lanes = lanes;
+    h->strategy = strategy; h->mode = mode; h->n = n;
+    {
+      DeviceGuard dg(device);
+      NDI_HIP(hipDeviceSynchronize());     // the source tables are complete
+    }
+    DeviceGuard dg(dev);
+    h->pyr.upload(pyr.host_knots.data(), n);
+    auto copy = [&](DevBuf& dst, const DevBuf& src) {
+      if (!src.p) return;
+      dst.reserve(src.bytes);
+      NDI_HIP(hipMemcpyPeer(dst.p, dev, src.p, device, src.bytes));
+    };
+    copy(h->data, data);
+    copy(h->ca, ca);
+    copy(h->cb, cb);
+    *out = h.release();
+    return NDI_OK;
+  }
+
   ndi_status coefficients(void* a_out, void* b_out, int memspace) override {
     DeviceGuard dg(device);
     if (strategy != NDI_CUBIC_SPLINE) return fail(NDI_BAD_ARG, "Linear has no coefficient tables");
@@ -1383,6 +1409,7 @@ struct Interp2DBase {
                                ndi_oob_info* info) = 0;
   virtual ndi_status trim() = 0;
   virtual ndi_status probe_ceiling(uint64_t nq, void* out, uint64_t out_stride, void* stream, int reps, double* ms) = 0;
+  virtual ndi_status clone_to(int dev, Interp2DBase** out) = 0;
 };
 
 template <class T>
@@ -1996,6 +2023,25 @@ struct Interp2DImpl final : Interp2DBase {
     return report(qx_, qy_, o.q_memspace, fx, fy, 0, info);
   }
 
+  // A replica on another (or the same) device (see Interp1DImpl::clone_to): the grid is copied device to device in
+  // the layout it is kept in (plain or pair-packed).
+  ndi_status clone_to(int dev, Interp2DBase** out) override {
+    std::unique_ptr<Interp2DImpl<T>> h(new Interp2DImpl<T>());
+    h->dtype = dtype; h->device = dev; h->lanes = lanes;
+    h->mode = mode; h->nx = nx; h->ny = ny; h->pair_packed = pair_packed;
+    {
+      DeviceGuard dg(device);
+      NDI_HIP(hipDeviceSynchronize());
+    }
+    DeviceGuard dg(dev);
+    h->px.upload(px.host_knots.data(), nx);
+    h->py.upload(py.host_knots.data(), ny);
+    h->data.reserve(data.bytes);
+    NDI_HIP(hipMemcpyPeer(h->data.p, dev, data.p, device, data.bytes));
+    *out = h.release();
+    return NDI_OK;
+  }
+
   // Median time of `reps` launches of probe_gather_kernel over nq queries (see kernels.hpp).
   ndi_status probe_ceiling(uint64_t nq, void* out, uint64_t out_stride, void* stream, int reps, double* ms) override {
     DeviceGuard dg(device);
@@ -2603,6 +2649,36 @@ NDI_API void ndi_interp2d_destroy(ndi_interp2d* h) {
   } catch (...) {
   }
   delete h;
+}
+
+NDI_API ndi_status ndi_interp1d_clone(const ndi_interp1d* h, int32_t device, ndi_interp1d** out) {
+  if (!h || !out) return ndi::fail(NDI_BAD_ARG, "null argument");
+  *out = nullptr;
+  ndi_status ds = need_device(device);
+  if (ds != NDI_OK) return ds;
+  NDI_TRY
+  ndi::Range rg("ndi_interp1d_clone");
+  ndi::Interp1DBase* impl = nullptr;
+  ndi_status st = h->impl->clone_to(device, &impl);
+  if (st != NDI_OK) return st;
+  *out = new ndi_interp1d{impl};
+  return NDI_OK;
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_interp2d_clone(const ndi_interp2d* h, int32_t device, ndi_interp2d** out) {
+  if (!h || !out) return ndi::fail(NDI_BAD_ARG, "null argument");
+  *out = nullptr;
+  ndi_status ds = need_device(device);
+  if (ds != NDI_OK) return ds;
+  NDI_TRY
+  ndi::Range rg("ndi_interp2d_clone");
+  ndi::Interp2DBase* impl = nullptr;
+  ndi_status st = h->impl->clone_to(device, &impl);
+  if (st != NDI_OK) return st;
+  *out = new ndi_interp2d{impl};
+  return NDI_OK;
+  NDI_CATCH
 }
 
 NDI_API ndi_status ndi_interp1d_coefficients(const ndi_interp1d* h, void* a_out, void* b_out, int32_t memspace) {

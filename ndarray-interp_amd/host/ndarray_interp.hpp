@@ -358,6 +358,14 @@ struct Device1D : Interp1DStrategy<T> {  // owns an ndi_interp1d*
     int st = ndi_interp1d_create(&d, &h);
     if (st != NDI_OK) throw_builder(st);
   }
+  // a replica on `dev` (ndi_interp1d_clone): tables copied device to device, nothing uploaded or solved again
+  std::shared_ptr<Device1D<T>> clone(int dev) const {
+    auto s = std::make_shared<Device1D<T>>();
+    s->lanes = lanes; s->path = path; s->device = dev;
+    int st = ndi_interp1d_clone(h, dev, &s->h);
+    if (st != NDI_OK) throw_builder(st);
+    return s;
+  }
   void interp_array_into(const Interp1D<T>&, const T* xs, size_t nq, T* out, size_t row_stride) const override {
     ndi_eval_opts o{};
     o.q_memspace = NDI_MEM_HOST; o.out_memspace = NDI_MEM_HOST; o.path = path;
@@ -449,6 +457,14 @@ class Interp1D {  // interp1d/mod.rs:39-51
   }
   size_t lanes() const { return detail::prod(data.shape, 1); }
   std::vector<size_t> lanes_shape() const { return {data.shape.begin() + 1, data.shape.end()}; }
+
+  // A replica of this interpolator whose tables live on `device` (copied device to device): what
+  // interp_array_sharded takes, one per device.
+  Interp1D replicate(int device) const {
+    auto dev = std::dynamic_pointer_cast<detail::Device1D<T>>(strategy);
+    if (!dev) throw Panic("replicate needs a built-in device strategy (f32 / f64 data)");
+    return new_unchecked(x, data, dev->clone(device));
+  }
 
   std::pair<T, const T*> index_point(size_t index) const { return {x.at(index), data.data.data() + index * lanes()}; }
   size_t get_index_left_of(T v) const {
@@ -598,6 +614,13 @@ struct Device2D : Interp2DStrategy<T> {
   size_t lanes = 1;
   int device = 0;
   ~Device2D() override { ndi_interp2d_destroy(h); }
+  std::shared_ptr<Device2D<T>> clone(int dev) const {   // ndi_interp2d_clone
+    auto s = std::make_shared<Device2D<T>>();
+    s->lanes = lanes; s->device = dev;
+    int st = ndi_interp2d_clone(h, dev, &s->h);
+    if (st != NDI_OK) throw_builder(st);
+    return s;
+  }
   void interp_array_into(const Interp2D<T>&, const T* xs, const T* ys, size_t nq, T* out,
                          size_t row_stride) const override {
     ndi_eval_opts o{};
@@ -656,6 +679,13 @@ class Interp2D {  // interp2d/mod.rs:36-48
   std::shared_ptr<Interp2DStrategy<T>> strategy;
   size_t lanes() const { return detail::prod(data.shape, 2); }
   std::vector<size_t> lanes_shape() const { return {data.shape.begin() + 2, data.shape.end()}; }
+  Interp2D replicate(int device) const {   // see Interp1D::replicate
+    auto dev = std::dynamic_pointer_cast<detail::Device2D<T>>(strategy);
+    if (!dev) throw Panic("replicate needs a built-in device strategy (f32 / f64 data)");
+    Interp2D r;
+    r.x = x; r.y = y; r.data = data; r.strategy = dev->clone(device);
+    return r;
+  }
   bool is_in_x_range(T v) const { return x.front() <= v && v <= x.back(); }
   bool is_in_y_range(T v) const { return y.front() <= v && v <= y.back(); }
   T interp_scalar(T xv, T yv) const {

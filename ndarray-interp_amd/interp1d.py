@@ -113,6 +113,17 @@ class _DeviceStrategy1D(Interp1DStrategy):
         except Exception:
             pass
 
+    def clone(self, device: int):
+        """A replica of this finished strategy on `device` (ndi_interp1d_clone): tables copied device to device."""
+        import copy
+        h = C.c_void_p()
+        st = _capi.lib().ndi_interp1d_clone(self._h, int(device), C.byref(h))
+        if st != _capi.OK:
+            raise_builder(st)
+        other = copy.copy(self)
+        other._h, other._device, other._inflight = h, int(device), []
+        return other
+
     # -- evaluate -----------------------------------------------------------------------------
     def interp_array_into(self, interpolator, xs_flat, out2d, *, async_launch=False):
         """Replaces the reference's query loop (interp1d/mod.rs:326-343) by one C-ABI call."""
@@ -560,6 +571,13 @@ class Interp1D:
             elif done:
                 where = np.unravel_index(np.arange(done), tuple(xs.shape))     # works for any strides
                 buffer[where] = tmp[:done].reshape((done,) + self._lanes_shape())
+
+    def replicate(self, devices):
+        """Replicas of this interpolator on the given devices (tables copied device to device, nothing rebuilt):
+        what `sharding.interp_array_sharded` takes.  `interp.replicate(range(pkg.device_count()))`."""
+        if not hasattr(self.strategy, "clone"):
+            raise TypeError("replicate needs a built-in device strategy (f32 / f64 data)")
+        return [Interp1D(self.x, self.data, self.strategy.clone(d)) for d in devices]
 
     def interp_array_ring(self, xs, chunk_queries, consumer=None, *, slots=None, n_slots=2):
         """`interp_array` (interp1d/mod.rs:197-211) for outputs larger than device memory: the flattened

@@ -119,6 +119,17 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
         except Exception:
             pass
 
+    def clone(self, device: int):
+        """A replica of this built strategy on `device` (ndi_interp2d_clone): the grid is copied device to device."""
+        import copy
+        h = C.c_void_p()
+        st = _capi.lib().ndi_interp2d_clone(self._h, int(device), C.byref(h))
+        if st != _capi.OK:
+            raise_builder(st)
+        other = copy.copy(self)
+        other._h, other._device, other._inflight = h, int(device), []
+        return other
+
     def interp_array_into(self, interpolator, xs_flat, ys_flat, out2d, *, async_launch=False):
         """Replaces the reference's query loop (interp2d/mod.rs:287-307) by one C-ABI call."""
         qx = Buf(xs_flat, self._np_dtype)
@@ -352,6 +363,12 @@ class Interp2D:
             elif done:
                 where = np.unravel_index(np.arange(done), tuple(xs.shape))
                 buffer[where] = tmp[:done].reshape((done,) + self._lanes_shape())
+
+    def replicate(self, devices):
+        """Replicas of this interpolator on the given devices (see Interp1D.replicate)."""
+        if not hasattr(self.strategy, "clone"):
+            raise TypeError("replicate needs a built-in device strategy (f32 / f64 data)")
+        return [Interp2D(self.x, self.y, self.data, self.strategy.clone(d)) for d in devices]
 
     def interp_array_ring(self, xs, ys, chunk_queries, consumer=None, *, slots=None, n_slots=2):
         """`interp_array` (interp2d/mod.rs:175-196) through a device-output ring (ndi_interp2d_eval_ring)."""

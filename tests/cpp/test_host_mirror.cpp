@@ -310,6 +310,14 @@ static void device() {
       return nullptr;
     });
     CHECK(rows == Q && got == whole2.data);
+    // replicas by device-to-device copy of the tables (ndi_interp1d_clone) behave like rebuilt ones
+    {
+      std::vector<Interp1D<double>> cl;
+      for (int r = 0; r < 2; ++r) cl.push_back(reps[0].replicate(ndev >= 2 ? r : 0));
+      std::vector<const Interp1D<double>*> cp{&cl[0], &cl[1]};
+      CHECK(interp_array_sharded(cp, Array<double>::from_vec(qs)).data == whole2.data);
+      CHECK(std::dynamic_pointer_cast<detail::Device1D<double>>(cl[1].strategy)->device == (ndev >= 2 ? 1 : 0));
+    }
     // a worker thread that owns a device: set_current_device once, then unchanged builder code
     set_current_device(ndev - 1);
     auto lin = Interp1DBuilder<double>::new_(arr({1, 2, 3})).build();
@@ -327,6 +335,7 @@ static void device() {
     for (size_t i = 0; i < 7; ++i) { qx[i] = 4.0 * i / 6.0; qy[i] = 3.0 * ((i * 5) % 7) / 6.0; }
     auto w2 = r2[0].interp_array(qx, qy);
     CHECK(interp_array_sharded(rp2, qx, qy).data == w2.data);
+    CHECK(r2[1].replicate(0).interp_array(qx, qy).data == w2.data);
     qy[5] = 3.5;
     try { interp_array_sharded(rp2, qx, qy); CHECK(false); } catch (const InterpolateError& e) { CHECK(e.index == 5 && e.axis == 1); }
   }

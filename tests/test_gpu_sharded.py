@@ -190,6 +190,43 @@ def test_sharded_calls_from_concurrent_host_threads(pkg):
     assert not bad
 
 
+def test_replicas_by_device_to_device_copy(pkg):
+    """ndi_interp{1,2}d_clone: a replica made by copying the device-resident tables equals one built from the host
+    arrays -- same coefficient tables, same results -- and is independent of its source."""
+    rng = np.random.default_rng(78)
+    x = knots("rand", 300, rng, np.float64); y = rng.uniform(0, 1, (300, 256))
+    st, a, b = oracle.cubic_build(x, y)
+    src = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().extrapolate(True)).build()
+    devs = _devices(pkg, 3)
+    reps = src.replicate(devs)
+    assert [r.strategy._device for r in reps] == devs
+    for r in reps:
+        ca, cb = r.strategy.coefficients()
+        assert np.array_equal(ca, a) and np.array_equal(cb, b)
+    q = rng.uniform(x[0] - 0.1, x[-1] + 0.1, 12_345)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q, extrapolate=oracle.EXTRAPOLATE_YES)
+    src.strategy.release()                                  # the replicas own their tables
+    out = np.empty_like(ref)
+    pkg.sharding.interp_array_sharded(reps, q, out=out)
+    assert np.array_equal(out, ref)
+    lin = pkg.Interp1DBuilder.new(y[:, :3]).x(x).build()    # Linear, short rows
+    assert np.array_equal(lin.replicate([0])[0].interp_array(q[(q >= x[0]) & (q <= x[-1])]),
+                          lin.interp_array(q[(q >= x[0]) & (q <= x[-1])]))
+    # 2-D, plain and pair-packed grid layouts
+    for Cn in (32, 4):
+        g = rng.random((40, 30, Cn), dtype=np.float32)
+        bi = pkg.Interp2DBuilder.new(g).build()
+        qx = rng.uniform(0, 39, 5000).astype(np.float32); qy = rng.uniform(0, 29, 5000).astype(np.float32)
+        _, _, _, ref2 = oracle.interp2d_bilinear(np.arange(40, dtype=np.float32), np.arange(30, dtype=np.float32), g, qx, qy)
+        r2 = bi.replicate(_devices(pkg, 2))
+        outs = pkg.sharding.interp_array_sharded(r2, qx, qy)
+        assert np.array_equal(np.concatenate([o.cpu().numpy() for o in outs]), ref2)
+    lib, cap = pkg._capi.lib(), pkg._capi
+    h = C.c_void_p()
+    assert lib.ndi_interp1d_clone(None, 0, C.byref(h)) == cap.BAD_ARG
+    assert lib.ndi_interp1d_clone(reps[0].strategy._h, 99, C.byref(h)) == cap.BAD_ARG and "out of range" in cap.last_error()
+
+
 def test_sharded_calls_reuse_their_scratch(pkg):
     """Shard i of every sharded call a host thread makes runs on the same persistent worker thread, so each handle
     keeps ONE scratch set however many calls are made (no allocation / eviction per call)."""

@@ -316,6 +316,7 @@ struct Workspace {
   DevBuf status, qdev, qdev2, stage;   // status: the range pre-pass of the ring / sharded evaluations
   StatusBlock* host_status = nullptr;  // pinned
   void* pin = nullptr;                 // pinned bounce buffer of the small-batch host path
+  void* pin_dev = nullptr;             // its device-side address (hipHostGetDevicePointer)
   size_t pin_bytes = 0;
   hipStream_t side = nullptr;          // ring evaluation: locate + group of the next chunk run here
   hipEvent_t ev = nullptr;             // general-purpose ordering event (timing disabled)
@@ -338,9 +339,15 @@ struct Workspace {
     if (need <= pin_bytes) return;
     if (pin) (void)hipHostFree(pin);
     pin = nullptr;
+    pin_dev = nullptr;
     pin_bytes = 0;
-    NDI_HIP(hipHostMalloc(&pin, need, hipHostMallocDefault));
+    NDI_HIP(hipHostMalloc(&pin, need, hipHostMallocMapped | hipHostMallocPortable));
+    NDI_HIP(hipHostGetDevicePointer(&pin_dev, pin, 0));   // the address kernels use for the zero-copy path
     pin_bytes = need;
+  }
+  template <class U>
+  U* pin_device(const void* host_ptr) const {   // device view of an address inside the pinned buffer
+    return reinterpret_cast<U*>((char*)pin_dev + ((const char*)host_ptr - (const char*)pin));
   }
   void ensure_status() {
     status.reserve(sizeof(StatusBlock));
@@ -1100,8 +1107,8 @@ struct Interp1DImpl final : Interp1DBase {
     A.data = data.as<T>();
     A.ca = ca.as<T>();
     A.cb = cb.as<T>();
-    A.q = pq;
-    A.out = po;
+    A.q = ws.pin_device<const T>(pq);
+    A.out = ws.pin_device<T>(po);
     A.nq = nq;
     A.out_stride = lanes;
     A.lanes = (uint32_t)lanes;
@@ -1828,8 +1835,8 @@ struct Interp2DImpl final : Interp2DBase {
     EvalSmall2Args<T> A{};
     A.px = px.view; A.py = py.view;
     A.data = data.as<T>();
-    A.qx = pqx; A.qy = pqy;
-    A.out = po;
+    A.qx = ws.pin_device<const T>(pqx); A.qy = ws.pin_device<const T>(pqy);
+    A.out = ws.pin_device<T>(po);
     A.nq = nq;
     A.out_stride = lanes;
     A.row_cells = pair_packed ? ny - 1 : ny;
@@ -2181,7 +2188,7 @@ struct LocatorImpl final : LocatorBase {
       T* pq = reinterpret_cast<T*>(ws.pin);
       int64_t* po = reinterpret_cast<int64_t*>((char*)ws.pin + q_bytes);
       std::memcpy(pq, q, nq * sizeof(T));
-      run_locate<T>(s, pyr, pq, nq, nullptr, po, nullptr, nullptr, EX_YES);
+      run_locate<T>(s, pyr, ws.pin_device<const T>(pq), nq, nullptr, ws.pin_device<int64_t>(po), nullptr, nullptr, EX_YES);
       NDI_HIP(hipStreamSynchronize(s));
       std::memcpy(out_idx, po, nq * sizeof(int64_t));
       return NDI_OK;

@@ -66,6 +66,52 @@ def synth_target_queries(x, nq, chunk, rank):
     return np.concatenate(parts)
 
 
+def measure_traffic_pmc(args, kernel_substr, timeout_s=180):
+    """HBM-side bytes per launch of the dominant kernel, MEASURED in this invocation: two short child runs of this
+    very script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes; counters are KiB, gfx950 FETCH_SIZE tallies 128-byte requests
+    at 64 B: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024).  The parent must have released its device memory.  Returns
+    (bytes_per_launch, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself running under a profiler"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-check",
+             "--no-gather-leg", "--placement-probe", "0", "--no-secondary", "--no-pmc",
+             "--knots", str(args.knots), "--lanes", str(args.lanes), "--queries", str(args.queries),
+             "--chunk", str(args.chunk), "--ring-slots", str(args.ring_slots), "--path", args.path,
+             "--ring-layout", args.ring_layout]
+    means = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ndi_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]]
+            if not vals:
+                return None, f"no {counter} rows for {kernel_substr}"
+            means[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as e:  # noqa: BLE001 -- a profiling failure must not fail the bench
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = means["FETCH_SIZE"][0], means["WRITE_SIZE"][0]
+    return int((2 * fetch + write) * 1024), {"FETCH_SIZE_KiB": round(fetch, 1), "WRITE_SIZE_KiB": round(write, 1),
+                                             "launches_sampled": means["FETCH_SIZE"][1],
+                                             "read_bytes": int(2 * fetch * 1024), "write_bytes": int(write * 1024)}
+
+
 def usable_cores():
     """Cores this process may actually run on: the affinity mask, capped by a cgroup CPU quota when there is one
     (a GPU box hands each job a share of a large host: os.cpu_count() alone overstates it)."""
@@ -326,7 +372,7 @@ def secondary_legs(pkg, torch, dev):
     gpu_us = (time.perf_counter() - t0) / reps * 1e6
     sec["c1"] = {"workload": "1D Linear, 1024 f64 knots (index axis), scalar data, 1e4 queries, host arrays in and out",
                  "gpu_us": round(gpu_us, 1), "cpu_us": round(cpu_us, 1), "bit_exact": bool(np.array_equal(out, ref)),
-                 "gpu_path": "C ABI host to host (H2D, fused search+evaluate launch, D2H, one sync)",
+                 "gpu_path": "C ABI host to host (zero-copy: memcpy into a pinned buffer, one fused search+evaluate launch that reads and writes it through its host mapping, one sync, memcpy out)",
                  "cpu_path": "oracle port, 1 thread"}
     return sec
 
@@ -509,9 +555,10 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
                                    "placement": "first allocation of the process, no selection"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     # `traffic` is NOT measured by this run: it is the PMC figure of the same workload from the
-                     # committed profiles/traffic.json.  achieved / frac are the COMPUTED compulsory bytes of one
-                     # launch divided by this run's kernel time.
+                     # achieved / frac are the COMPUTED compulsory bytes of one launch divided by this run's kernel
+                     # time.  `traffic` starts as the PMC figure of the same workload from the committed
+                     # profiles/traffic.json and is REPLACED below by this invocation's own measurement (two child
+                     # runs under rocprofv3 --pmc) unless --no-pmc / N > 1 / no profiler.
                      "traffic_source": "stored (profiles/traffic.json, rocprofv3 --pmc of this workload)" if traffic else None,
                      "bytes_basis": "compulsory bytes per launch (output + tables + query records, once)",
                      "kernel": "eval_bucketed_kernel" if bucketed else "eval_rows_kernel",
@@ -598,6 +645,24 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         torch.cuda.empty_cache()
         line["secondary"] = secondary_legs(pkg, torch, dev)
 
+    if world == 1 and not args.no_pmc:
+        # the parent holds no device memory any more (released before the secondary legs): two short child runs of
+        # the same workload under rocprofv3 --pmc give this invocation's own HBM traffic per launch
+        if "secondary" not in line:
+            interp.strategy.release()
+            del ring, qd, interp, yd, xd
+            torch.cuda.empty_cache()
+        measured, detail = measure_traffic_pmc(args, "eval_bucketed_kernel" if bucketed else "eval_rows_kernel")
+        rf = line["roofline"]
+        if measured:
+            rf["traffic"] = measured
+            rf["traffic_source"] = "measured by this run (child runs under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE)"
+            rf["traffic_detail"] = detail
+            rf["traffic_frac"] = round(measured / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            rf.pop("stored_traffic_frac", None)
+        else:
+            rf["traffic_measurement_failed"] = detail
+
     if world == 1 and not args.no_cpu_baseline:
         res, build_s = cpu_baseline(x, y, q)
         v1, done1, _ = res["1t"]
@@ -633,6 +698,8 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the sampled-rows check against the CPU oracle")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the extra pass with the gather formulation")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C5-share / C1 legs after the timed region")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two child runs under rocprofv3 --pmc that measure "
+                    "this invocation's HBM traffic per launch (roofline.traffic then comes from profiles/traffic.json)")
     ap.add_argument("--ring-layout", choices=["striped", "separate"], default="striped",
                     help="target: striped = one allocation, slots interleaved row by row (recommended); separate = one "
                          "buffer per slot")

@@ -5,11 +5,11 @@ O=$R/gpurun_out
 cd $R && python bench.py --steps 20 --warmup 5 > $O/r03_bench_default.json 2> $O/r03_bench_default.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/r03_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r03_stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-check --no-gather-leg --placement-probe 0 --no-secondary > $O/r03_target_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r03_stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-check --no-gather-leg --placement-probe 0 --no-secondary --no-pmc > $O/r03_target_bench_under_rocprof.json 2>/dev/null
 cp $(find /tmp/r03_stats -name "*kernel_stats.csv" | head -1) $O/r03_target_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/r03_pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r03_pmc_$c -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-gather-leg --placement-probe 0 --no-secondary > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r03_pmc_$c -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-gather-leg --placement-probe 0 --no-secondary --no-pmc > /dev/null 2>&1
   python3 - "$(find /tmp/r03_pmc_$c -name '*counter_collection.csv' | head -1)" $c >> $O/r03_pmc_hbm_counters.txt <<'PY'
 import csv, sys, collections
 f, c = sys.argv[1:3]

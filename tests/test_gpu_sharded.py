@@ -190,6 +190,51 @@ def test_sharded_calls_from_concurrent_host_threads(pkg):
     assert not bad
 
 
+def test_sharded_fuzz_against_the_serial_loop(pkg):
+    """Seeded fuzz: random replica counts, batch sizes (empty shards included), strategies, extrapolation modes and
+    failing queries at random positions.  The sharded call must behave exactly like the reference's serial loop over
+    the whole batch (src/interp1d/mod.rs:326-343): same error kind and flat index, rows before it bit-equal to the
+    oracle, every later row untouched."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        dt = np.float64 if rng.random() < 0.6 else np.float32
+        n = int(rng.integers(3, 200)); L = int(rng.choice([1, 2, 3, 8, 64, 512]))
+        nshards = int(rng.integers(1, 6))
+        Q = int(rng.choice([0, 1, 2, nshards - 1 if nshards > 1 else 1, 7, 100, 4097, 20_000]))
+        cubic = bool(rng.random() < 0.6); extrap = bool(rng.random() < 0.4)
+        x = knots("rand", n, rng, dt); y = rng.uniform(-1, 1, (n, L)).astype(dt)
+        span = x[-1] - x[0]
+        q = rng.uniform(x[0] - (0.3 * span if extrap else 0), x[-1] + (0.3 * span if extrap else 0), Q).astype(dt)
+        q = np.clip(q, x[0], x[-1]) if not extrap else q
+        nbad = int(rng.integers(0, 4)) if Q else 0
+        bad = np.sort(rng.choice(Q, size=min(nbad, Q), replace=False)) if nbad else np.array([], dtype=int)
+        for b_ in bad:
+            q[b_] = np.nan if extrap else (x[-1] + dt(1.0) if rng.random() < 0.5 else x[0] - dt(1.0))
+        strat = (lambda d: pkg.CubicSpline.new().extrapolate(extrap).device(d)) if cubic else \
+            (lambda d: pkg.Linear.new().extrapolate(extrap).device(d))
+        reps = [pkg.Interp1DBuilder.new(y).x(x).strategy(strat(d)).build() for d in _devices(pkg, nshards)]
+        ex = oracle.EXTRAPOLATE_YES if extrap else oracle.EXTRAPOLATE_NO
+        if cubic:
+            st, a, b = oracle.cubic_build(x, y)
+            st, fail, ref = oracle.interp1d_cubic(x, y, a, b, q, extrapolate=ex)
+        else:
+            st, fail, ref = oracle.interp1d_linear(x, y, q, extrapolate=extrap)
+        out = np.full((Q, L), -9.0, dtype=dt)
+        tag = (case, dt.__name__, n, L, nshards, Q, cubic, extrap, bad.tolist())
+        if bad.size == 0:
+            pkg.sharding.interp_array_sharded(reps, q, out=out)
+            assert np.array_equal(out, ref), tag
+        else:
+            first = int(bad[0])
+            with pytest.raises((pkg.InterpolateError.OutOfBounds, pkg.Panic)) as ei:
+                pkg.sharding.interp_array_sharded(reps, q, out=out)
+            assert isinstance(ei.value, pkg.Panic if extrap else pkg.InterpolateError.OutOfBounds), tag
+            assert ei.value.index == first == fail, tag
+            assert np.array_equal(out[:first], ref[:first]) and np.all(out[first:] == -9.0), tag
+        for r in reps:
+            r.strategy.release()
+
+
 def test_replicas_by_device_to_device_copy(pkg):
     """ndi_interp{1,2}d_clone: a replica made by copying the device-resident tables equals one built from the host
     arrays -- same coefficient tables, same results -- and is independent of its source."""

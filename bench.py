@@ -66,7 +66,7 @@ def synth_target_queries(x, nq, chunk, rank):
     return np.concatenate(parts)
 
 
-def measure_traffic_pmc(args, kernel_substr, timeout_s=180):
+def measure_traffic_pmc(args, kernel_substr, timeout_s=90):
     """HBM-side bytes per launch of the dominant kernel, MEASURED in this invocation: two short child runs of this
     very script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; counters are KiB, gfx950 FETCH_SIZE tallies 128-byte requests
@@ -89,6 +89,7 @@ def measure_traffic_pmc(args, kernel_substr, timeout_s=180):
              "--ring-layout", args.ring_layout]
     means = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        progress(f"measuring HBM traffic: child run under rocprofv3 --pmc {counter}")
         d = tempfile.mkdtemp(prefix="ndi_pmc_", dir="/tmp")
         try:
             r = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child,
@@ -110,6 +111,11 @@ def measure_traffic_pmc(args, kernel_substr, timeout_s=180):
     return int((2 * fetch + write) * 1024), {"FETCH_SIZE_KiB": round(fetch, 1), "WRITE_SIZE_KiB": round(write, 1),
                                              "launches_sampled": means["FETCH_SIZE"][1],
                                              "read_bytes": int(2 * fetch * 1024), "write_bytes": int(write * 1024)}
+
+
+def progress(msg):
+    """One line on stderr per stage after the timed region: a long default run keeps showing signs of life."""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def usable_cores():
@@ -643,6 +649,7 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         interp.strategy.release()
         del ring, qd, interp, yd, xd
         torch.cuda.empty_cache()
+        progress("secondary legs: C3, C5 share, C1")
         line["secondary"] = secondary_legs(pkg, torch, dev)
 
     if world == 1 and not args.no_pmc:
@@ -664,6 +671,7 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
             rf["traffic_measurement_failed"] = detail
 
     if world == 1 and not args.no_cpu_baseline:
+        progress("CPU baseline (oracle port on the host cores, ~25 s)")
         res, build_s = cpu_baseline(x, y, q)
         v1, done1, _ = res["1t"]
         vall, doneall, threads = res["all"]

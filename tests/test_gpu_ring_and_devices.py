@@ -203,6 +203,37 @@ def test_ring_2d_bilinear(pkg):
     assert ei.value.index == 30_000 and sum(count) == 30_000
 
 
+def test_ring_2d_tile_grouped_order_through_the_pipeline(pkg):
+    """The tile-grouped 2-D order (tile histogram in locate2_kernel, LDS-tile evaluation) chunk by chunk through the
+    two-stream ring pipeline: search + grouping of chunk k+1 on the side stream while chunk k is evaluated; both
+    scratch sets are in use; bit-equal to the oracle; first-error cut."""
+    import torch
+    rng = np.random.default_rng(16)
+    nx, ny, Cn, Q, chunk = 90, 75, 32, 70_001, 9000
+    g = rng.random((nx, ny, Cn), dtype=np.float32)
+    x = knots("rand", nx, rng, np.float32); y = knots("rand", ny, rng, np.float32)
+    interp = pkg.Interp2DBuilder.new(g).x(x).y(y).build()
+    interp.strategy.path = pkg.PATH_BUCKETED
+    qx = rng.uniform(x[0], x[-1], Q).astype(np.float32); qy = rng.uniform(y[0], y[-1], Q).astype(np.float32)
+    _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy)
+    got = np.zeros_like(ref)
+    ring = pkg.striped_ring(chunk, Cn, 3, np.float32, 0)
+
+    def consumer(c, rows):
+        got[c.q_begin:c.q_begin + c.q_count] = rows.cpu().numpy()
+    for _ in range(2):                                   # second pass: scratch sets and events are reused
+        got[:] = 0
+        interp.interp_array_ring(torch.as_tensor(qx, device="cuda:0"), torch.as_tensor(qy, device="cuda:0"), chunk,
+                                 consumer, slots=ring)
+        assert pkg.profile_read(reset=False)["last_path"] == "bucketed"
+        assert np.array_equal(got, ref)
+    qx[50_000] = x[-1] + 1
+    count = []
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        interp.interp_array_ring(qx, qy, chunk, lambda c, rows: count.append(c.q_count), slots=ring)
+    assert ei.value.index == 50_000 and sum(count) == 50_000
+
+
 def test_c4_share_chunked(pkg):
     """configs[3], one GPU's share: 1D CubicSpline 4096 knots x 4096 lanes f64, 1.25e7 queries (409.6 GB of
     output) through a 2-slot device-output ring in chunks of 1e6.  Per chunk: the integer checksum of all

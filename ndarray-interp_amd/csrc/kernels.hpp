@@ -1220,43 +1220,88 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
       s_b0 = lo;
     }
     __syncthreads();
-    const uint32_t b0 = s_b0;
-    for (uint32_t b = b0; b < A.nb; ++b) {
-      const uint64_t bs = const_load(A.bin_start, b);
-      const uint64_t be = (b + 1u < A.nb) ? (uint64_t)const_load(A.bin_start, b + 1u) : n_pos;
-      if (bs >= p1) break;
-      const uint64_t lo = bs > p0 ? bs : p0, hi = be < p1 ? be : p1;
-      if (lo >= hi) continue;                       // empty tile (workgroup-uniform)
-      const uint32_t tx = b / A.nty, ty = b - tx * A.nty;
-      const uint64_t gx0 = (uint64_t)tx << A.ts, gy0 = (uint64_t)ty << A.ts;
-      const uint32_t rows = (uint32_t)((A.nx - gx0 < S1) ? A.nx - gx0 : S1);     // grid points of the tile
-      const uint32_t cols = (uint32_t)((A.ny - gy0 < S1) ? A.ny - gy0 : S1);
-      __syncthreads();                              // the previous tile is no longer being read
-      {
-        const uint32_t row_vecs = cols * LV;        // one contiguous segment per grid row
-        const uint32_t items = rows * row_vecs;
-        for (uint32_t it = tid; it < items; it += TB) {
+    // Tiles are double-buffered through REGISTERS: while the records of the current tile are evaluated out of LDS,
+    // the grid points, knots and knot spacings of the next tile the chunk touches are already on their way into
+    // `pre` / `pk` (at most MAXI 16-byte vectors per thread); at the tile switch they are written to LDS.  vmcnt is
+    // in-order, so the prefetch is complete by the time the first block of records of the current tile is handed
+    // over -- its latency hides behind one block of evaluation instead of stalling the CU's only workgroup.
+    constexpr int MAXI = 6;   // (2^ts + 1)^2 * LV <= MAXI * TB vectors: guaranteed by the host's LDS budget (96 KiB)
+    struct TileGeo { uint64_t gx0, gy0, lo, hi; uint32_t rows, cols, b; bool valid; };
+    auto find_tile = [&](uint32_t b_from) {
+      TileGeo g{};
+      g.valid = false;
+      for (uint32_t bb = b_from; bb < A.nb; ++bb) {
+        const uint64_t bs = const_load(A.bin_start, bb);
+        const uint64_t be = (bb + 1u < A.nb) ? (uint64_t)const_load(A.bin_start, bb + 1u) : n_pos;
+        if (bs >= p1) break;
+        const uint64_t lo = bs > p0 ? bs : p0, hi = be < p1 ? be : p1;
+        if (lo >= hi) continue;                     // empty tile (workgroup-uniform)
+        const uint32_t tx = bb / A.nty, ty = bb - tx * A.nty;
+        g.gx0 = (uint64_t)tx << A.ts;
+        g.gy0 = (uint64_t)ty << A.ts;
+        g.rows = (uint32_t)((A.nx - g.gx0 < S1) ? A.nx - g.gx0 : S1);   // grid points of the tile
+        g.cols = (uint32_t)((A.ny - g.gy0 < S1) ? A.ny - g.gy0 : S1);
+        g.lo = lo; g.hi = hi; g.b = bb; g.valid = true;
+        break;
+      }
+      return g;
+    };
+    V pre[MAXI];
+    uint32_t pre_off[MAXI];
+    T pk0 = T(0), pk1 = T(0);
+    auto prefetch = [&](const TileGeo& g) {
+      const uint32_t row_vecs = g.cols * LV;        // one contiguous segment per grid row
+      const uint32_t items = g.rows * row_vecs;
+#pragma unroll
+      for (int k = 0; k < MAXI; ++k) {
+        const uint32_t it = tid + (uint32_t)k * TB;
+        pre_off[k] = 0xffffffffu;
+        if (it < items) {
           const uint32_t r = it / row_vecs, j = it - r * row_vecs;
-          const V* src = reinterpret_cast<const V*>(A.data + ((gx0 + r) * A.ny + gy0) * A.lanes);
-          s_tile[(size_t)r * S1 * LV + j] = src[j];
-        }
-        if (tid < rows) s_kx[tid] = A.xk[gx0 + tid];
-        if (tid >= 64u && tid - 64u < cols) s_ky[tid - 64u] = A.yk[gy0 + (tid - 64u)];
-        // one IEEE reciprocal per knot interval of the tile (instead of one per division and lane)
-        if (tid >= 128u && tid - 128u + 1u < rows) {
-          const uint32_t i = tid - 128u;
-          const SharedDivisor<T> sd = shared_divisor<T>(A.xk[gx0 + i + 1u] - A.xk[gx0 + i]);
-          s_rx[i] = sd.ok ? sd.r : T(0);
-        }
-        if (tid >= 192u && tid - 192u + 1u < cols) {
-          const uint32_t i = tid - 192u;
-          const SharedDivisor<T> sd = shared_divisor<T>(A.yk[gy0 + i + 1u] - A.yk[gy0 + i]);
-          s_ry[i] = sd.ok ? sd.r : T(0);
+          const V* src = reinterpret_cast<const V*>(A.data + ((g.gx0 + r) * A.ny + g.gy0) * A.lanes);
+          pre[k] = src[j];
+          pre_off[k] = r * S1 * LV + j;
         }
       }
+      // threads 0 .. rows-1 carry the x knots (and their right neighbours, for the spacing), 64 .. 64+cols-1 the y knots
+      if (tid < g.rows) {
+        pk0 = A.xk[g.gx0 + tid];
+        if (tid + 1u < g.rows) pk1 = A.xk[g.gx0 + tid + 1u];
+      } else if (tid >= 64u && tid - 64u < g.cols) {
+        pk0 = A.yk[g.gy0 + (tid - 64u)];
+        if (tid - 64u + 1u < g.cols) pk1 = A.yk[g.gy0 + (tid - 64u) + 1u];
+      }
+    };
+    auto commit = [&](const TileGeo& g) {
+#pragma unroll
+      for (int k = 0; k < MAXI; ++k)
+        if (pre_off[k] != 0xffffffffu) s_tile[pre_off[k]] = pre[k];
+      // one IEEE reciprocal per knot interval of the tile (instead of one per division and lane)
+      if (tid < g.rows) {
+        s_kx[tid] = pk0;
+        if (tid + 1u < g.rows) {
+          const SharedDivisor<T> sd = shared_divisor<T>(pk1 - pk0);
+          s_rx[tid] = sd.ok ? sd.r : T(0);
+        }
+      } else if (tid >= 64u && tid - 64u < g.cols) {
+        s_ky[tid - 64u] = pk0;
+        if (tid - 64u + 1u < g.cols) {
+          const SharedDivisor<T> sd = shared_divisor<T>(pk1 - pk0);
+          s_ry[tid - 64u] = sd.ok ? sd.r : T(0);
+        }
+      }
+    };
+    TileGeo cur = find_tile(s_b0);
+    if (cur.valid) prefetch(cur);
+    while (cur.valid) {
+      const uint64_t gx0 = cur.gx0, gy0 = cur.gy0, lo = cur.lo, hi = cur.hi;
+      __syncthreads();                              // the previous tile is no longer being read
+      commit(cur);
+      const TileGeo nxt = find_tile(cur.b + 1u);
+      if (nxt.valid) prefetch(nxt);                 // in flight while this tile's records are evaluated
       __syncthreads();
-      // The tile's records are brought in 256 at a time (one coalesced 16-byte load per thread) and handed to the
-      // 16-lane groups through LDS; the next block's loads are in flight while the current block is evaluated, so a
+      // The tile's records are brought in TB at a time (one coalesced 16-byte load per thread) and handed to the
+      // LV-lane groups through LDS; the next block's loads are in flight while the current block is evaluated, so a
       // workgroup pays one memory latency per 256 queries instead of one per trip.
       bool compact = false;
       if constexpr (std::is_same<T, float>::value) compact = A.rec_q == nullptr;
@@ -1273,10 +1318,10 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
         s_rec[tid] = r_in;
         if (!compact) { s_rq[2 * tid] = rx_in; s_rq[2 * tid + 1] = ry_in; }
         __syncthreads();                            // (also: the tile staged above is complete)
-        const uint64_t nxt = pb + TB;
-        if (nxt + tid < hi) {
-          r_in = A.rec_i[nxt + tid];
-          if (!compact) { rx_in = A.rec_q[2 * (nxt + tid)]; ry_in = A.rec_q[2 * (nxt + tid) + 1]; }
+        const uint64_t nxt_p = pb + TB;
+        if (nxt_p + tid < hi) {
+          r_in = A.rec_i[nxt_p + tid];
+          if (!compact) { rx_in = A.rec_q[2 * (nxt_p + tid)]; ry_in = A.rec_q[2 * (nxt_p + tid) + 1]; }
         }
         for (uint32_t j = ql; j < cnt; j += qpt) {
           const uint4 r = s_rec[j];
@@ -1309,8 +1354,9 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
           const V z2 = frac_shared<T, V>(x1, a12, dx, a22, x);
           __builtin_nontemporal_store(frac_shared<T, V>(y1, z1, dy, z2, y), o + v);
         }
-        pb = nxt;
+        pb = nxt_p;
       }
+      cur = nxt;
     }
     __syncthreads();                                // s_b0 is rewritten by the next chunk
   }

@@ -1494,7 +1494,9 @@ struct Interp2DImpl final : Interp2DBase {
         nx < (1ull << 31) && ny < (1ull << 31)) {
       static const int ts_env = [] { const char* e = std::getenv("NDI_TILE_TS"); return e ? std::atoi(e) : -1; }();
       // the largest tile that leaves room for two workgroups per CU, else the largest that fits at all
-      for (size_t budget : {(size_t)76 * 1024, (size_t)118 * 1024}) {   // + 24-32 KiB of static LDS per workgroup
+      // the tile must fit the kernel's register double-buffer (6 x 1024 16-byte vectors = 96 KiB) next to 24-32 KiB of
+      // static LDS; the smaller budget is tried first (shorter staging per tile)
+      for (size_t budget : {(size_t)76 * 1024, (size_t)96 * 1024}) {
         for (int sh = 6; sh >= 1 && !shape_ok; --sh) {
           if (ts_env >= 0 && sh != ts_env) continue;
           const uint64_t bins = (uint64_t)ntiles_of(nx, sh) * ntiles_of(ny, sh);

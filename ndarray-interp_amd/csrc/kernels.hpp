@@ -1,6 +1,6 @@
 // csrc/kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
 //
-// Everything here is HBM-bound gather/stream work (no dense contraction, so no MFMA):
+// Everything here is gather/stream work (no dense contraction, so no MFMA), HBM-bound except where noted:
 //   locate_kernel / locate2_kernel
 //                          per-query interval search (one / both axes): knot pyramid staged in LDS, top level
 //                          held one entry per lane and bisected with cross-lane gathers, lower levels bisected
@@ -16,8 +16,13 @@
 //                          block-local counting sort of the queries by interval (LDS histograms and cursors)
 //   eval_bucketed_kernel   BUCKETED formulation: grouped order, operand rows held in registers across a
 //                          group, output streamed; XCD-aware chunk order
-//   eval_bilinear_kernel   2-D (bilinear.rs:83-97), plain or pair-packed grid (pack_pairs_kernel);
-//                          locate2_kernel's tile histogram + group_scatter2d_kernel give the tile-grouped order
+//   eval_bilinear_kernel   2-D gather order (bilinear.rs:83-97), plain or pair-packed grid (pack_pairs_kernel)
+//   eval_bilinear_tiles_kernel
+//                          2-D tile-grouped order (locate2_kernel's tile histogram + group_scatter2d_kernel): every
+//                          tile of grid points staged once in LDS (double-buffered through registers), per-row
+//                          divisions as correctly rounded shared-divisor divisions (div_shared); bound by
+//                          occupancy beside the tile, not by HBM
+//   probe_gather_kernel    measurement aid: the 2-D gather's memory access mix alone
 //   spline_build_*         batched Thomas solve, one lane of the trailing axes per thread, shared (or
 //                          per-lane selected) elimination factors          (cubic_spline.rs:310-368, 409-721)
 //

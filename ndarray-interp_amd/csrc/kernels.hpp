@@ -1020,91 +1020,6 @@ __global__ __launch_bounds__(BLOCK) void pack_pairs_kernel(const E* in, E* out, 
   }
 }
 
-// APPROX exists only for the tuning harness (tools/tune_eval.hip: how much of the kernel is division cost);
-// the library instantiates the exact form.
-template <class T, class V, bool APPROX = false>
-__device__ __forceinline__ V frac_v(T x1, V y1, T x2, V y2, T x) {
-  V m;
-  if (APPROX) m = (y2 - y1) * (T(1) / (x2 - x1));
-  else m = (y2 - y1) / (x2 - x1);  // Linear::calc_frac, linear.rs:33-35
-  return m * (x - x1) + y1;
-}
-
-// UNR items (one output vector each) per thread and loop trip, processed in three phases -- indices and query
-// values, then knots and the four corner vectors, then arithmetic and store -- so that the two dependent memory
-// latencies of an item (index -> corner) are paid once per UNR items: the kernel is a random gather whose only
-// lever is memory-level parallelism (C5, 8192 x 8192 x 16 f32: UNR 1 -> 2: 0.88 -> see DESIGN.md 4.4).
-// KLDS: both knot vectors are staged in LDS once per workgroup (TB = 1024 threads, a grid of about two workgroups
-// per CU) and the four knot values of an item come from there instead of four scattered global loads.
-template <class T, int VEC, bool APPROX = false, int UNR = 2, int TB = BLOCK, bool KLDS = false>
-__global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint32_t tile_q) {
-  using V = typename VecT<T, VEC>::type;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typename KnotPtr<T, KLDS>::type xk, yk;
-  if constexpr (KLDS) {
-    T* s0 = reinterpret_cast<T*>(smem_raw);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)A.nx; i += TB) s0[i] = A.xk[i];
-    for (uint32_t i = threadIdx.x; i < (uint32_t)A.ny; i += TB) s0[A.nx + i] = A.yk[i];
-    __syncthreads();
-    xk = (lds_ptr<T>)(smem_raw);
-    yk = xk + A.nx;
-  } else {
-    xk = A.xk;
-    yk = A.yk;
-  }
-  const uint32_t LV = (uint32_t)(A.lanes / VEC);
-  unsigned long long limit = A.status->first_fail[0];
-  if (A.status->first_fail[1] < limit) limit = A.status->first_fail[1];
-  if (limit > A.nq) limit = A.nq;
-  // grouped order covers every query (rows at/after the first failure are skipped one by one)
-  const uint64_t span = limit;
-  const uint64_t ntiles = (span + tile_q - 1) / tile_q;
-  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint64_t q0 = tile * tile_q;
-    const uint32_t nq_here = (span - q0 < tile_q) ? (uint32_t)(span - q0) : tile_q;
-    const uint32_t items = nq_here * LV;
-    for (uint32_t it0 = threadIdx.x; it0 < items; it0 += TB * UNR) {
-      bool live[UNR];
-      uint32_t v[UNR], xi[UNR], yi[UNR];
-      uint64_t qi[UNR];
-      T x[UNR], y[UNR];
-#pragma unroll
-      for (int k = 0; k < UNR; ++k) {          // phase 1: indices and query values
-        const uint32_t it = it0 + (uint32_t)k * TB;
-        live[k] = it < items;
-        const uint32_t ql = live[k] ? it / LV : 0u;
-        v[k] = live[k] ? it - ql * LV : 0u;
-        qi[k] = q0 + ql;
-        xi[k] = A.xi[qi[k]];
-        yi[k] = A.yi[qi[k]];
-        x[k] = A.qx[qi[k]];
-        y[k] = A.qy[qi[k]];
-      }
-      T x1[UNR], x2[UNR], y1[UNR], y2[UNR];
-      V a11[UNR], a12[UNR], a21[UNR], a22[UNR];
-#pragma unroll
-      for (int k = 0; k < UNR; ++k) {          // phase 2: knots and the four corner vectors
-        x1[k] = xk[xi[k]]; x2[k] = xk[xi[k] + 1];
-        y1[k] = yk[yi[k]]; y2[k] = yk[yi[k] + 1];
-        const V* z11 = reinterpret_cast<const V*>(A.data + ((uint64_t)xi[k] * A.row_cells + yi[k]) * A.cell_elems);
-        const V* z21 = reinterpret_cast<const V*>(A.data + ((uint64_t)(xi[k] + 1) * A.row_cells + yi[k]) * A.cell_elems);
-        a11[k] = z11[v[k]];
-        a12[k] = z11[LV + v[k]];                 // (xi,   yi+1)
-        a21[k] = z21[v[k]];
-        a22[k] = z21[LV + v[k]];                 // (xi+1, yi+1)
-      }
-#pragma unroll
-      for (int k = 0; k < UNR; ++k) {          // phase 3: bilinear.rs:88-97, store
-        const V z1 = frac_v<T, V, APPROX>(x1[k], a11[k], x2[k], a21[k], x[k]);
-        const V z2 = frac_v<T, V, APPROX>(x1[k], a12[k], x2[k], a22[k], x[k]);
-        V* o = reinterpret_cast<V*>(A.out + qi[k] * A.out_stride);
-        // written once, never re-read by the kernel: non-temporal (C3 -3 %, C5 share -4 %: profiles/r03_c3_grouped.md)
-        if (live[k]) __builtin_nontemporal_store(frac_v<T, V, APPROX>(y1[k], z1, y2[k], z2, y[k]), o + v[k]);
-      }
-    }
-  }
-}
-
 // Correctly rounded division of many numerators by ONE divisor (the per-query knot spacing shared by all channels
 // of a row): r = RN(1 / d) is formed once with the IEEE division, then every quotient costs one multiplication and
 // four FMAs -- all available as packed 2 x f32 instructions -- instead of the ~10-instruction IEEE sequence with its
@@ -1170,6 +1085,98 @@ template <class T, class V>
 __device__ __forceinline__ V frac_shared(T x1, V y1, const SharedDivisor<T>& dx, V y2, T x) {
   const V m = div_shared<T, V>(y2 - y1, dx);
   return m * (x - x1) + y1;
+}
+
+// APPROX exists only for the tuning harness (tools/tune_eval.hip: how much of the kernel is division cost);
+// the library instantiates the exact form.
+template <class T, class V, bool APPROX = false>
+__device__ __forceinline__ V frac_v(T x1, V y1, T x2, V y2, T x) {
+  V m;
+  if (APPROX) m = (y2 - y1) * (T(1) / (x2 - x1));
+  else m = (y2 - y1) / (x2 - x1);  // Linear::calc_frac, linear.rs:33-35
+  return m * (x - x1) + y1;
+}
+
+// UNR items (one output vector each) per thread and loop trip, processed in three phases -- indices and query
+// values, then knots and the four corner vectors, then arithmetic and store -- so that the two dependent memory
+// latencies of an item (index -> corner) are paid once per UNR items: the kernel is a random gather whose only
+// lever is memory-level parallelism (C5, 8192 x 8192 x 16 f32: UNR 1 -> 2: 0.88 -> see DESIGN.md 4.4).
+// KLDS: both knot vectors are staged in LDS once per workgroup (TB = 1024 threads, a grid of about two workgroups
+// per CU) and the four knot values of an item come from there instead of four scattered global loads.
+template <class T, int VEC, bool APPROX = false, int UNR = 2, int TB = BLOCK, bool KLDS = false, bool SDIV = false>
+__global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint32_t tile_q) {
+  using V = typename VecT<T, VEC>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typename KnotPtr<T, KLDS>::type xk, yk;
+  if constexpr (KLDS) {
+    T* s0 = reinterpret_cast<T*>(smem_raw);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)A.nx; i += TB) s0[i] = A.xk[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)A.ny; i += TB) s0[A.nx + i] = A.yk[i];
+    __syncthreads();
+    xk = (lds_ptr<T>)(smem_raw);
+    yk = xk + A.nx;
+  } else {
+    xk = A.xk;
+    yk = A.yk;
+  }
+  const uint32_t LV = (uint32_t)(A.lanes / VEC);
+  unsigned long long limit = A.status->first_fail[0];
+  if (A.status->first_fail[1] < limit) limit = A.status->first_fail[1];
+  if (limit > A.nq) limit = A.nq;
+  // grouped order covers every query (rows at/after the first failure are skipped one by one)
+  const uint64_t span = limit;
+  const uint64_t ntiles = (span + tile_q - 1) / tile_q;
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t q0 = tile * tile_q;
+    const uint32_t nq_here = (span - q0 < tile_q) ? (uint32_t)(span - q0) : tile_q;
+    const uint32_t items = nq_here * LV;
+    for (uint32_t it0 = threadIdx.x; it0 < items; it0 += TB * UNR) {
+      bool live[UNR];
+      uint32_t v[UNR], xi[UNR], yi[UNR];
+      uint64_t qi[UNR];
+      T x[UNR], y[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {          // phase 1: indices and query values
+        const uint32_t it = it0 + (uint32_t)k * TB;
+        live[k] = it < items;
+        const uint32_t ql = live[k] ? it / LV : 0u;
+        v[k] = live[k] ? it - ql * LV : 0u;
+        qi[k] = q0 + ql;
+        xi[k] = A.xi[qi[k]];
+        yi[k] = A.yi[qi[k]];
+        x[k] = A.qx[qi[k]];
+        y[k] = A.qy[qi[k]];
+      }
+      T x1[UNR], x2[UNR], y1[UNR], y2[UNR];
+      V a11[UNR], a12[UNR], a21[UNR], a22[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {          // phase 2: knots and the four corner vectors
+        x1[k] = xk[xi[k]]; x2[k] = xk[xi[k] + 1];
+        y1[k] = yk[yi[k]]; y2[k] = yk[yi[k] + 1];
+        const V* z11 = reinterpret_cast<const V*>(A.data + ((uint64_t)xi[k] * A.row_cells + yi[k]) * A.cell_elems);
+        const V* z21 = reinterpret_cast<const V*>(A.data + ((uint64_t)(xi[k] + 1) * A.row_cells + yi[k]) * A.cell_elems);
+        a11[k] = z11[v[k]];
+        a12[k] = z11[LV + v[k]];                 // (xi,   yi+1)
+        a21[k] = z21[v[k]];
+        a22[k] = z21[LV + v[k]];                 // (xi+1, yi+1)
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {          // phase 3: bilinear.rs:88-97, store
+        V* o = reinterpret_cast<V*>(A.out + qi[k] * A.out_stride);
+        if constexpr (SDIV) {   // the row's divisions share their divisors: one reciprocal per axis and item
+          const SharedDivisor<T> dx = shared_divisor<T>(x2[k] - x1[k]), dy = shared_divisor<T>(y2[k] - y1[k]);
+          const V z1 = frac_shared<T, V>(x1[k], a11[k], dx, a21[k], x[k]);
+          const V z2 = frac_shared<T, V>(x1[k], a12[k], dx, a22[k], x[k]);
+          if (live[k]) __builtin_nontemporal_store(frac_shared<T, V>(y1[k], z1, dy, z2, y[k]), o + v[k]);
+          continue;
+        }
+        const V z1 = frac_v<T, V, APPROX>(x1[k], a11[k], x2[k], a21[k], x[k]);
+        const V z2 = frac_v<T, V, APPROX>(x1[k], a12[k], x2[k], a22[k], x[k]);
+        // written once, never re-read by the kernel: non-temporal (C3 -3 %, C5 share -4 %: profiles/r03_c3_grouped.md)
+        if (live[k]) __builtin_nontemporal_store(frac_v<T, V, APPROX>(y1[k], z1, y2[k], z2, y[k]), o + v[k]);
+      }
+    }
+  }
 }
 
 // TILE-GROUPED 2-D evaluation (ndi_path BUCKETED / AUTO for long batches on large grids).  The queries have been

@@ -24,3 +24,6 @@ done
 rm -rf /tmp/r03_stats_sec
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r03_stats_sec -- python3 $R/bench.py --workload c3 --steps 10 --warmup 3 > $O/r03_c3_bench_under_rocprof.json 2>/dev/null
 cp $(find /tmp/r03_stats_sec -name "*kernel_stats.csv" | head -1) $O/r03_c3_kernel_stats.csv
+rm -rf /tmp/r03_stats_c5
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r03_stats_c5 -- python3 $R/bench.py --workload c5 --steps 10 --warmup 3 > $O/r03_c5_bench_under_rocprof.json 2>/dev/null
+cp $(find /tmp/r03_stats_c5 -name "*kernel_stats.csv" | head -1) $O/r03_c5_share_kernel_stats.csv

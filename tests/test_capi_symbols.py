@@ -121,3 +121,32 @@ def test_header_is_plain_c99(tmp_path):
         exp = [0.5, 0.1851851851851852, 0.01851851851851853, -5.551115123125783e-17, 0.12962962962962965,
                0.40740740740740755, 0.8333333333333331, 1.407407407407407, 2.1296296296296293, 3.0]
         assert run.returncode == 0 and max(abs(a - b) for a, b in zip(vals, exp)) <= 2.220446049250313e-16
+
+
+def test_sharded_example_is_plain_c99(tmp_path):
+    """examples/c_abi_sharded.c: replicas by ndi_interp1d_clone + ndi_interp1d_eval_sharded from strict C99; loud
+    failure without a GPU, the sharded result equal to the single-handle one (and the global first error) with one."""
+    import ctypes
+    import subprocess
+    exe = tmp_path / "c_abi_sharded"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                        os.path.join(ROOT, "examples", "c_abi_sharded.c"), "-I", os.path.join(ROOT, "include"),
+                        "-L", os.path.join(ROOT, "ndarray-interp_amd"), "-lndinterp_hip",
+                        "-Wl,-rpath," + os.path.join(ROOT, "ndarray-interp_amd"), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    if ctypes.CDLL(os.path.join(ROOT, "ndarray-interp_amd", "libndinterp_hip.so")).ndi_device_count() == 0:
+        assert run.returncode == 1 and "no CPU fallback" in run.stderr
+    else:
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert "sharded == single-handle result; first error at flat index 5 (x = -1000000000 is not in range)" in run.stdout
+
+
+@pytest.mark.gpu
+def test_c_examples_on_the_device(tmp_path):
+    """The same two C99 programs in the GPU suite: there they must run to completion against the device."""
+    import ctypes
+    assert ctypes.CDLL(os.path.join(ROOT, "ndarray-interp_amd", "libndinterp_hip.so")).ndi_device_count() >= 1
+    test_header_is_plain_c99(tmp_path)
+    test_sharded_example_is_plain_c99(tmp_path)

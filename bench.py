@@ -345,6 +345,48 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
     return res
 
 
+def in_process_sharded_leg(args, pkg, torch, x, y, steps=3):
+    """When this ONE process sees several devices (the N = 1 run on a multi-GPU node): the Target batch per device
+    through ndi_interp1d_eval_ring_sharded -- replicas by device-to-device copy, one library call per step, one host
+    thread per device inside the library, no collective.  Reported after the timed region; never part of `value`."""
+    devs = [int(d) for d in args.sharded_leg_devices.split(",")] if args.sharded_leg_devices else \
+        list(range(pkg.device_count()))
+    ndev = len(devs)
+    if ndev < 2:
+        return None
+    try:
+        nq, chunk, lanes = args.queries, args.chunk, args.lanes
+        first = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=f"cuda:{devs[0]}")).x(torch.as_tensor(x, device=f"cuda:{devs[0]}")) \
+            .strategy(pkg.CubicSpline.new().device(devs[0])).build()
+        reps = [first] + first.replicate(devs[1:])
+        blocks = [torch.as_tensor(synth_target_queries(x, nq, chunk, 1000 + i), device=f"cuda:{d}") for i, d in enumerate(devs)]
+        total = nq * ndev
+        # the library splits the whole batch with ndi_shard_bounds: equal blocks of nq here
+        assert all(pkg.sharding.shard_bounds(total, d, ndev) == (d * nq, (d + 1) * nq) for d in range(ndev))
+
+        def step():
+            pkg.sharding.interp_array_ring_sharded(reps, blocks, chunk_queries=chunk, consumer=None, n_slots=args.ring_slots)
+        step()
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+        el = (time.perf_counter() - t0) / steps
+        res = {"devices": devs, "queries_per_device": nq, "ms_per_step": round(el * 1e3, 3),
+               "Mpoints_s": round(total * lanes / el / 1e6, 1),
+               "what": "one process, one ndi_interp1d_eval_ring_sharded call per step over all visible devices"}
+        for r in reps:
+            r.strategy.release()
+        del reps, blocks
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:  # noqa: BLE001 -- an extra leg must not fail the bench
+        return {"devices": devs, "error": f"{type(e).__name__}: {e}"}
+
+
 def secondary_legs(pkg, torch, dev):
     """Short legs for the other BASELINE configs, run AFTER the timed Target region (never inside it): C3
     (configs[2]), C5's per-GPU share (configs[4]) and C1 (configs[0], the reference's CPU-runnable case, host arrays
@@ -651,6 +693,12 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         torch.cuda.empty_cache()
         progress("secondary legs: C3, C5 share, C1")
         line["secondary"] = secondary_legs(pkg, torch, dev)
+        if pkg.device_count() >= 2 or args.sharded_leg_devices:
+            progress("in-process sharded leg over the visible devices")
+            leg = in_process_sharded_leg(args, pkg, torch, x, y)
+            if leg:
+                leg["speedup_vs_this_run_one_device"] = round(leg.get("Mpoints_s", 0.0) / value, 3) if "Mpoints_s" in leg else None
+                line["in_process_sharded"] = leg
 
     if world == 1 and not args.no_pmc:
         # the parent holds no device memory any more (released before the secondary legs): two short child runs of
@@ -706,6 +754,9 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the sampled-rows check against the CPU oracle")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the extra pass with the gather formulation")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C5-share / C1 legs after the timed region")
+    ap.add_argument("--sharded-leg-devices", default=None,
+                    help="rehearsal: device ordinals of the in-process sharded leg (default: every visible device when "
+                         "there are at least two), e.g. 0,0 on a 1-GPU box")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two child runs under rocprofv3 --pmc that measure "
                     "this invocation's HBM traffic per launch (roofline.traffic then comes from profiles/traffic.json)")
     ap.add_argument("--ring-layout", choices=["striped", "separate"], default="striped",

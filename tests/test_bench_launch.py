@@ -79,3 +79,18 @@ def test_bench_two_ranks_on_one_gpu_line_carries_ranks():
     assert all(v > 0 for v in rk["per_rank_ms"] + rk["per_rank_kernel_ms"])
     assert [d["ordinal"] for d in rk["devices"]] == [0, 0] and rk["distinct_devices"] == 1
     assert line["ms_per_step"] >= max(rk["per_rank_ms"]) * 0.999 and line["check"]["bit_exact"]
+
+
+@pytest.mark.gpu
+def test_bench_in_process_sharded_leg():
+    """The leg the N = 1 run adds when its one process sees several devices (one ndi_interp1d_eval_ring_sharded call
+    per step over all of them), rehearsed on the 1-GPU box with two replicas on device 0 and a small workload."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--knots", "512", "--lanes", "1024", "--queries",
+                        "400000", "--chunk", "100000", "--steps", "2", "--warmup", "1", "--placement-probe", "0",
+                        "--no-gather-leg", "--no-pmc", "--no-cpu-baseline", "--sharded-leg-devices", "0,0"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _one_json_line(r.stdout)
+    leg = line["in_process_sharded"]
+    assert leg["devices"] == [0, 0] and "error" not in leg and leg["Mpoints_s"] > 0 and leg["queries_per_device"] == 400000
+    assert set(line["secondary"]) == {"c3", "c5_share", "c1"}

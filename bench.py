@@ -356,6 +356,12 @@ def in_process_sharded_leg(args, pkg, torch, x, y, steps=3):
         return None
     try:
         nq, chunk, lanes = args.queries, args.chunk, args.lanes
+        # every device must have room for its share of rings and tables -- a device someone else is using is left alone
+        per_dev = {d: devs.count(d) * (args.ring_slots * chunk * lanes * 8 + (2 << 30)) for d in set(devs)}
+        for d, need in per_dev.items():
+            free_b, _ = torch.cuda.mem_get_info(d)
+            if free_b < need:
+                return {"devices": devs, "skipped": f"device {d} has {free_b / 1e9:.0f} GB free, the leg needs {need / 1e9:.0f} GB"}
         first = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=f"cuda:{devs[0]}")).x(torch.as_tensor(x, device=f"cuda:{devs[0]}")) \
             .strategy(pkg.CubicSpline.new().device(devs[0])).build()
         reps = [first] + first.replicate(devs[1:])

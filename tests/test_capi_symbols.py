@@ -101,7 +101,7 @@ def test_argument_validation_needs_no_device(pkg):
     assert lib.ndi_profile_read(None, 0) == pkg._capi.BAD_ARG
 
 
-def test_header_is_plain_c99(tmp_path):
+def test_header_is_plain_c99(pkg, tmp_path):
     """The boundary is a C ABI: the header must compile as strict C99 (no C++-isms, no torch/HIP types) and a
     C program using it must link against the library."""
     import subprocess
@@ -113,8 +113,9 @@ def test_header_is_plain_c99(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    import ctypes
-    if ctypes.CDLL(os.path.join(ROOT, "ndarray-interp_amd", "libndinterp_hip.so")).ndi_device_count() == 0:
+    # (the library is reached through the package, i.e. after torch: a process that loads this library first and torch
+    # second ends up with two HIP runtimes -- torch bundles its own -- and torch then sees no device)
+    if pkg._capi.lib().ndi_device_count() == 0:
         assert run.returncode == 1 and "no CPU fallback" in run.stderr     # loud failure without a GPU
     else:
         vals = [float(v) for v in run.stdout.split()]
@@ -123,7 +124,7 @@ def test_header_is_plain_c99(tmp_path):
         assert run.returncode == 0 and max(abs(a - b) for a, b in zip(vals, exp)) <= 2.220446049250313e-16
 
 
-def test_sharded_example_is_plain_c99(tmp_path):
+def test_sharded_example_is_plain_c99(pkg, tmp_path):
     """examples/c_abi_sharded.c: replicas by ndi_interp1d_clone + ndi_interp1d_eval_sharded from strict C99; loud
     failure without a GPU, the sharded result equal to the single-handle one (and the global first error) with one."""
     import ctypes
@@ -136,7 +137,7 @@ def test_sharded_example_is_plain_c99(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    if ctypes.CDLL(os.path.join(ROOT, "ndarray-interp_amd", "libndinterp_hip.so")).ndi_device_count() == 0:
+    if pkg._capi.lib().ndi_device_count() == 0:
         assert run.returncode == 1 and "no CPU fallback" in run.stderr
     else:
         assert run.returncode == 0, run.stdout + run.stderr
@@ -144,9 +145,8 @@ def test_sharded_example_is_plain_c99(tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_examples_on_the_device(tmp_path):
+def test_c_examples_on_the_device(pkg, tmp_path):
     """The same two C99 programs in the GPU suite: there they must run to completion against the device."""
-    import ctypes
-    assert ctypes.CDLL(os.path.join(ROOT, "ndarray-interp_amd", "libndinterp_hip.so")).ndi_device_count() >= 1
-    test_header_is_plain_c99(tmp_path)
-    test_sharded_example_is_plain_c99(tmp_path)
+    assert pkg.device_count() >= 1
+    test_header_is_plain_c99(pkg, tmp_path)
+    test_sharded_example_is_plain_c99(pkg, tmp_path)

@@ -576,18 +576,55 @@ struct EvalSmallArgs {
 template <class T>
 __global__ __launch_bounds__(BLOCK) void range_check_kernel(const T* qx, const T* qy, uint64_t nq, T x0, T xn,
                                                             T y0, T yn, int mode, unsigned long long* first_fail) {
-  for (uint64_t qi = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; qi < nq; qi += (uint64_t)gridDim.x * BLOCK) {
-    const T x = qx[qi];
-    const bool inr = (x0 <= x) && (x <= xn);
-    T xs = x;
-    if (mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - x0, xn - x0) + x0;   // +-inf wraps to NaN, as in locate_slice
-    const bool badx = (mode == EX_NO) ? !inr : !(xs == xs);
-    if (badx) atomicMin(&first_fail[0], (unsigned long long)qi);
-    if (qy) {
-      const T y = qy[qi];
-      const bool bady = (mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
-      if (bady) atomicMin(&first_fail[1], (unsigned long long)qi);
+  // four independent loads per thread and trip: the pass is a pure read stream and needs the bytes in flight
+  constexpr int RU = 4;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t q0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; q0 < nq; q0 += step * RU) {
+    T xv[RU], yv[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const uint64_t qi = q0 + (uint64_t)u * step;
+      xv[u] = (qi < nq) ? qx[qi] : x0;
+      yv[u] = (qy && qi < nq) ? qy[qi] : y0;
     }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const uint64_t qi = q0 + (uint64_t)u * step;
+      if (qi >= nq) break;
+      const T x = xv[u];
+      const bool inr = (x0 <= x) && (x <= xn);
+      T xs = x;
+      if (mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - x0, xn - x0) + x0;   // +-inf wraps to NaN, as in locate_slice
+      const bool badx = (mode == EX_NO) ? !inr : !(xs == xs);
+      if (badx) atomicMin(&first_fail[0], (unsigned long long)qi);
+      if (qy) {
+        const T y = yv[u];
+        const bool bady = (mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
+        if (bady) atomicMin(&first_fail[1], (unsigned long long)qi);
+      }
+    }
+  }
+}
+
+// Interval-packed copy of the tables for rows shorter than a cache line: P[i] = { y[i], y[i+1], a[i], b[i] } (cubic) or
+// { y[i], y[i+1] } (linear), i < n - 1.  A query's operands are then ONE contiguous record (2 lines at 8 f64 lanes)
+// instead of three separate row pieces that each cost a whole 128-byte line fill (3.5 lines on average): the
+// query-order kernel is bound by L2 -> L1 line fills at these shapes (profiles/r04_short_rows.md).  Values are
+// copied, never recomputed.  One thread per element of the packed array.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void pack_intervals_kernel(const T* data, const T* ca, const T* cb, T* out,
+                                                               uint64_t n, uint64_t lanes, int parts) {
+  const uint64_t total = (n - 1) * (uint64_t)parts * lanes;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t l = e % lanes;
+    const uint64_t r = e / lanes;
+    const uint64_t k = r % (uint64_t)parts, i = r / (uint64_t)parts;
+    T v;
+    if (k == 0) v = data[i * lanes + l];
+    else if (k == 1) v = data[(i + 1) * lanes + l];
+    else if (k == 2) v = ca[i * lanes + l];
+    else v = cb[i * lanes + l];
+    out[e] = v;
   }
 }
 
@@ -726,6 +763,180 @@ __global__ __launch_bounds__(BLOCK) void eval_flat_kernel(Eval1Args<T> A, uint32
       V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
       o[v] = row_point<T, STRAT, V>(c, yl[v], yr[v], a, b);
     }
+  }
+}
+
+// GATHER, short rows (fewer than 256 vectors), QUERY ORDER, search fused in: the formulation for the reference's own
+// data shapes (scalar data, (100, 5), a few dozen lanes -- benches/bench_interp1d.rs:82-122).  A wave takes 64
+// consecutive queries, one per lane: search (bucket index or pyramid, knots staged in LDS) and the per-query scalars
+// (cubic_spline.rs:818 / linear.rs:33-35), parked in a wave-private LDS strip; then the wave walks the batch's
+// 64 * LV output vectors in row-major order, 64 per trip -- lane -> (query, vector) by one v_mul_hi (LV is not a
+// power of two for the reference's 5-lane rows) -- so a trip's stores cover 1 KiB of CONSECUTIVE output bytes and the
+// whole batch is one sequential write stream, with no idx[] / t[] round trip through memory (12 B written + 12-20 B
+// re-read per query by the two-kernel form: a third of the traffic at 8 f64 lanes).  UNR trips are issued together:
+// scalars, then all 4 * UNR operand loads, then arithmetic and stores.
+// TLDS: the tables themselves (data, a, b) are staged in LDS once per workgroup -- when they fit (the reference's
+// bench shapes do many times over) the operand gathers never leave the CU.
+// The first failing query of the batch is known before the launch (range_check_kernel): rows at / after it are
+// never written, as in the reference's serial loop (interp1d/mod.rs:334-342).
+template <class T>
+struct EvalFusedArgs {
+  Pyramid<T> pyr;
+  BucketIndex<T> bx;     // lut == nullptr: pyramid search
+  const T* data;
+  const T* ca;
+  const T* cb;
+  const T* q;
+  T* out;
+  uint64_t nq, out_stride;
+  uint32_t lanes;
+  uint32_t lv;           // vectors per row
+  uint32_t lv_magic;     // ceil(2^32 / lv) for lv >= 2: it / lv == mulhi(it, lv_magic) for it * lv < 2^32
+  uint32_t rec_stride;   // vectors between the operands of interval i and i + 1: lv for the plain tables; 4 * lv
+                         // (cubic) / 2 * lv (linear) for the interval-packed copy (pack_intervals_kernel), where data
+                         // / ca / cb point at the y / a / b parts of interval 0's record
+  int mode;              // ExtrapMode
+  const unsigned long long* first_fail;
+};
+
+template <class V, bool LDS>
+struct TabPtr { using type = const V*; };
+template <class V>
+struct TabPtr<V, true> { using type = const __attribute__((address_space(3))) V*; };
+
+template <class T, int STRAT, int VEC, int UNR, int TB, bool TLDS>
+__global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
+  using V = typename VecT<T, VEC>::type;
+  using tab_ptr = typename TabPtr<V, TLDS>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t WAVES = TB / 64;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = A.pyr.n, n1 = A.pyr.n1;
+  // LDS: [pyramid | lut | per-wave strips (interval, c0, c1) | tables]
+  size_t off = 0;
+  {
+    T* s0 = reinterpret_cast<T*>(smem_raw);
+    const uint32_t total = n + n1;   // the levels are one allocation
+    for (uint32_t i = tid; i < total; i += TB) s0[i] = A.pyr.lv0[i];
+    off = ((size_t)total * sizeof(T) + 15u) & ~(size_t)15u;
+  }
+  lds_u16 lut = nullptr;
+  if (A.bx.lut) {
+    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
+    const uint32_t words = (A.bx.m + 2u) / 2u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.bx.lut);
+    for (uint32_t i = tid; i < words; i += TB) sl[i] = src[i];
+    lut = (lds_u16)(smem_raw + off);
+    off += ((size_t)words * 4u + 15u) & ~(size_t)15u;
+  }
+  uint32_t* w_i = reinterpret_cast<uint32_t*>(smem_raw + off) + (tid >> 6) * 64u;
+  off += (size_t)WAVES * 64u * sizeof(uint32_t);
+  T* w_c0 = reinterpret_cast<T*>(smem_raw + off) + (tid >> 6) * 64u;
+  off += (size_t)WAVES * 64u * sizeof(T);
+  T* w_c1 = reinterpret_cast<T*>(smem_raw + off) + (tid >> 6) * 64u;
+  off += (size_t)WAVES * 64u * sizeof(T);
+  const uint32_t LV = A.lv;
+  const uint32_t RS = TLDS ? LV : A.rec_stride;
+  tab_ptr t_y, t_a, t_b;
+  if constexpr (TLDS) {
+    V* sy = reinterpret_cast<V*>(smem_raw + off);
+    const uint32_t ny = n * LV, nab = (STRAT == ST_CUBIC) ? (n - 1u) * LV : 0u;
+    V* sa = sy + ny;
+    V* sb = sa + nab;
+    const V* gy = reinterpret_cast<const V*>(A.data);
+    const V* ga = reinterpret_cast<const V*>(A.ca);
+    const V* gb = reinterpret_cast<const V*>(A.cb);
+    for (uint32_t i = tid; i < ny; i += TB) sy[i] = gy[i];
+    for (uint32_t i = tid; i < nab; i += TB) sa[i] = ga[i];
+    for (uint32_t i = tid; i < nab; i += TB) sb[i] = gb[i];
+    t_y = (tab_ptr)(smem_raw + off);
+    t_a = t_y + ny;
+    t_b = t_a + nab;
+  } else {
+    t_y = reinterpret_cast<const V*>(A.data);
+    t_a = reinterpret_cast<const V*>(A.ca);
+    t_b = reinterpret_cast<const V*>(A.cb);
+  }
+  __syncthreads();
+  PyramidLds<T> P;
+  P.lv0 = (lds_ptr<T>)(smem_raw);
+  P.lv1 = P.lv0 + n;
+  P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
+  const T k0 = P.lv0[0], kn = P.lv0[n - 1];
+  const uint32_t lane = tid & 63u;
+  unsigned long long limit = *A.first_fail;
+  if (limit > A.nq) limit = A.nq;
+  const uint64_t wave_step = (uint64_t)gridDim.x * TB;
+  uint64_t base = ((uint64_t)blockIdx.x * WAVES + (tid >> 6)) * 64u;
+  T x_next = (base + lane < limit) ? A.q[base + lane] : k0;
+  for (; base < limit; base += wave_step) {
+    const T x = x_next;
+    x_next = (base + wave_step + lane < limit) ? A.q[base + wave_step + lane] : k0;   // next batch, requested early
+    const bool inr = (k0 <= x) && (x <= kn);
+    T xs = x;
+    if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;   // cubic_spline.rs:805-809
+    // (queries at / after the first failing one never get here; an inactive lane searches k0)
+    const uint32_t i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs)
+                           : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);   // all 64 lanes take part
+    const T xl = P.lv0[i], xr = P.lv0[i + 1];
+    w_i[lane] = i;
+    if (STRAT == ST_CUBIC) {
+      w_c0[lane] = (xs - xl) / (xr - xl);   // t, cubic_spline.rs:818
+    } else {
+      w_c0[lane] = xr - xl;                 // linear.rs:33-35: (x2 - x1), (x - x1)
+      w_c1[lane] = x - xl;
+    }
+    __builtin_amdgcn_wave_barrier();        // LDS operations of one wave execute in order: no s_barrier needed
+    const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
+    const uint32_t items = nq_here * LV;
+    T* const o_base = A.out + base * A.out_stride;
+    for (uint32_t it0 = lane; it0 < items; it0 += 64u * UNR) {
+      bool live[UNR];
+      uint32_t ql[UNR], v[UNR], ii[UNR];
+      T s0[UNR], s1[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {        // phase 1: (query, vector) of the item and the query's scalars
+        const uint32_t it = it0 + (uint32_t)k * 64u;
+        live[k] = it < items;
+        const uint32_t itc = live[k] ? it : 0u;
+        ql[k] = (LV == 1u) ? itc : __umulhi(itc, A.lv_magic);
+        v[k] = itc - ql[k] * LV;
+        ii[k] = w_i[ql[k]];
+        s0[k] = w_c0[ql[k]];
+        s1[k] = (STRAT == ST_LINEAR) ? w_c1[ql[k]] : T(0);
+      }
+      V yl[UNR], yr[UNR], a[UNR], b[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {        // phase 2: the four operand vectors
+        const uint32_t e = ii[k] * RS + v[k];
+        yl[k] = t_y[e];
+        yr[k] = t_y[e + LV];
+        if (STRAT == ST_CUBIC) {
+          a[k] = t_a[e];
+          b[k] = t_b[e];
+        } else {
+          a[k] = V(0);
+          b[k] = V(0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {        // phase 3: polynomial and store
+        RowCoef<T, STRAT> c;
+        if (STRAT == ST_CUBIC) {
+          const T one = T(1);
+          c.c0 = one - s0[k];
+          c.c1 = s0[k];
+          c.c2 = s0[k] * (one - s0[k]);
+        } else {
+          c.c0 = s0[k];
+          c.c1 = s1[k];
+          c.c2 = T(0);
+        }
+        V* o = reinterpret_cast<V*>(o_base + (uint64_t)ql[k] * A.out_stride) + v[k];
+        if (live[k]) store_stream<true>(o, row_point<T, STRAT, V>(c, yl[k], yr[k], a[k], b[k]));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();        // the strip is rewritten by the next batch
   }
 }
 
@@ -926,6 +1137,71 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
           }
         }
       }
+    }
+  }
+}
+
+// BUCKETED for rows shorter than one workgroup pass (fewer than 256 vectors): the workgroup is split into NG = 256 / G
+// groups of G threads (G = power of two >= vectors per row; lanes beyond the row idle), each group streams its own
+// run of CQ consecutive grouped records and keeps the interval's four operand vectors in registers -- one vector per
+// thread and table -- while the interval does not change.  The grouped records of a workgroup pass (NG * CQ of them)
+// are staged in LDS with one coalesced load.  As in eval_bucketed_kernel the table traffic all but disappears and the
+// kernel is a stream of whole output rows written at their original positions; it pays from rows of a few hundred
+// bytes upwards (shorter rows are partial-line scattered writes: the query-order kernel above is the one for them).
+template <class T, int STRAT, int G, int CQ, bool NT = true>
+__global__ __launch_bounds__(BLOCK) void eval_bucketed_short_kernel(Eval1Args<T> A) {
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  constexpr uint32_t NG = BLOCK / G;
+  constexpr uint32_t WQ = NG * CQ;
+  __shared__ uint32_t s_q[WQ];
+  __shared__ uint32_t s_i[WQ];
+  __shared__ T s_s[WQ];  // cubic: t          linear: raw x
+  const uint32_t LV = (uint32_t)(A.lanes / VN);
+  const uint32_t g = threadIdx.x / G, v = threadIdx.x % G;
+  const bool vlive = v < LV;
+  const unsigned long long n_valid = A.nq;             // every query is grouped ...
+  unsigned long long limit = A.status->first_fail[0];  // ... and rows at or after the first failure are skipped
+  if (limit > A.nq) limit = A.nq;
+  const uint64_t nchunks = (n_valid + WQ - 1) / WQ;
+  const uint64_t per = (nchunks + 7) / 8;              // XCD-aware chunk order as in eval_bucketed_kernel
+  V ryl = V(0), ryr = V(0), ra = V(0), rb = V(0);
+  uint32_t cur = 0xffffffffu;
+  for (uint64_t vb = blockIdx.x; vb < per * 8; vb += gridDim.x) {
+    const uint64_t chunk = (vb & 7u) * per + (vb >> 3);
+    if (chunk >= nchunks) continue;                    // (workgroup-uniform)
+    const uint64_t p0 = chunk * WQ;
+    const uint32_t cnt = (n_valid - p0 < (uint64_t)WQ) ? (uint32_t)(n_valid - p0) : WQ;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) {
+      const uint4 r = A.rec[p0 + j];
+      s_q[j] = r.x;
+      s_i[j] = r.y;
+      s_s[j] = rec_value(r, T(0));
+    }
+    __syncthreads();
+    const uint32_t j0 = g * CQ;
+    const uint32_t j1 = (j0 + CQ < cnt) ? j0 + CQ : cnt;
+    for (uint32_t j = j0; j < j1; ++j) {
+      const uint32_t i = s_i[j];
+      const uint32_t qi = s_q[j];
+      if (qi >= limit) continue;
+      const T sj = s_s[j];
+      if (i != cur) {
+        cur = i;
+        if (vlive) {
+          const V* yl = reinterpret_cast<const V*>(A.data + (uint64_t)i * A.lanes);
+          ryl = yl[v];
+          ryr = yl[LV + v];
+          if (STRAT == ST_CUBIC) {
+            ra = reinterpret_cast<const V*>(A.ca + (uint64_t)i * A.lanes)[v];
+            rb = reinterpret_cast<const V*>(A.cb + (uint64_t)i * A.lanes)[v];
+          }
+        }
+      }
+      const RowCoef<T, STRAT> c = row_coef<T, STRAT>(A.knots, i, sj, sj);
+      V* o = reinterpret_cast<V*>(A.out + (uint64_t)qi * A.out_stride);
+      if (vlive) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl, ryr, ra, rb));
     }
   }
 }

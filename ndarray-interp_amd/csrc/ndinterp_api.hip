@@ -288,6 +288,7 @@ struct DevicePyramid {
 
 constexpr uint64_t MAX_KNOTS = (1ull << 31) - 1;          // interval indices are 32-bit
 constexpr size_t LDS_STAGE_LIMIT = 150 * 1024;          // of the CU's 160 KiB
+constexpr size_t FUSED_LDS_LIMIT = 160 * 1024;          // eval_fused_kernel with the tables in LDS: all of it
 
 // ---------------------------------------------------------------------------------------------
 // workspace: per (handle, stream) scratch, reused across stream-ordered evaluations
@@ -547,6 +548,43 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Tuning knobs of the short-row 1-D kernels (tools/short_rows_sweep.py).  Read once -- unless NDI_TUNE_LIVE is set
+// when the library is loaded, in which case every evaluation re-reads them (one process then sweeps the variants).
+//   NDI_SHORT_MODE   0 = auto, 1 = the two-kernel flat form (locate, then eval_flat_kernel), 2 = fused query order,
+//                    3 = grouped (eval_bucketed_short_kernel)
+//   NDI_FUSED_UNR    trips issued together by eval_fused_kernel (1 / 2 / 4)
+//   NDI_FUSED_TB     its workgroup size (256 / 512 / 1024; 0 = chosen from the LDS footprint)
+//   NDI_FUSED_LDS    tables in LDS: -1 = when they fit, 0 = never, 1 = whenever they fit (same as -1; kept for A/B)
+//   NDI_FUSED_WGS    workgroups per CU of its grid (0 = default)
+//   NDI_SHORT_CQ     grouped records per thread group and pass (16 / 64)
+//   NDI_SHORT_ROWB   auto: the grouped form is taken from rows of this many bytes upwards
+//   NDI_FUSED_PACK   interval-packed table copy for the fused kernel: -1 = rows shorter than a cache line,
+//                    0 = never, 1 = always
+struct ShortKnobs {
+  int mode = 0, unr = 2, tb = 0, lds = -1, wgs = 0, cq = 64, rowb = 1024, pack = -1;
+  static int env(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e && *e ? std::atoi(e) : dflt;
+  }
+  static ShortKnobs read() {
+    ShortKnobs k;
+    k.mode = env("NDI_SHORT_MODE", k.mode);
+    k.unr = env("NDI_FUSED_UNR", k.unr);
+    k.tb = env("NDI_FUSED_TB", k.tb);
+    k.lds = env("NDI_FUSED_LDS", k.lds);
+    k.wgs = env("NDI_FUSED_WGS", k.wgs);
+    k.cq = env("NDI_SHORT_CQ", k.cq);
+    k.rowb = env("NDI_SHORT_ROWB", k.rowb);
+    k.pack = env("NDI_FUSED_PACK", k.pack);
+    return k;
+  }
+};
+static ShortKnobs short_knobs() {
+  static const bool live = std::getenv("NDI_TUNE_LIVE") != nullptr;
+  static const ShortKnobs once = ShortKnobs::read();
+  return live ? ShortKnobs::read() : once;
+}
+
 // Measurement knob (profiles/r03_ring_overlap.md): NDI_RING_OVERLAP=0 runs the ring's locate + group on the
 // evaluation stream instead of the side stream.  Read once.
 static bool ring_overlap() {
@@ -596,6 +634,28 @@ struct Interp1DImpl final : Interp1DBase {
   DevBuf data, ca, cb;
   SpaceSet spaces;
   OwnedRing ring_own;
+  // interval-packed copy of the tables for rows shorter than a cache line (pack_intervals_kernel), built on first
+  // use by a batch that takes the query-order kernel; a replica builds its own
+  DevBuf packed;
+  std::once_flag packed_once;
+  bool packed_ok = false;
+  static constexpr size_t PACKED_LIMIT = 1ull << 30;
+  bool ensure_packed() {
+    std::call_once(packed_once, [this] {
+      const int parts = strategy == NDI_CUBIC_SPLINE ? 4 : 2;
+      const size_t bytes = (size_t)(n - 1) * parts * lanes * sizeof(T);
+      if (bytes == 0 || bytes > PACKED_LIMIT) return;
+      packed.reserve(bytes);
+      const uint64_t total = (n - 1) * (uint64_t)parts * lanes;
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((total + BLOCK - 1) / BLOCK, 65536));
+      hipLaunchKernelGGL(pack_intervals_kernel<T>, dim3(g), dim3(BLOCK), 0, (hipStream_t) nullptr, (const T*)data.as<T>(),
+                         (const T*)ca.as<T>(), (const T*)cb.as<T>(), packed.as<T>(), n, lanes, parts);
+      NDI_HIP(hipGetLastError());
+      NDI_HIP(hipDeviceSynchronize());   // once per handle; later launches may be on any stream
+      packed_ok = true;
+    });
+    return packed_ok;
+  }
 
   // ---- build (CubicSpline::build, cubic_spline.rs:754-771) --------------------------------
   ndi_status build_spline(const ndi_interp1d_desc& d) {
@@ -764,21 +824,91 @@ struct Interp1DImpl final : Interp1DBase {
   // A batch is evaluated in two stages that may run on different streams: prep() = search (+ grouping) into a
   // scratch set, launch_eval() = the evaluation kernel reading that set.  Plan1 carries what prep() decided.
   struct Plan1 {
-    enum Kind { SMALL, BUCKETED, ROWS, FLAT } kind = ROWS;
+    enum Kind { SMALL, BUCKETED, ROWS, FLAT, FUSED, BUCKETED_SHORT } kind = ROWS;
     const T* q = nullptr;
     uint64_t nq = 0;
     T* out = nullptr;
     uint64_t out_stride = 0;
     bool vec_ok = false;
     uint64_t LV = 0;
+    // FUSED (eval_fused_kernel)
+    bool f_lut = false, f_tlds = false, f_pack = false;
+    unsigned f_tb = 256, f_grid = 1;
+    int f_unr = 2;
+    size_t f_lds = 0;
+    int s_cq = 64;   // BUCKETED_SHORT
   };
+
+  // LDS footprint of eval_fused_kernel: [pyramid | lut | per-wave strips | tables]
+  size_t fused_lds_bytes(bool with_lut, unsigned tb, bool tables) const {
+    size_t b = (pyr.lds_bytes + 15) & ~(size_t)15;
+    if (with_lut) b += pyr.lut_bytes;
+    b += (size_t)(tb / 64) * 64 * (sizeof(uint32_t) + 2 * sizeof(T));
+    if (tables) {
+      const size_t rows = strategy == NDI_CUBIC_SPLINE ? 3 * n - 2 : n;
+      b += rows * lanes * sizeof(T);
+    }
+    return b;
+  }
+
+  // Query-order fused search + evaluation (short rows): decides the variant and its launch shape, and enqueues the
+  // range pre-pass the kernel relies on.  Returns false when the shape is not eligible.
+  bool plan_fused(hipStream_t s, Scratch& sc, Plan1& P, const ShortKnobs& K) {
+    if (pyr.lds_bytes > LDS_STAGE_LIMIT / 2) return false;
+    const uint64_t LV = P.LV;
+    if (LV == 0 || 64ull * LV * LV >= (1ull << 32) || (uint64_t)n * LV >= (1ull << 32)) return false;   // 32-bit item / vector indices
+    static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+    if (lut_env && P.nq >= 4096) pyr.ensure_bucket_index();
+    P.f_lut = lut_env && P.nq >= 4096 && pyr.lut_bytes != 0 &&
+              fused_lds_bytes(true, 256, false) <= LDS_STAGE_LIMIT / 2;
+    P.f_unr = (K.unr == 1 || K.unr == 4) ? K.unr : 2;
+    // Tables in LDS when they fit beside everything else, and when the batch gives every workgroup several times the
+    // table size to write (the staging pass is per workgroup).  Workgroup size: the one that keeps most waves on a
+    // CU beside the tables; among equals the largest (fewest staging passes).
+    P.f_tlds = false;
+    P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : 256u;
+    if (K.lds != 0) {
+      size_t best_waves = 0;
+      for (unsigned tb : {1024u, 512u, 256u}) {
+        if (K.tb && (unsigned)K.tb != tb) continue;
+        const size_t need = fused_lds_bytes(P.f_lut, tb, true);
+        if (need > FUSED_LDS_LIMIT) continue;
+        const size_t waves = std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
+        if (waves > best_waves) {
+          best_waves = waves;
+          P.f_tlds = true;
+          P.f_tb = tb;
+        }
+      }
+      const size_t tab = fused_lds_bytes(false, 64, true);
+      if (P.f_tlds && K.lds < 0 && P.nq * lanes * sizeof(T) < 8 * (size_t)cu_count() * tab) {
+        P.f_tlds = false;
+        P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : 256u;
+      }
+    }
+    P.f_lds = fused_lds_bytes(P.f_lut, P.f_tb, P.f_tlds);
+    // rows shorter than a cache line read from L2: one contiguous record per interval instead of three row pieces
+    P.f_pack = !P.f_tlds && (K.pack > 0 || (K.pack < 0 && lanes * sizeof(T) < 128)) && ensure_packed();
+    const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(P.f_lds, 1), 32 / (P.f_tb / 64)));
+    const uint64_t want = (uint64_t)cu_count() * (K.wgs > 0 ? (size_t)K.wgs : wg_per_cu * (P.f_tlds ? 1 : 4));
+    P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + P.f_tb - 1) / P.f_tb, want));
+    P.kind = Plan1::FUSED;
+    g_last_path.store(NDI_PATH_GATHER);
+    StatusBlock* st = sc.status.as<StatusBlock>();
+    const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
+    const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + BLOCK - 1) / BLOCK, 4096));
+    ProfScope ps(s, PC_LOCATE);
+    hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, P.q, (const T*)nullptr, P.nq, k0, kn, k0, kn,
+                       mode, &st->first_fail[0]);
+    NDI_HIP(hipGetLastError());
+    ps.done();
+    return true;
+  }
 
   Plan1 prep(hipStream_t s, Scratch& sc, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path,
              bool beside_eval = false) {
     Plan1 P;
     P.q = q; P.nq = nq; P.out = out; P.out_stride = out_stride;
-    sc.idx.reserve(nq * sizeof(uint32_t));
-    if (strategy == NDI_CUBIC_SPLINE) sc.t.reserve(nq * sizeof(T));
     sc.status.reserve(sizeof(StatusBlock));
     reset_status(sc.status.p, s);
     StatusBlock* st = sc.status.as<StatusBlock>();
@@ -801,14 +931,29 @@ struct Interp1DImpl final : Interp1DBase {
     P.vec_ok = (lanes % VN == 0) && (out_stride % VN == 0) && aligned16(out);
     P.LV = P.vec_ok ? lanes / VN : lanes;
     const bool rows_ok = P.vec_ok && P.LV >= (uint64_t)BLOCK;
-    bool bucketed = false;
-    if (path == NDI_PATH_BUCKETED) bucketed = rows_ok && nq < 0xffffffffull;
-    else if (path == NDI_PATH_AUTO) bucketed = rows_ok && nq < 0xffffffffull && nq >= 5 * (n - 1);  // measured crossover (tools/auto_threshold.py)
-    g_last_path.store(bucketed ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
+    const ShortKnobs K = short_knobs();
+    // rows shorter than one workgroup pass (or unaligned): grouped from a few hundred bytes per row upwards when the
+    // batch has enough queries per interval, else query order with the search fused in
+    const bool short_rows = !rows_ok;
+    const bool group_ok = nq < 0xffffffffull && P.vec_ok && lds_sort_fits(pyr, n - 1);
+    bool bucketed = false, grouped_short = false;
+    if (path == NDI_PATH_BUCKETED) {
+      bucketed = rows_ok && nq < 0xffffffffull;
+      grouped_short = short_rows && group_ok && K.mode != 1 && K.mode != 2;
+    } else if (path == NDI_PATH_AUTO) {
+      bucketed = rows_ok && nq < 0xffffffffull && nq >= 5 * (n - 1);  // measured crossover (tools/auto_threshold.py)
+      grouped_short = short_rows && group_ok && nq >= 5 * (n - 1) &&
+                      (K.mode == 3 || (K.mode == 0 && lanes * sizeof(T) >= (uint64_t)K.rowb));
+    }
+    if (short_rows && !grouped_short && K.mode != 1 && K.mode != 3 && plan_fused(s, sc, P, K)) return P;
+    g_last_path.store(bucketed || grouped_short ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
+    sc.idx.reserve(nq * sizeof(uint32_t));   // the two-kernel forms: interval index (and t) per query
+    if (strategy == NDI_CUBIC_SPLINE) sc.t.reserve(nq * sizeof(T));
     T* t_out = strategy == NDI_CUBIC_SPLINE ? sc.t.as<T>() : nullptr;
 
-    if (bucketed) {
-      P.kind = Plan1::BUCKETED;
+    if (bucketed || grouped_short) {
+      P.kind = bucketed ? Plan1::BUCKETED : Plan1::BUCKETED_SHORT;
+      P.s_cq = K.cq;
       const uint32_t nb = (uint32_t)(n - 1);
       sc.counts.reserve((size_t)nb * sizeof(uint32_t));
       sc.cursor.reserve((size_t)nb * sizeof(uint32_t));
@@ -880,6 +1025,10 @@ struct Interp1DImpl final : Interp1DBase {
       else launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), shmem, eval_small_kernel<T, ST_LINEAR>, S);
       return;
     }
+    if (P.kind == Plan1::FUSED) {
+      launch_fused(s, sc, P);
+      return;
+    }
     Eval1Args<T> A{};
     A.knots = pyr.view.lv0;
     A.data = data.as<T>();
@@ -928,6 +1077,30 @@ struct Interp1DImpl final : Interp1DBase {
 #undef NDI_BK
       return;
     }
+    if (P.kind == Plan1::BUCKETED_SHORT) {
+      A.rec = sc.perm.as<uint4>();
+      uint32_t G = 8;
+      while (G < LV) G *= 2;   // threads per row: power of two >= vectors per row (LV < 256)
+      const int CQ = P.s_cq == 16 ? 16 : 64;
+      const uint64_t wq = (uint64_t)(BLOCK / G) * CQ;
+      const uint64_t per_xcd = ((nq + wq - 1) / wq + 7) / 8;
+      const unsigned gx = (unsigned)std::max<uint64_t>(8, std::min<uint64_t>(per_xcd * 8, 65528));
+#define NDI_BS(ST, GG)                                                                                          \
+  do {                                                                                                          \
+    if (CQ == 16) launch1<T>(s, PC_EVAL, dim3(gx), dim3(BLOCK), 0, eval_bucketed_short_kernel<T, ST, GG, 16>, A); \
+    else launch1<T>(s, PC_EVAL, dim3(gx), dim3(BLOCK), 0, eval_bucketed_short_kernel<T, ST, GG, 64>, A);          \
+  } while (0)
+#define NDI_BSG(ST)                                                                   \
+  do {                                                                                \
+    if (G == 8) NDI_BS(ST, 8); else if (G == 16) NDI_BS(ST, 16);                      \
+    else if (G == 32) NDI_BS(ST, 32); else if (G == 64) NDI_BS(ST, 64);               \
+    else if (G == 128) NDI_BS(ST, 128); else NDI_BS(ST, 256);                         \
+  } while (0)
+      if (strategy == NDI_CUBIC_SPLINE) NDI_BSG(ST_CUBIC); else NDI_BSG(ST_LINEAR);
+#undef NDI_BSG
+#undef NDI_BS
+      return;
+    }
     if (P.kind == Plan1::ROWS) {
       // one 256-vector segment per workgroup pass and many workgroups: measured best on MI355X
       const uint64_t segs = (LV + BLOCK - 1) / BLOCK;
@@ -951,6 +1124,65 @@ struct Interp1DImpl final : Interp1DBase {
     }
     NDI_HIP(hipGetLastError());
     ps.done();
+  }
+
+  void launch_fused(hipStream_t s, Scratch& sc, const Plan1& P) {
+    EvalFusedArgs<T> F{};
+    F.pyr = pyr.view;
+    F.bx = P.f_lut ? pyr.bidx : BucketIndex<T>{nullptr, 0, T(0)};
+    F.data = data.as<T>();
+    F.ca = ca.as<T>();
+    F.cb = cb.as<T>();
+    F.rec_stride = (uint32_t)P.LV;
+    if (P.f_pack) {   // {y[i], y[i+1], a[i], b[i]} per interval
+      F.data = packed.as<T>();
+      F.ca = packed.as<T>() + 2 * lanes;
+      F.cb = packed.as<T>() + 3 * lanes;
+      F.rec_stride = (uint32_t)P.LV * (strategy == NDI_CUBIC_SPLINE ? 4u : 2u);
+    }
+    F.q = P.q;
+    F.out = P.out;
+    F.nq = P.nq;
+    F.out_stride = P.out_stride;
+    F.lanes = (uint32_t)lanes;
+    F.lv = (uint32_t)P.LV;
+    F.lv_magic = F.lv >= 2 ? (uint32_t)(((1ull << 32) + F.lv - 1) / F.lv) : 0u;
+    F.mode = mode;
+    F.first_fail = &sc.status.as<StatusBlock>()->first_fail[0];
+    constexpr int VN = Wide<T>::N;
+    const dim3 grid(P.f_grid), block(P.f_tb);
+#define NDI_FU(ST, VEC, UNR, TB, TL)                                                                   \
+  do {                                                                                                 \
+    auto kern = eval_fused_kernel<T, ST, VEC, UNR, TB, TL>;                                            \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);                      \
+    launch1<T>(s, PC_EVAL, grid, block, P.f_lds, kern, F);                                             \
+  } while (0)
+#define NDI_FU_TB(ST, VEC, UNR, TL)                                      \
+  do {                                                                   \
+    if (P.f_tb == 1024) NDI_FU(ST, VEC, UNR, 1024, TL);                  \
+    else if (P.f_tb == 512) NDI_FU(ST, VEC, UNR, 512, TL);               \
+    else NDI_FU(ST, VEC, UNR, 256, TL);                                  \
+  } while (0)
+#define NDI_FU_UNR(ST, VEC, TL)                                          \
+  do {                                                                   \
+    if (P.f_unr == 4) NDI_FU_TB(ST, VEC, 4, TL);                         \
+    else if (P.f_unr == 1) NDI_FU_TB(ST, VEC, 1, TL);                    \
+    else NDI_FU_TB(ST, VEC, 2, TL);                                      \
+  } while (0)
+#define NDI_FU_ST(VEC, TL)                                                              \
+  do {                                                                                  \
+    if (strategy == NDI_CUBIC_SPLINE) NDI_FU_UNR(ST_CUBIC, VEC, TL);                    \
+    else NDI_FU_UNR(ST_LINEAR, VEC, TL);                                                \
+  } while (0)
+    if (P.vec_ok) {
+      if (P.f_tlds) NDI_FU_ST(VN, true); else NDI_FU_ST(VN, false);
+    } else {
+      if (P.f_tlds) NDI_FU_ST(1, true); else NDI_FU_ST(1, false);
+    }
+#undef NDI_FU_ST
+#undef NDI_FU_UNR
+#undef NDI_FU_TB
+#undef NDI_FU
   }
 
   void enqueue(hipStream_t s, Workspace& ws, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path) {

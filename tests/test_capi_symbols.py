@@ -27,11 +27,22 @@ def test_header_symbols_are_exported(pkg):
     assert sorted(pkg._capi.SYMBOLS) == names
 
 
-def test_integration_md_binds_every_export():
-    """INTEGRATION.md's Rust `extern "C"` block declares every symbol of the header (and nothing else)."""
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    rust = sorted(set(re.findall(r"pub fn (ndi_[a-z0-9_]+)\(", text)))
+def test_rust_shim_binds_every_export():
+    """rust/ndarray-interp-hip/src/hip_ffi.rs declares every symbol of the header (and nothing else); the types are
+    compared in tests/test_rust_ffi_abi.py.  INTEGRATION.md quotes the files of the shim: they must exist."""
+    text = open(os.path.join(ROOT, "rust", "ndarray-interp-hip", "src", "hip_ffi.rs")).read()
+    rust = sorted(set(re.findall(r"pub fn (ndi_[a-z0-9_]+)\s*\(", text)))
     assert rust == _declared_symbols()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for rel in ("rust/ndarray-interp-hip/build.rs", "rust/patches/ndarray-interp-0.6.0-batched-hook.patch"):
+        assert rel in doc and os.path.exists(os.path.join(ROOT, rel)), rel
+    for f in ("lib", "hip_ffi", "strategies", "ring", "sharded"):
+        assert os.path.exists(os.path.join(ROOT, "rust", "ndarray-interp-hip", "src", f + ".rs")), f
+    patch = open(os.path.join(ROOT, "rust", "patches", "ndarray-interp-0.6.0-batched-hook.patch")).read()
+    for target in ("src/interp1d/strategies/mod.rs", "src/interp2d/strategies/mod.rs", "src/interp1d/mod.rs",
+                   "src/interp2d/mod.rs"):
+        assert "+++ b/" + target in patch, target
+    assert patch.count("+    fn interp_array_into<") == 2   # one defaulted method per finished-strategy trait
 
 
 def test_version_and_error_string(pkg):

@@ -301,26 +301,62 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
     step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
     alg = nq * C * 20 + nq * 8                                   # 5 x 4 B per point + the query pair
 
+    import ctypes
+    cap = pkg._capi
+
     def measure(path):
         interp.strategy.path = path
         for _ in range(warmup):
             step()
         interp.strategy.finish()
+        # (a) per-stage kernel times: the library's HIP events (two event records per stage on the launch stream)
         pkg.profile_enable(True); pkg.profile_read(reset=True)
+        for _ in range(steps):
+            step()
+        interp.strategy.finish()
+        prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
+        kms = prof["eval_ms"] / max(1, prof["eval_launches"])
+        tiled = prof["last_path"] == "bucketed"
+        # (b) end to end, event recording off, through the bare C ABI (what a compiled host pays per call) -- `steps`
+        # stream-ordered async calls, one synchronisation.  host_ms_per_call is the time the host spends INSIDE the
+        # call: when it stays below the GPU's time per step the stream never runs dry and a step costs what its
+        # kernels cost.
+        opts = cap.EvalOpts(); info = cap.OobInfo()
+        opts.q_memspace = cap.MEM_DEVICE; opts.out_memspace = cap.MEM_DEVICE; opts.path = path; opts.async_launch = 1
+        opts.stream = torch.cuda.current_stream(dev).cuda_stream   # the stream the mirror (and finish()) uses
+        fn, h = cap.lib().ndi_interp2d_eval, interp.strategy._h
+        cargs = (h, qx.data_ptr(), qy.data_ptr(), nq, out.data_ptr(), C, ctypes.byref(opts), ctypes.byref(info))
+        for _ in range(warmup):
+            assert fn(*cargs) == 0
+        interp.strategy.finish()
+        torch.cuda.synchronize()
+        host = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h0 = time.perf_counter()
+            assert fn(*cargs) == 0
+            host += time.perf_counter() - h0
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        interp.strategy.finish()
+        # (c) the same loop through the Python mirror (ctypes marshalling + the mirror's argument handling per call)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        torch.cuda.synchronize()
+        el_py = time.perf_counter() - t0
         interp.strategy.finish()
-        el = time.perf_counter() - t0
-        prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
-        kms = prof["eval_ms"] / max(1, prof["eval_launches"])
-        tiled = prof["last_path"] == "bucketed"
+        gpu_ms = kms + prof["locate_ms"] / max(1, prof["locate_launches"]) + prof["group_ms"] / steps
         r = {"path": "tile-grouped" if tiled else "gather",
              "kernel": "eval_bilinear_tiles_kernel" if tiled else "eval_bilinear_kernel", "kernel_ms": round(kms, 4),
              "locate_ms": round(prof["locate_ms"] / max(1, prof["locate_launches"]), 4),
              "group_ms": round(prof["group_ms"] / steps, 4),
-             "ms_per_step": round(el / steps * 1e3, 4), "Mpoints_s": round(nq * C * steps / el / 1e6, 1)}
+             "ms_per_step": round(el / steps * 1e3, 4), "Mpoints_s": round(nq * C * steps / el / 1e6, 1),
+             "timed_through": "bare C ABI (ndi_interp2d_eval, async_launch), event recording off",
+             "host_ms_per_call": round(host / steps * 1e3, 4),
+             "step_minus_kernels_ms": round(el / steps * 1e3 - gpu_ms, 4),
+             "python_mirror_ms_per_step": round(el_py / steps * 1e3, 4)}
         if tiled:   # every grid value once + output + records: the bytes this formulation has to move
             comp = nx * nx * C * 4 + nq * C * 4 + nq * 16
             r["compulsory_bytes_per_launch"] = comp
@@ -345,7 +381,53 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
     return res
 
 
-def in_process_sharded_leg(args, pkg, torch, x, y, steps=3):
+def short_rows_leg(pkg, torch, dev, out_bytes=4e9, steps=5):
+    """1-D CubicSpline on rows shorter than one workgroup pass (the reference's own data shapes are of this kind:
+    scalar data, (100, 5) -- benches/bench_interp1d.rs:82-122): 1024 random knots, 4 GB of device-resident output per
+    call, the formulation AUTO picks (query order with the search fused in / grouped by interval), HIP-event stage
+    times, output TB/s, and the long-row bucketed kernel (32 KiB rows) on the SAME buffer as the yardstick."""
+    rng = np.random.default_rng(0)
+    res = {"what": "1D CubicSpline, 1024 random knots, 4 GB of output per call, device buffers; out_TBps = output bytes / "
+                   "wall time of a whole interp_array_into call (search [+ grouping] + evaluation)", "shapes": []}
+    for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        el = np.dtype(dt).itemsize
+        x = np.unique(rng.uniform(0, 1, 2048).astype(dt))[:1024]
+        xd = torch.as_tensor(x, device=dev)
+        buf = torch.empty(int(out_bytes) // el, dtype=tdt, device=dev)
+        for L in (32768 // el, 8, 32, 64, 128, 256):
+            Q = int(out_bytes // (L * el))
+            yd = torch.rand((xd.numel(), L), dtype=tdt, device=dev)
+            interp = pkg.Interp1DBuilder.new(yd).x(xd).strategy(pkg.CubicSpline.new()).build()
+            qd = (torch.rand(Q, dtype=tdt, device=dev) * (xd[-1] - xd[0]) * 0.999 + xd[0]).clamp(xd[0], xd[-1])
+            out = buf[: Q * L].view(Q, L)
+            call = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
+            call(); interp.strategy.finish()
+            pkg.profile_enable(True); pkg.profile_read(reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                call()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / steps
+            interp.strategy.finish()
+            prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
+            res["shapes"].append({"dtype": np.dtype(dt).name, "lanes": L, "queries": Q, "path": prof["last_path"],
+                                  "ms": round(wall * 1e3, 4), "out_TBps": round(Q * L * el / wall / 1e12, 3),
+                                  "Gpoints_s": round(Q * L / wall / 1e9, 1),
+                                  "eval_ms": round(prof["eval_ms"] / steps, 4),
+                                  "locate_ms": round(prof["locate_ms"] / steps, 4),
+                                  "group_ms": round(prof["group_ms"] / steps, 4)})
+            interp.strategy.release()
+            del interp, qd, yd, out
+        del buf
+        torch.cuda.empty_cache()
+    for r in res["shapes"]:
+        ref = next(s for s in res["shapes"] if s["dtype"] == r["dtype"] and s["lanes"] * np.dtype(r["dtype"]).itemsize == 32768)
+        r["frac_of_long_row_rate"] = round(r["out_TBps"] / ref["out_TBps"], 3)
+    return res
+
+
+def in_process_sharded_leg(args, pkg, torch, x, y, steps=3, budget_s=90.0):
     """When this ONE process sees several devices (the N = 1 run on a multi-GPU node): the Target batch per device
     through ndi_interp1d_eval_ring_sharded -- replicas by device-to-device copy, one library call per step, one host
     thread per device inside the library, no collective.  Reported after the timed region; never part of `value`."""
@@ -354,6 +436,7 @@ def in_process_sharded_leg(args, pkg, torch, x, y, steps=3):
     ndev = len(devs)
     if ndev < 2:
         return None
+    t_leg = time.perf_counter()      # wall-clock guard: the whole leg (replicas, rings, steps) stays inside budget_s
     try:
         nq, chunk, lanes = args.queries, args.chunk, args.lanes
         # every device must have room for its share of rings and tables -- a device someone else is using is left alone
@@ -372,17 +455,31 @@ def in_process_sharded_leg(args, pkg, torch, x, y, steps=3):
 
         def step():
             pkg.sharding.interp_array_ring_sharded(reps, blocks, chunk_queries=chunk, consumer=None, n_slots=args.ring_slots)
-        step()
-        for d in set(devs):
-            torch.cuda.synchronize(d)
+        setup_s = time.perf_counter() - t_leg
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        step()                        # first step: allocates the library-owned rings and the per-shard scratch
         for d in set(devs):
             torch.cuda.synchronize(d)
-        el = (time.perf_counter() - t0) / steps
-        res = {"devices": devs, "queries_per_device": nq, "ms_per_step": round(el * 1e3, 3),
+        first_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        step()                        # second step: warm
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+        warm_s = time.perf_counter() - t0
+        left = budget_s - (time.perf_counter() - t_leg)
+        n_timed = max(0, min(steps, int(left / max(warm_s, 1e-3)) - 1))
+        el, note = warm_s, "the one warm step (wall-clock guard: no budget left for a timed loop)"
+        if n_timed >= 1:
+            t0 = time.perf_counter()
+            for _ in range(n_timed):
+                step()
+            for d in set(devs):
+                torch.cuda.synchronize(d)
+            el, note = (time.perf_counter() - t0) / n_timed, f"mean of {n_timed} steps"
+        res = {"devices": devs, "queries_per_device": nq, "ms_per_step": round(el * 1e3, 3), "timed": note,
                "Mpoints_s": round(total * lanes / el / 1e6, 1),
+               "setup_s": round(setup_s, 2), "first_step_s": round(first_s, 2),
+               "leg_wall_s": round(time.perf_counter() - t_leg, 2), "budget_s": budget_s,
                "what": "one process, one ndi_interp1d_eval_ring_sharded call per step over all visible devices"}
         for r in reps:
             r.strategy.release()
@@ -402,7 +499,8 @@ def secondary_legs(pkg, torch, dev):
     sys.path.insert(0, ROOT)
     import oracle
     sec = {"c3": bilinear_leg(pkg, torch, dev, 2048, 64, 10_000_000),
-           "c5_share": bilinear_leg(pkg, torch, dev, 8192, 16, 12_500_000, probe=True)}
+           "c5_share": bilinear_leg(pkg, torch, dev, 8192, 16, 12_500_000, probe=True),
+           "short_rows": short_rows_leg(pkg, torch, dev)}
     n, nq = 1024, 10_000
     rng = np.random.default_rng(42)
     yv = rng.uniform(0, 1, n); q = np.random.default_rng(123).uniform(0, n - 1, nq)
@@ -531,9 +629,11 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
     def step():
         interp.interp_array_ring(qd, chunk, consumer, slots=ring)   # raises if any query failed (none may)
 
+    use_dist = world > 1 or args.force_dist    # --force-dist: the collectives run on RCCL with world size 1
+
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -562,7 +662,7 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
     cdev = dev if args.backend == "nccl" else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     ranks = None
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ranks = gather_ranks(torch, dist, world, rank, my_elapsed / args.steps * 1e3, my_kernel_ms, my_dev, cdev)
     elapsed = float(t.item())
@@ -778,6 +878,10 @@ def main():
                          "ring); the others are secondary measurements for DESIGN.md")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: initialise torch.distributed anyway (backend nccl = RCCL, world size 1) so that "
+                         "init_process_group(device_id=...), the barrier, the MAX all-reduce and all_gather_object of "
+                         "the N > 1 path execute on a 1-GPU box")
     ap.add_argument("--launch-rehearsal", action="store_true",
                     help="no GPU work: only the launch / rendezvous / barrier / max-over-ranks skeleton (gloo), used by "
                          "the CPU tests to cover the N>1 self-launch")
@@ -816,8 +920,15 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:    # --force-dist without a launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -832,7 +943,7 @@ def main():
         extra_workload(args, pkg, torch, dev, rank, world)
     # success path only: a rank that raised above exits non-zero without entering another collective (its peers
     # may be inside a different one), and self_launch() takes the siblings down
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -9,7 +9,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libndinterp_hip.so")
+# NDI_LIB names another build of the same library (the bounds-checked one, `make debug`: libndinterp_hip_dbg.so;
+# the tuning one, `make tune`); a bare file name is looked up next to this file.
+LIB_PATH = os.environ.get("NDI_LIB") or os.path.join(_HERE, "libndinterp_hip.so")
+if not os.path.isabs(LIB_PATH):
+    LIB_PATH = os.path.join(_HERE, LIB_PATH)
 
 # ndi_status
 OK, NOT_ENOUGH_DATA, MONOTONIC, SHAPE, VALUE, OUT_OF_BOUNDS, NAN_QUERY, HIP_ERROR, BAD_ARG, UNSUPPORTED = range(10)

@@ -49,6 +49,49 @@ struct StatusBlock {
   unsigned long long periodic_mismatch;  // build: lanes with y[0] != y[n-1]
 };
 
+// Opt-in checked build (`make debug` -> libndinterp_hip_dbg.so, -DNDI_BOUNDS): every device-side index that
+// addresses memory -- interval index, grouped record position, query index taken from a record, tile-local offset,
+// histogram bin -- goes through NDI_CHK(index, limit, code).  A violation is RECORDED (first one wins: code, source
+// line, index, limit) in a device word the host reads after every synchronising call, and the index is clamped to 0,
+// so the kernel runs on inside its buffers: no trap, no fault, no early return past a barrier -- nothing that could
+// hang a wave or take the device down.  GPU AddressSanitizer is not available on this pool; this is the substitute
+// ("race detection / sanitizers").  In the normal build NDI_CHK(i, ...) is just (i).
+#ifdef NDI_BOUNDS
+__device__ unsigned long long g_ndi_bounds[4];   // [0] violations seen, [1] code << 32 | line, [2] index, [3] limit
+__device__ __forceinline__ unsigned long long ndi_bounds_fail(int code, int line, unsigned long long idx,
+                                                              unsigned long long lim) {
+  if (atomicAdd(&g_ndi_bounds[0], 1ull) == 0ull) {
+    g_ndi_bounds[1] = ((unsigned long long)code << 32) | (unsigned)line;
+    g_ndi_bounds[2] = idx;
+    g_ndi_bounds[3] = lim;
+  }
+  return 0ull;
+}
+template <class I>
+__device__ __forceinline__ I ndi_chk(I idx, unsigned long long lim, int code, int line) {
+  return (unsigned long long)idx < lim ? idx : (I)ndi_bounds_fail(code, line, (unsigned long long)idx, lim);
+}
+#define NDI_CHK(idx, lim, code) ::ndi::ndi_chk((idx), (unsigned long long)(lim), (code), __LINE__)
+#else
+#define NDI_CHK(idx, lim, code) (idx)
+#endif
+enum BoundsCode : int {
+  BC_INTERVAL = 1,      // interval index i, limit n - 1
+  BC_QUERY = 2,         // query index read from a grouped record, limit nq
+  BC_POSITION = 3,      // grouped record position, limit nq
+  BC_BIN = 4,           // histogram / cursor bin, limit nb
+  BC_CELL_X = 5, BC_CELL_Y = 6,   // 2-D cell indices, limits nx - 1 / ny - 1
+  BC_TILE = 7,          // tile-local grid point offset, limit (2^ts + 1)^2
+  BC_STRIP = 8,         // query slot of a wave's strip, limit 64
+};
+
+__global__ __launch_bounds__(64) void reset_status_kernel(StatusBlock* s) {
+  s->first_fail[0] = NO_FAIL;
+  s->first_fail[1] = NO_FAIL;
+  s->n_valid = 0;
+  s->periodic_mismatch = 0;
+}
+
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef float flt4 __attribute__((ext_vector_type(4)));
 
@@ -315,13 +358,14 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
     const bool isnan_q = !(xs == xs);
     const bool bad = (A.mode == EX_NO) ? !inr : isnan_q;
     if (bad && A.first_fail) atomicMin(A.first_fail, (unsigned long long)qi);
+    i = NDI_CHK(i, P.n - 1u, BC_INTERVAL);
     if (A.idx) A.idx[qi] = i;
     if (A.idx64) A.idx64[qi] = isnan_q ? (int64_t)-1 : (int64_t)i;
     if (A.t) {
       const T xl = P.lv0[i], xr = P.lv0[i + 1];
       A.t[qi] = (xs - xl) / (xr - xl);  // cubic_spline.rs:818
     }
-    if (s_hist) atomicAdd(&s_hist[i], 1u);
+    if (s_hist) atomicAdd(&s_hist[NDI_CHK(i, A.nb, BC_BIN)], 1u);
   }
 }
 
@@ -456,9 +500,9 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
     const bool bady = (A.mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
     if (badx) atomicMin(&A.first_fail[0], (unsigned long long)qi);
     if (bady) atomicMin(&A.first_fail[1], (unsigned long long)qi);
-    A.xi[qi] = ix;
-    A.yi[qi] = iy;
-    if (s_hist) atomicAdd(&s_hist[(ix >> A.sx) * A.nty + (iy >> A.sy)], 1u);
+    A.xi[qi] = NDI_CHK(ix, PX.n - 1u, BC_CELL_X);
+    A.yi[qi] = NDI_CHK(iy, PY.n - 1u, BC_CELL_Y);
+    if (s_hist) atomicAdd(&s_hist[NDI_CHK((ix >> A.sx) * A.nty + (iy >> A.sy), A.nb, BC_BIN)], 1u);
   }
   if (s_hist) {
     __syncthreads();
@@ -488,6 +532,7 @@ struct Eval1Args {
   // write stream several times their share of the bytes: profiles/r02_tuning.md)
   const uint4* rec;
   uint32_t run;   // consecutive chunks per workgroup (0 = 1)
+  uint32_t n_int; // n - 1: limit of every interval index (checked build)
 };
 
 template <class T>
@@ -699,7 +744,7 @@ __global__ __launch_bounds__(BLOCK) void eval_rows_kernel(Eval1Args<T> A) {
   unsigned long long limit = A.status->first_fail[0];
   if (limit > A.nq) limit = A.nq;
   for (uint64_t qi = blockIdx.x; qi < limit; qi += gridDim.x) {
-    const uint32_t i = A.idx[qi];
+    const uint32_t i = NDI_CHK(A.idx[qi], A.n_int, BC_INTERVAL);
     const RowCoef<T, STRAT> c =
         row_coef<T, STRAT>(A.knots, i, STRAT == ST_LINEAR ? A.q[qi] : T(0),
                            STRAT == ST_CUBIC ? A.t[qi] : T(0));
@@ -749,7 +794,7 @@ __global__ __launch_bounds__(BLOCK) void eval_flat_kernel(Eval1Args<T> A, uint32
       const uint32_t ql = it / LV;
       const uint32_t v = it - ql * LV;
       const uint64_t qi = q0 + ql;
-      const uint32_t i = A.idx[qi];
+      const uint32_t i = NDI_CHK(A.idx[qi], A.n_int, BC_INTERVAL);
       const RowCoef<T, STRAT> c =
           row_coef<T, STRAT>(A.knots, i, STRAT == ST_LINEAR ? A.q[qi] : T(0),
                              STRAT == ST_CUBIC ? A.t[qi] : T(0));
@@ -797,6 +842,8 @@ struct EvalFusedArgs {
                          // / ca / cb point at the y / a / b parts of interval 0's record
   int mode;              // ExtrapMode
   const unsigned long long* first_fail;
+  int debug;             // NDI_TUNING builds only (measurement aid, results meaningless): bit 0 no search, bit 1 every
+                         // item reads interval (lane & 7), bit 2 no stores, bit 3 no operand loads at all
 };
 
 template <class V, bool LDS>
@@ -876,10 +923,16 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
     T xs = x;
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;   // cubic_spline.rs:805-809
     // (queries at / after the first failing one never get here; an inactive lane searches k0)
+#ifdef NDI_TUNING
+    uint32_t i;
+    if (A.debug & 1) i = (uint32_t)((base + lane) * 2654435761ull >> 7) % (n - 1u);
+    else i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs) : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);
+#else
     const uint32_t i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs)
                            : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);   // all 64 lanes take part
+#endif
     const T xl = P.lv0[i], xr = P.lv0[i + 1];
-    w_i[lane] = i;
+    w_i[lane] = NDI_CHK(i, n - 1u, BC_INTERVAL);
     if (STRAT == ST_CUBIC) {
       w_c0[lane] = (xs - xl) / (xr - xl);   // t, cubic_spline.rs:818
     } else {
@@ -900,6 +953,7 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
         live[k] = it < items;
         const uint32_t itc = live[k] ? it : 0u;
         ql[k] = (LV == 1u) ? itc : __umulhi(itc, A.lv_magic);
+        ql[k] = NDI_CHK(ql[k], 64u, BC_STRIP);
         v[k] = itc - ql[k] * LV;
         ii[k] = w_i[ql[k]];
         s0[k] = w_c0[ql[k]];
@@ -908,6 +962,10 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
       V yl[UNR], yr[UNR], a[UNR], b[UNR];
 #pragma unroll
       for (int k = 0; k < UNR; ++k) {        // phase 2: the four operand vectors
+#ifdef NDI_TUNING
+        if (A.debug & 2) ii[k] = lane & 7u;
+        if (A.debug & 8) { yl[k] = V(s0[k]); yr[k] = V(s1[k]); a[k] = V(T(v[k])); b[k] = V(T(ql[k])); continue; }
+#endif
         const uint32_t e = ii[k] * RS + v[k];
         yl[k] = t_y[e];
         yr[k] = t_y[e + LV];
@@ -933,6 +991,15 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
           c.c2 = T(0);
         }
         V* o = reinterpret_cast<V*>(o_base + (uint64_t)ql[k] * A.out_stride) + v[k];
+#ifdef NDI_TUNING
+        if (A.debug & 4) {   // keep the arithmetic alive without the store
+          const V r = row_point<T, STRAT, V>(c, yl[k], yr[k], a[k], b[k]);
+          bool hit;
+          if constexpr (VEC == 1) hit = r == T(-123.456); else hit = r[0] == T(-123.456);
+          if (live[k] && hit) store_stream<true>(o, r);
+          continue;
+        }
+#endif
         if (live[k]) store_stream<true>(o, row_point<T, STRAT, V>(c, yl[k], yr[k], a[k], b[k]));
       }
     }
@@ -1037,8 +1104,8 @@ __global__ __launch_bounds__(BLOCK) void group_scatter_kernel(const uint32_t* id
   uint64_t q_end = q_begin + slice;
   if (q_end > nq) q_end = nq;
   for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += BLOCK) {
-    const uint32_t i = idx[qi];
-    const uint32_t pos = atomicAdd(&cur[i], 1u);
+    const uint32_t i = NDI_CHK(idx[qi], nb, BC_BIN);
+    const uint32_t pos = NDI_CHK(atomicAdd(&cur[i], 1u), nq, BC_POSITION);
     rec[pos] = make_rec<T>((uint32_t)qi, i, sval[qi]);
   }
 }
@@ -1099,8 +1166,8 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
         }
         __syncthreads();
         for (uint32_t j = 0; j < cnt; ++j) {
-          const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_i[j]);
-          const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_q[j]);
+          const uint32_t i = NDI_CHK((uint32_t)__builtin_amdgcn_readfirstlane((int)s_i[j]), A.n_int, BC_INTERVAL);
+          const uint32_t qi = NDI_CHK((uint32_t)__builtin_amdgcn_readfirstlane((int)s_q[j]), A.nq, BC_QUERY);
           if (qi >= limit) continue;
           const T sj = s_s[j];
           if (i != cur) {
@@ -1183,8 +1250,8 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_short_kernel(Eval1Args<T>
     const uint32_t j0 = g * CQ;
     const uint32_t j1 = (j0 + CQ < cnt) ? j0 + CQ : cnt;
     for (uint32_t j = j0; j < j1; ++j) {
-      const uint32_t i = s_i[j];
-      const uint32_t qi = s_q[j];
+      const uint32_t i = NDI_CHK(s_i[j], A.n_int, BC_INTERVAL);
+      const uint32_t qi = NDI_CHK(s_q[j], A.nq, BC_QUERY);
       if (qi >= limit) continue;
       const T sj = s_s[j];
       if (i != cur) {
@@ -1262,7 +1329,7 @@ __global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* x
   for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += blockDim.x) {
     const uint32_t ix = xi[qi], iy = yi[qi];
     const T x = qx[qi], y = qy[qi];
-    const uint32_t pos = atomicAdd(&cur[(ix >> sx) * nty + (iy >> sy)], 1u);
+    const uint32_t pos = NDI_CHK(atomicAdd(&cur[NDI_CHK((ix >> sx) * nty + (iy >> sy), nb, BC_BIN)], 1u), nq, BC_POSITION);
     if constexpr (COMPACT && sizeof(T) == 4) {
       rec_i[pos] = make_uint4((uint32_t)qi, ix | (iy << 16), __builtin_bit_cast(uint32_t, x),
                               __builtin_bit_cast(uint32_t, y));
@@ -1418,8 +1485,8 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
         const uint32_t ql = live[k] ? it / LV : 0u;
         v[k] = live[k] ? it - ql * LV : 0u;
         qi[k] = q0 + ql;
-        xi[k] = A.xi[qi[k]];
-        yi[k] = A.yi[qi[k]];
+        xi[k] = NDI_CHK(A.xi[qi[k]], (uint32_t)A.nx - 1u, BC_CELL_X);
+        yi[k] = NDI_CHK(A.yi[qi[k]], (uint32_t)A.ny - 1u, BC_CELL_Y);
         x[k] = A.qx[qi[k]];
         y[k] = A.qy[qi[k]];
       }
@@ -1466,13 +1533,21 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
 // saw 5.2 GB -- concurrent misses on a line are not merged -- and the kernel stayed latency-bound at 1.45-1.65 ms;
 // profiles/r03_c3_grouped.md.)  Results are bit-identical: same operands, same operation order (bilinear.rs:88-97).
 // LV = lanes / VEC vectors per row must divide BLOCK.  XCD-aware chunk order as in eval_bucketed_kernel.
-template <class T, int VEC, int TB>
+// TB threads per workgroup; records are handed over RB at a time (RB <= TB; the first RB threads load them); MAXI =
+// 16-byte vectors per thread of the register double buffer ((2^ts + 1)^2 * LV <= MAXI * TB, checked by the host);
+// COMPACT = self-contained 16-byte f32 records (no {qx, qy} side array, no LDS for it).  The host instantiates
+// <1024, 1024, 6> (one workgroup per CU beside a tile of up to 96 KiB).  <512, 256, 10> -- two workgroups per CU, each
+// with its own 74 KiB tile, the same 16 waves per CU but no shared barriers -- was measured at C3 and is SLOWER
+// (1.54 vs 1.17 ms, profiles/r04_c3_tiles_ab.jsonl: twice the tile staging per CU and half the rows per trip); it
+// stays selectable with NDI_TILE_WG=512 for A/B runs.
+template <class T, int VEC, int TB, int RB = TB, int MAXI = 6, bool COMPACT = false>
 __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A) {
   using V = typename VecT<T, VEC>::type;
+  static_assert(RB <= TB, "the first RB threads of the workgroup load the records");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ uint32_t s_b0;
-  __shared__ uint4 s_rec[TB];
-  __shared__ T s_rq[2 * TB];   // {qx, qy} of non-compact records (f64, or an axis with more than 65536 knots)
+  __shared__ uint4 s_rec[RB];
+  __shared__ T s_rq[COMPACT ? 2 : 2 * RB];   // {qx, qy} of non-compact records (f64, or an axis with more than 65536 knots)
   const uint32_t S = 1u << A.ts, S1 = S + 1u;
   const uint32_t LV = (uint32_t)(A.lanes / VEC);
   V* s_tile = reinterpret_cast<V*>(smem_raw);                              // [S1][S1][LV]
@@ -1513,7 +1588,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
     // `pre` / `pk` (at most MAXI 16-byte vectors per thread); at the tile switch they are written to LDS.  vmcnt is
     // in-order, so the prefetch is complete by the time the first block of records of the current tile is handed
     // over -- its latency hides behind one block of evaluation instead of stalling the CU's only workgroup.
-    constexpr int MAXI = 6;   // (2^ts + 1)^2 * LV <= MAXI * TB vectors: guaranteed by the host's LDS budget (96 KiB)
+    // (2^ts + 1)^2 * LV <= MAXI * TB vectors: guaranteed by the host's tile budget
     struct TileGeo { uint64_t gx0, gy0, lo, hi; uint32_t rows, cols, b; bool valid; };
     auto find_tile = [&](uint32_t b_from) {
       TileGeo g{};
@@ -1591,23 +1666,25 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
       // The tile's records are brought in TB at a time (one coalesced 16-byte load per thread) and handed to the
       // LV-lane groups through LDS; the next block's loads are in flight while the current block is evaluated, so a
       // workgroup pays one memory latency per 256 queries instead of one per trip.
-      bool compact = false;
-      if constexpr (std::is_same<T, float>::value) compact = A.rec_q == nullptr;
+      constexpr bool compact = COMPACT;
+      const bool loader = (RB == TB) || tid < (uint32_t)RB;
       uint64_t pb = lo;
       uint4 r_in = make_uint4(0u, 0u, 0u, 0u);
       T rx_in = T(0), ry_in = T(0);
-      if (pb + tid < hi) {
+      if (loader && pb + tid < hi) {
         r_in = A.rec_i[pb + tid];
         if (!compact) { rx_in = A.rec_q[2 * (pb + tid)]; ry_in = A.rec_q[2 * (pb + tid) + 1]; }
       }
       while (pb < hi) {
-        const uint32_t cnt = (hi - pb < (uint64_t)TB) ? (uint32_t)(hi - pb) : (uint32_t)TB;
+        const uint32_t cnt = (hi - pb < (uint64_t)RB) ? (uint32_t)(hi - pb) : (uint32_t)RB;
         __syncthreads();                            // the previous block's records are no longer being read
-        s_rec[tid] = r_in;
-        if (!compact) { s_rq[2 * tid] = rx_in; s_rq[2 * tid + 1] = ry_in; }
+        if (loader) {
+          s_rec[tid] = r_in;
+          if (!compact) { s_rq[2 * tid] = rx_in; s_rq[2 * tid + 1] = ry_in; }
+        }
         __syncthreads();                            // (also: the tile staged above is complete)
-        const uint64_t nxt_p = pb + TB;
-        if (nxt_p + tid < hi) {
+        const uint64_t nxt_p = pb + RB;
+        if (loader && nxt_p + tid < hi) {
           r_in = A.rec_i[nxt_p + tid];
           if (!compact) { rx_in = A.rec_q[2 * (nxt_p + tid)]; ry_in = A.rec_q[2 * (nxt_p + tid) + 1]; }
         }
@@ -1628,9 +1705,9 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
             xi = r.y;
             yi = r.z;
           }
-          const uint64_t qi = r.x;
+          const uint64_t qi = NDI_CHK((uint64_t)r.x, A.nq, BC_QUERY);
           if (qi >= limit) continue;
-          const uint32_t lx = xi - (uint32_t)gx0, ly = yi - (uint32_t)gy0;
+          const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
           const V* z11 = s_tile + ((size_t)lx * S1 + ly) * LV + v;
           const V a11 = z11[0], a12 = z11[LV], a21 = z11[(size_t)S1 * LV], a22 = z11[(size_t)S1 * LV + LV];
           const T x1 = s_kx[lx], x2 = s_kx[lx + 1u], y1 = s_ky[ly], y2 = s_ky[ly + 1u];
@@ -1778,6 +1855,14 @@ struct BuildArgs {
   const T* up0_4;   // [4]
   const T* wl;      // [4][4]  w[n-1]
   const T* midl;    // [4][4]  mid'[n-1]
+  // blocked sweeps (narrow trailing axes, many knots): see spline_blocked_* below
+  T* rfull;         // [n][lanes] scratch: rhs -> r' -> r'/mid' -> local k     (nullptr: the per-lane serial kernels)
+  T* ends;          // [nblocks][lanes] value at each block's last (forward) / first (backward) row, zero carry in
+  T* carry;         // [nblocks][lanes] carry into each block
+  const T* fP;      // [n] prod_{j = block start .. i} (-w[j])
+  const T* dco;     // [n] -up[i] / mid'[i]
+  const T* bP;      // [n] prod_{j = i .. block end} dco[j]
+  uint64_t S, nblocks;
 };
 
 // SPLINE_GENERAL: rows 0 and n-1 from the boundary kinds (cubic_spline.rs:597-670), interior
@@ -1837,7 +1922,8 @@ __global__ __launch_bounds__(BLOCK) void spline_rhs_kernel(BuildArgs<T> A) {
       if (PER_LANE && lk == 3) r = (((a2 - a1) / A.dx[1]) * A.dx[0] + ((a1 - a0) / A.dx[0]) * A.dx[1]) * three;  // :593-594
       else r = three * (dxn * (a1 - a0) / dxn_1 + dxn_1 * (a2 - a1) / dxn);
     }
-    if (i + 1 == n) A.cb[(n - 2) * L + l] = r;
+    if (A.rfull) A.rfull[e] = r;                 // blocked sweeps: one array for all n rows
+    else if (i + 1 == n) A.cb[(n - 2) * L + l] = r;
     else A.ca[i * L + l] = r;
   }
 }
@@ -1973,6 +2059,124 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
       }
     }
     hi -= (uint64_t)cnt;
+  }
+}
+
+// BLOCKED Thomas sweeps for narrow trailing axes with many knots (scalar data on 1e5-1e6 knots; 8 lanes on 4096).
+// The per-lane serial kernel above gives such a build ONE wave with a handful of live lanes doing 2n dependent steps
+// (a division in every step of the back substitution): 10x-100x behind one CPU core.  Both sweeps are first-order
+// linear recurrences with lane-independent coefficients (spline_blocked_coef_kernel), so the rows are cut into
+// blocks of S: every (block, lane) pair solves its block from a zero carry (spline_blocked_local_kernel, fully
+// parallel), one thread per lane chains the nblocks carries (spline_blocked_carry_kernel), and every row is corrected
+// by carry x (product of the coefficients between the block edge and the row).  The back substitution is evaluated
+// as k[i] = r'[i] / mid'[i] + (-up[i] / mid'[i]) k[i+1] -- the reference has (r'[i] - up[i] k[i+1]) / mid'[i]
+// (cubic_spline.rs:711-720).  This is THE ONE PATH WHOSE RESULTS ARE NOT BIT-IDENTICAL to the reference order: the
+// coefficient tables agree with the oracle to a few ulp of the largest table entry (bar: 1e-10 f64 / 1e-5 f32,
+// tests/test_gpu_spline_blocked.py); NDI_SPLINE_BLOCKED=0 keeps the serial kernels.
+// The lane-independent coefficient products of the blocked sweeps, one thread per block of S rows:
+//     fP[i] = prod_{j = block start .. i} (-w[j])      dco[i] = -up[i] / mid'[i]      bP[i] = prod_{j = i .. block end} dco[j]
+// (w, up, mid' are the x-only factors of the host plan, host_logic.hpp).
+template <class T>
+__global__ __launch_bounds__(BLOCK) void spline_blocked_coef_kernel(const T* w, const T* up, const T* midp, T* fP,
+                                                                    T* dco, T* bP, uint64_t n, uint64_t S,
+                                                                    uint64_t nblocks) {
+  const uint64_t b = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (b >= nblocks) return;
+  const uint64_t i0 = b * S, i1 = (i0 + S < n) ? i0 + S : n;
+  T p = T(0);
+  for (uint64_t i = i0; i < i1; ++i) {
+    const T c = -w[i];
+    p = (i == i0) ? c : p * c;
+    fP[i] = p;
+  }
+  for (uint64_t i = i1; i-- > i0;) {
+    const T d = (i + 1 < n) ? -(up[i] / midp[i]) : T(0);
+    dco[i] = d;
+    p = (i + 1 == i1) ? d : d * p;
+    bP[i] = p;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void spline_blocked_local_kernel(BuildArgs<T> A, int backward) {
+  const uint64_t L = A.lanes, n = A.n;
+  const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;   // = block * L + lane
+  if (t >= A.nblocks * L) return;
+  const uint64_t b = t / L, l = t - b * L;
+  const uint64_t i0 = b * A.S;
+  const uint64_t i1 = (i0 + A.S < n) ? i0 + A.S : n;
+  T* r = A.rfull + l;
+  T prev = T(0);
+  constexpr int UB = 8;   // rows per trip: their loads are independent of the recurrence and issued together
+  if (!backward) {        // r'[i] = rhs[i] - w[i] r'[i-1]      (thomas, cubic_spline.rs:690-702)
+    for (uint64_t i = i0; i < i1; i += UB) {
+      T rv[UB], wv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (i + u < i1) { rv[u] = r[(i + u) * L]; wv[u] = const_load(A.w, i + u); }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (i + u < i1) { prev = rv[u] - wv[u] * prev; r[(i + u) * L] = prev; }
+    }
+  } else {                // k[i] = c[i] + d[i] k[i+1],  c = r' / mid' (already divided), from the block's last row down
+    for (uint64_t i = i1; i > i0;) {
+      const uint64_t cnt = (i - i0 < (uint64_t)UB) ? i - i0 : (uint64_t)UB;
+      T cv[UB], dv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if ((uint64_t)u < cnt) { cv[u] = r[(i - 1 - u) * L]; dv[u] = const_load(A.dco, i - 1 - u); }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if ((uint64_t)u < cnt) { prev = cv[u] + dv[u] * prev; r[(i - 1 - u) * L] = prev; }
+      i -= cnt;
+    }
+  }
+  A.ends[b * L + l] = prev;
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void spline_blocked_carry_kernel(BuildArgs<T> A, int backward) {
+  const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= A.lanes) return;
+  const uint64_t L = A.lanes, n = A.n, nb = A.nblocks;
+  T c = T(0);
+  if (!backward) {
+    for (uint64_t b = 0; b < nb; ++b) {
+      A.carry[b * L + l] = c;
+      const uint64_t last = ((b + 1) * A.S < n ? (b + 1) * A.S : n) - 1;
+      c = A.ends[b * L + l] + const_load(A.fP, last) * c;
+    }
+  } else {
+    for (uint64_t b = nb; b-- > 0;) {
+      A.carry[b * L + l] = c;
+      c = A.ends[b * L + l] + const_load(A.bP, b * A.S) * c;
+    }
+  }
+}
+
+// forward correction fused with the division of the back substitution: rfull[i] = (r'_local[i] + fP[i] carry) / mid'[i]
+template <class T>
+__global__ __launch_bounds__(BLOCK) void spline_blocked_fix_forward_kernel(BuildArgs<T> A) {
+  const uint64_t L = A.lanes, total = A.n * A.lanes;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t i = e / L, l = e - i * L;
+    const T rp = A.rfull[e] + const_load(A.fP, i) * A.carry[(i / A.S) * L + l];
+    A.rfull[e] = rp / const_load(A.midp, i);
+  }
+}
+
+// backward correction fused with a / b (cubic_spline.rs:354-365):  k[i] = k_local[i] + bP[i] carry
+template <class T>
+__global__ __launch_bounds__(BLOCK) void spline_blocked_finish_kernel(BuildArgs<T> A) {
+  const uint64_t L = A.lanes, total = (A.n - 1) * A.lanes;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t i = e / L, l = e - i * L;
+    const T k0 = A.rfull[e] + const_load(A.bP, i) * A.carry[(i / A.S) * L + l];
+    const T k1 = A.rfull[e + L] + const_load(A.bP, i + 1) * A.carry[((i + 1) / A.S) * L + l];
+    const T dy = A.data[e + L] - A.data[e];
+    const T dxi = const_load(A.dx, i);
+    A.ca[e] = k0 * dxi - dy;
+    A.cb[e] = dy - k1 * dxi;
   }
 }
 

@@ -66,6 +66,36 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Device-to-device copy of a replica's tables (ndi_interp{1,2}d_clone).  Between two GPUs that can address each
+// other (xGMI peers) it is one hipMemcpyPeer; when hipDeviceCanAccessPeer says no -- or NDI_CLONE_STAGED=1 forces it,
+// which is how the 1-GPU test box exercises the path -- the bytes are staged through a pinned host buffer in
+// 64 MiB pieces (device -> host on the source device, host -> device on the destination).
+static void copy_across_devices(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes) {
+  if (bytes == 0) return;
+  const char* force = std::getenv("NDI_CLONE_STAGED");   // read per call: a test switches it
+  int can = 1;
+  if (dst_dev != src_dev) NDI_HIP(hipDeviceCanAccessPeer(&can, dst_dev, src_dev));
+  if (can && !(force && force[0] == '1')) {
+    NDI_HIP(hipMemcpyPeer(dst, dst_dev, src, src_dev, bytes));
+    return;
+  }
+  constexpr size_t PIECE = 64ull << 20;
+  void* pin = nullptr;
+  NDI_HIP(hipHostMalloc(&pin, std::min(bytes, PIECE), hipHostMallocPortable));
+  struct Free { void* p; ~Free() { (void)hipHostFree(p); } } guard{pin};
+  for (size_t off = 0; off < bytes; off += PIECE) {
+    const size_t nb = std::min(PIECE, bytes - off);
+    {
+      DeviceGuard g(src_dev);
+      NDI_HIP(hipMemcpy(pin, (const char*)src + off, nb, hipMemcpyDeviceToHost));
+    }
+    {
+      DeviceGuard g(dst_dev);
+      NDI_HIP(hipMemcpy((char*)dst + off, pin, nb, hipMemcpyHostToDevice));
+    }
+  }
+}
+
 // Workspaces are keyed by (stream, calling thread): work enqueued on one stream is ordered, so a
 // thread may reuse its scratch across stream-ordered evaluations, and two host threads that share a
 // stream (e.g. the default stream) still get private scratch -- `eval` on one handle is re-entrant.
@@ -447,10 +477,10 @@ static void launch1(hipStream_t s, int cat, dim3 grid, dim3 block, size_t shmem,
 }
 
 static void reset_status(void* status, hipStream_t s) {
-  // first_fail[0..1] = NO_FAIL (all ones), the rest zero
-  NDI_HIP(hipMemsetAsync(status, 0xFF, 2 * sizeof(unsigned long long), s));
-  NDI_HIP(hipMemsetAsync((char*)status + 2 * sizeof(unsigned long long), 0,
-                         sizeof(StatusBlock) - 2 * sizeof(unsigned long long), s));
+  // first_fail[0..1] = NO_FAIL (all ones), the rest zero -- ONE launch (two hipMemsetAsync calls cost the host twice
+  // the enqueue time of a kernel, and the host path of a 0.8 ms step matters: DESIGN.md 4.4)
+  hipLaunchKernelGGL(reset_status_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<StatusBlock*>(status));
+  NDI_HIP(hipGetLastError());
 }
 
 constexpr uint32_t BUCKETED_RUN = 1;         // consecutive 128-query chunks per workgroup of eval_bucketed_kernel
@@ -610,8 +640,18 @@ static ndi_status check_ring_desc(const ndi_ring_desc* ring, uint64_t lanes, uin
 // ---------------------------------------------------------------------------------------------
 // Interp1D
 // ---------------------------------------------------------------------------------------------
+// What makes two handles replicas of ONE interpolator beyond element type and lanes: knot count and values,
+// strategy, extrapolation mode.  (Data and coefficient tables live on the devices and are not compared.)
+static uint64_t fnv1a(uint64_t h, const void* p, size_t bytes) {
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+  return h;
+}
+constexpr uint64_t FNV_SEED = 0xcbf29ce484222325ull;
+
 struct Interp1DBase {
   virtual ~Interp1DBase() = default;
+  virtual uint64_t signature() const = 0;
   int dtype = 0, device = 0;
   uint64_t lanes = 0;
   virtual ndi_status eval(const void* q, uint64_t nq, void* out, uint64_t out_stride,
@@ -657,6 +697,12 @@ struct Interp1DImpl final : Interp1DBase {
     return packed_ok;
   }
 
+  uint64_t signature() const override {
+    uint64_t h = fnv1a(FNV_SEED, pyr.host_knots.data(), pyr.host_knots.size() * sizeof(T));
+    const uint64_t f[3] = {n, (uint64_t)strategy, (uint64_t)mode};
+    return fnv1a(h, f, sizeof(f));
+  }
+
   // ---- build (CubicSpline::build, cubic_spline.rs:754-771) --------------------------------
   ndi_status build_spline(const ndi_interp1d_desc& d) {
     Range rg("ndi:spline_build");
@@ -676,6 +722,7 @@ struct Interp1DImpl final : Interp1DBase {
     // scalars of the plan, packed into one upload: dx | up | w | midp | k2
     const size_t m = P.m;
     std::vector<T> pack;
+    pack.reserve(P.dx.size() + P.up.size() + P.w.size() + P.midp.size() + P.k2.size());
     pack.insert(pack.end(), P.dx.begin(), P.dx.end());
     const size_t o_up = pack.size();
     pack.insert(pack.end(), P.up.begin(), P.up.end());
@@ -715,6 +762,48 @@ struct Interp1DImpl final : Interp1DBase {
     A.status = status.as<StatusBlock>();
     const unsigned grid = (unsigned)((lanes + 63) / 64);
     hipStream_t s = nullptr;
+    // Narrow trailing axes with many knots: the per-lane serial kernel would be one or two waves doing 2n dependent
+    // steps.  The blocked sweeps (kernels.hpp, spline_blocked_*) take over -- the one path whose tables are not
+    // bit-identical to the reference order (a few ulp; NDI_SPLINE_BLOCKED=0 keeps the serial kernels, =1 forces the
+    // blocked ones wherever they apply).
+    static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
+    static const int blocked_once = ShortKnobs::env("NDI_SPLINE_BLOCKED", -1);
+    const int blocked_env = tune_live ? ShortKnobs::env("NDI_SPLINE_BLOCKED", -1) : blocked_once;
+    const bool blocked = P.mode == SPLINE_GENERAL && n >= 16 &&
+                         (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256));
+    if (blocked) {
+      uint64_t S = 64;
+      while (S * S < n && S < 2048) S *= 2;          // ~sqrt(n) rows per block: local sweeps and carry chain balance
+      // one scratch allocation: [fP | dco | bP | rfull | ends | carry]; the coefficient products are formed on the
+      // device from the plan already uploaded
+      const uint64_t nblk = (n + S - 1) / S;
+      DevBuf scratch;
+      scratch.reserve((3 * (size_t)n + (size_t)n * lanes + 2 * (size_t)nblk * lanes) * sizeof(T));
+      T* sp = scratch.as<T>();
+      A.fP = sp;
+      A.dco = sp + n;
+      A.bP = sp + 2 * n;
+      A.rfull = sp + 3 * n;
+      A.ends = A.rfull + n * lanes;
+      A.carry = A.ends + nblk * lanes;
+      A.S = S;
+      A.nblocks = nblk;
+      const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * lanes + BLOCK - 1) / BLOCK, 65536));
+      const unsigned gl = (unsigned)((nblk * lanes + BLOCK - 1) / BLOCK);
+      hipLaunchKernelGGL(spline_blocked_coef_kernel<T>, dim3((unsigned)((nblk + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                         A.w, A.up, A.midp, sp, sp + n, sp + 2 * n, n, S, nblk);
+      hipLaunchKernelGGL((spline_rhs_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, s, A);
+      hipLaunchKernelGGL(spline_blocked_local_kernel<T>, dim3(gl), dim3(BLOCK), 0, s, A, 0);
+      hipLaunchKernelGGL(spline_blocked_carry_kernel<T>, dim3(grid), dim3(64), 0, s, A, 0);
+      hipLaunchKernelGGL(spline_blocked_fix_forward_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, A);
+      hipLaunchKernelGGL(spline_blocked_local_kernel<T>, dim3(gl), dim3(BLOCK), 0, s, A, 1);
+      hipLaunchKernelGGL(spline_blocked_carry_kernel<T>, dim3(grid), dim3(64), 0, s, A, 1);
+      hipLaunchKernelGGL(spline_blocked_finish_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, A);
+      NDI_HIP(hipGetLastError());
+      NDI_HIP(hipDeviceSynchronize());   // the scratch above is freed on return
+      if (mode != EX_NO && periodic) mode = EX_PERIODIC;
+      return NDI_OK;
+    }
     switch (P.mode) {
       case SPLINE_GENERAL: {
         const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * lanes + BLOCK - 1) / BLOCK, 65536));
@@ -1042,6 +1131,10 @@ struct Interp1DImpl final : Interp1DBase {
     A.out_stride = P.out_stride;
     A.nq = nq;
     A.status = st;
+    A.n_int = (uint32_t)(n - 1);
+#ifdef NDI_BOUNDS
+    if (ShortKnobs::env("NDI_BOUNDS_SELFTEST", 0)) A.n_int = 1;   // checked build: provoke the checker (rows are then wrong)
+#endif
     constexpr int VN = Wide<T>::N;
     const uint64_t LV = P.LV;
     if (P.kind == Plan1::BUCKETED) {
@@ -1149,6 +1242,10 @@ struct Interp1DImpl final : Interp1DBase {
     F.lv_magic = F.lv >= 2 ? (uint32_t)(((1ull << 32) + F.lv - 1) / F.lv) : 0u;
     F.mode = mode;
     F.first_fail = &sc.status.as<StatusBlock>()->first_fail[0];
+    F.debug = 0;
+#ifdef NDI_TUNING
+    F.debug = ShortKnobs::env("NDI_FUSED_DEBUG", 0);
+#endif
     constexpr int VN = Wide<T>::N;
     const dim3 grid(P.f_grid), block(P.f_tb);
 #define NDI_FU(ST, VEC, UNR, TB, TL)                                                                   \
@@ -1559,7 +1656,7 @@ struct Interp1DImpl final : Interp1DBase {
     auto copy = [&](DevBuf& dst, const DevBuf& src) {
       if (!src.p) return;
       dst.reserve(src.bytes);
-      NDI_HIP(hipMemcpyPeer(dst.p, dev, src.p, device, src.bytes));
+      copy_across_devices(dst.p, dev, src.p, device, src.bytes);
     };
     copy(h->data, data);
     copy(h->ca, ca);
@@ -1638,6 +1735,7 @@ static ndi_status create1d(const ndi_interp1d_desc& d, Interp1DBase** out) {
 // ---------------------------------------------------------------------------------------------
 struct Interp2DBase {
   virtual ~Interp2DBase() = default;
+  virtual uint64_t signature() const = 0;
   int dtype = 0, device = 0;
   uint64_t lanes = 0;
   virtual ndi_status eval(const void* qx, const void* qy, uint64_t nq, void* out, uint64_t out_stride,
@@ -1660,6 +1758,13 @@ struct Interp2DImpl final : Interp2DBase {
   bool pair_packed = false;   // data holds the pair-packed layout (pack_pairs_kernel)
   SpaceSet spaces;
   OwnedRing ring_own;
+
+  uint64_t signature() const override {
+    uint64_t h = fnv1a(FNV_SEED, px.host_knots.data(), px.host_knots.size() * sizeof(T));
+    h = fnv1a(h, py.host_knots.data(), py.host_knots.size() * sizeof(T));
+    const uint64_t f[3] = {nx, ny, (uint64_t)mode};
+    return fnv1a(h, f, sizeof(f));
+  }
 
   // Two stages as in Interp1DImpl: prep() = both searches (+ the optional tile grouping) into a scratch set,
   // launch_eval() = the bilinear kernel reading that set.
@@ -1882,10 +1987,28 @@ struct Interp2DImpl final : Interp2DBase {
       const uint64_t nchunks = (nq + A.chunk - 1) / A.chunk;
       const uint64_t resident = (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (shm + 64)));
       const unsigned gx = (unsigned)((std::max<uint64_t>(1, std::min<uint64_t>(nchunks, resident * 4)) + 7) / 8 * 8);
-      constexpr int TTB = 1024;
-      allow_dynamic_lds(reinterpret_cast<const void*>(&eval_bilinear_tiles_kernel<T, VNt, TTB>),
-                        (int)(160 * 1024 - TTB * (16 + 2 * sizeof(T)) - 512));
-      launch1<T>(s, PC_EVAL, dim3(gx), dim3(TTB), shm, eval_bilinear_tiles_kernel<T, VNt, TTB>, A);
+      // One 1024-thread workgroup per CU.  NDI_TILE_WG=512 (A/B only): two 512-thread workgroups per CU when two tiles
+      // (+ 256 records each) fit the 160 KiB and the tile fits the 10 x 512-vector register double buffer -- measured
+      // slower at C3 (1.54 vs 1.17 ms: twice the tile staging per CU, half the rows per trip).
+      static const int wg_env = [] { const char* e = std::getenv("NDI_TILE_WG"); return e ? std::atoi(e) : 0; }();
+      const size_t tile_vecs = s1 * s1 * (lanes / VNt);
+      const size_t static512 = 256 * 16 + (P.compact ? 2 : 2 * 256) * sizeof(T) + 64;
+      const bool two_wg = wg_env == 512 && tile_vecs <= 10 * 512 && 2 * (shm + static512) <= 160 * 1024 &&
+                          (lanes / VNt) <= 512 && 512 % (lanes / VNt) == 0;
+#define NDI_TILES(TTB, RB, MX, CP)                                                                            \
+  do {                                                                                                        \
+    auto kern = eval_bilinear_tiles_kernel<T, VNt, TTB, RB, MX, CP>;                                          \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024 - RB * (16 + 2 * sizeof(T)) - 512)); \
+    launch1<T>(s, PC_EVAL, dim3(gx), dim3(TTB), shm, kern, A);                                                \
+  } while (0)
+      if constexpr (std::is_same<T, float>::value) {
+        if (P.compact) {
+          if (two_wg) NDI_TILES(512, 256, 10, true); else NDI_TILES(1024, 1024, 6, true);
+          return;
+        }
+      }
+      if (two_wg) NDI_TILES(512, 256, 10, false); else NDI_TILES(1024, 1024, 6, false);
+#undef NDI_TILES
       return;
     }
     constexpr int VN = Wide<T>::N;
@@ -2287,7 +2410,7 @@ struct Interp2DImpl final : Interp2DBase {
     h->px.upload(px.host_knots.data(), nx);
     h->py.upload(py.host_knots.data(), ny);
     h->data.reserve(data.bytes);
-    NDI_HIP(hipMemcpyPeer(h->data.p, dev, data.p, device, data.bytes));
+    copy_across_devices(h->data.p, dev, data.p, device, data.bytes);
     *out = h.release();
     return NDI_OK;
   }
@@ -2505,6 +2628,16 @@ struct ShardBarrier {
       cv.wait(l, [&] { return g != gen; });
     }
   }
+  // k shards will never arrive (their worker could not be started): the others must not wait for them
+  void drop(unsigned k) {
+    std::unique_lock<std::mutex> l(m);
+    n -= k;
+    if (n > 0 && count == n) {
+      count = 0;
+      ++gen;
+      cv.notify_all();
+    }
+  }
 };
 
 struct ShardOutcome {
@@ -2627,14 +2760,44 @@ static void run_shards(const Job& job, uint32_t n, std::vector<ShardOutcome>& ou
     }
     if (!arrived) bar.wait();
   };
+  // The workers run `work` by reference to this frame: whatever happens while they are being started, this frame
+  // must not unwind before every started worker is idle again, and the shards that did start must not wait at the
+  // barrier for shards that never will.  The pool belongs to the calling thread and is busy for the whole call: a
+  // nested sharded call from the same host thread (a ring consumer issuing one) is refused by the callers.
   ShardWorkers& pool = shard_workers();
-  pool.ensure(n - 1);
-  for (uint32_t i = 1; i < n; ++i) pool.start(i - 1, [&work, i] { work(i); });
-  work(0);   // shard 0 runs on the calling thread
-  pool.wait(n - 1);
+  uint32_t started = 0;
+  try {
+    pool.ensure(n - 1);
+    for (uint32_t i = 1; i < n; ++i) {
+      pool.start(i - 1, [&work, i] { work(i); });
+      ++started;
+    }
+  } catch (...) {
+    broken.store(1);
+    for (uint32_t i = started + 1; i < n; ++i) {
+      out[i].st = NDI_HIP_ERROR;
+      out[i].msg = "could not start the shard's host thread";
+    }
+    bar.drop(n - 1 - started);
+  }
+  work(0);   // shard 0 runs on the calling thread (never throws: the body catches everything)
+  pool.wait(started);
   F[0] = fx.load();
   F[1] = fy.load();
 }
+
+// One sharded call at a time per calling host thread (its persistent workers are busy until the call returns).
+struct ShardedCallScope {
+  static bool& flag() {
+    static thread_local bool in_call = false;
+    return in_call;
+  }
+  bool nested;
+  ShardedCallScope() : nested(flag()) { flag() = true; }
+  ~ShardedCallScope() {
+    if (!nested) flag() = false;
+  }
+};
 
 template <class T>
 struct Job1 {
@@ -2779,6 +2942,10 @@ static uint32_t shard_owner(uint64_t nq, uint32_t n, uint64_t index) {
 
 template <class T>
 static ndi_status sharded1d(Job1<T>& J, ndi_oob_info* info) {
+  ShardedCallScope scope;
+  if (scope.nested)
+    return fail(NDI_BAD_ARG, "nested sharded call: this host thread is inside a sharded evaluation (e.g. its ring "
+                "consumer); issue the inner call from another thread");
   const uint32_t n = (uint32_t)J.H.size();
   std::vector<ShardOutcome> out(n);
   unsigned long long F[2];
@@ -2793,6 +2960,10 @@ static ndi_status sharded1d(Job1<T>& J, ndi_oob_info* info) {
 
 template <class T>
 static ndi_status sharded2d(Job2<T>& J, ndi_oob_info* info) {
+  ShardedCallScope scope;
+  if (scope.nested)
+    return fail(NDI_BAD_ARG, "nested sharded call: this host thread is inside a sharded evaluation (e.g. its ring "
+                "consumer); issue the inner call from another thread");
   const uint32_t n = (uint32_t)J.H.size();
   std::vector<ShardOutcome> out(n);
   unsigned long long F[2];
@@ -2813,6 +2984,33 @@ static ndi_status sharded2d(Job2<T>& J, ndi_oob_info* info) {
 // =============================================================================================
 // extern "C"
 // =============================================================================================
+namespace ndi {
+// Checked build (-DNDI_BOUNDS): what the device-side index checks recorded since the last look (kernels.hpp,
+// NDI_CHK).  Called where an entry point returns; reading the device word synchronises the device, which is fine
+// for a debugging build.  A recorded violation turns any status into NDI_HIP_ERROR with the first violation's
+// code, source line, index and limit.
+static ndi_status bounds_verdict(ndi_status st, int device) {
+#ifdef NDI_BOUNDS
+  try {
+    DeviceGuard dg(device);
+    unsigned long long w[4] = {0, 0, 0, 0};
+    NDI_HIP(hipMemcpyFromSymbol(w, HIP_SYMBOL(g_ndi_bounds), sizeof(w)));
+    if (w[0] != 0) {
+      const unsigned long long z[4] = {0, 0, 0, 0};
+      NDI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ndi_bounds), z, sizeof(z)));
+      return fail(NDI_HIP_ERROR, "device bounds check failed: %llu violation(s); first: code %u at kernels.hpp:%u, "
+                  "index %llu, limit %llu", w[0], (unsigned)(w[1] >> 32), (unsigned)(w[1] & 0xffffffffu), w[2], w[3]);
+    }
+  } catch (const HipFailure& f) {
+    return from_hip(f);
+  }
+#else
+  (void)device;
+#endif
+  return st;
+}
+}  // namespace ndi
+
 struct ndi_interp1d { ndi::Interp1DBase* impl; };
 struct ndi_interp2d { ndi::Interp2DBase* impl; };
 struct ndi_locator { ndi::LocatorBase* impl; };
@@ -2942,7 +3140,7 @@ NDI_API ndi_status ndi_interp1d_eval(const ndi_interp1d* h, const void* q, uint6
                                      uint64_t out_row_stride, const ndi_eval_opts* opts, ndi_oob_info* info) {
   if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
   NDI_TRY
-  return h->impl->eval(q, nq, out, out_row_stride, opts, info);
+  return ndi::bounds_verdict(h->impl->eval(q, nq, out, out_row_stride, opts, info), h->impl->device);
   NDI_CATCH
 }
 
@@ -2951,21 +3149,21 @@ NDI_API ndi_status ndi_interp2d_eval(const ndi_interp2d* h, const void* qx, cons
                                      ndi_oob_info* info) {
   if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
   NDI_TRY
-  return h->impl->eval(qx, qy, nq, out, out_row_stride, opts, info);
+  return ndi::bounds_verdict(h->impl->eval(qx, qy, nq, out, out_row_stride, opts, info), h->impl->device);
   NDI_CATCH
 }
 
 NDI_API ndi_status ndi_interp1d_finish(const ndi_interp1d* h, void* stream, ndi_oob_info* info) {
   if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
   NDI_TRY
-  return h->impl->finish(stream, info);
+  return ndi::bounds_verdict(h->impl->finish(stream, info), h->impl->device);
   NDI_CATCH
 }
 
 NDI_API ndi_status ndi_interp2d_finish(const ndi_interp2d* h, void* stream, ndi_oob_info* info) {
   if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
   NDI_TRY
-  return h->impl->finish(stream, info);
+  return ndi::bounds_verdict(h->impl->finish(stream, info), h->impl->device);
   NDI_CATCH
 }
 
@@ -2974,7 +3172,7 @@ NDI_API ndi_status ndi_interp1d_eval_ring(const ndi_interp1d* h, const void* q, 
                                           const ndi_eval_opts* opts, ndi_oob_info* info) {
   if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
   NDI_TRY
-  return h->impl->eval_ring(q, nq, ring, consume, user, opts, info);
+  return ndi::bounds_verdict(h->impl->eval_ring(q, nq, ring, consume, user, opts, info), h->impl->device);
   NDI_CATCH
 }
 
@@ -2983,7 +3181,7 @@ NDI_API ndi_status ndi_interp2d_eval_ring(const ndi_interp2d* h, const void* qx,
                                           const ndi_eval_opts* opts, ndi_oob_info* info) {
   if (!h) return ndi::fail(NDI_BAD_ARG, "null handle");
   NDI_TRY
-  return h->impl->eval_ring(qx, qy, nq, ring, consume, user, opts, info);
+  return ndi::bounds_verdict(h->impl->eval_ring(qx, qy, nq, ring, consume, user, opts, info), h->impl->device);
   NDI_CATCH
 }
 
@@ -3002,6 +3200,11 @@ static ndi_status gather_handles(const Handle* const* handles, uint32_t n, int d
     if (handles[i]->impl->dtype != dtype || handles[i]->impl->lanes != handles[0]->impl->lanes)
       return ndi::fail(NDI_BAD_ARG, "shard %u: the handles of a sharded call must be replicas (same element type "
                        "and trailing lanes)", i);
+    // ... and the same knots, strategy and extrapolation mode: every shard range-checks and evaluates with its own
+    // handle, so a mismatched set would mix interpolators and report a first-error index no serial loop produces
+    if (i > 0 && handles[i]->impl->signature() != handles[0]->impl->signature())
+      return ndi::fail(NDI_BAD_ARG, "shard %u: the handles of a sharded call must be replicas of one interpolator "
+                       "(same knots, strategy and extrapolation mode as shard 0)", i);
     out[i] = static_cast<Impl*>(handles[i]->impl);
   }
   return NDI_OK;

@@ -10,6 +10,8 @@ restate `interp_into` with the element type's own arithmetic (integer division t
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 from .errors import InterpolateError, Panic
@@ -62,7 +64,7 @@ def _scalar(v, dt):
     the reference (the query type IS the element type), so it is refused here instead of being truncated."""
     if not _is_int(dt):
         return np.dtype(dt).type(v)
-    if isinstance(v, (float, np.floating)) and float(v) != int(v):
+    if isinstance(v, (float, np.floating)) and (not math.isfinite(float(v)) or float(v) != int(v)):
         raise TypeError(f"query {v!r} is not a value of the element type {np.dtype(dt)}")
     iv = int(v)
     info = np.iinfo(dt)

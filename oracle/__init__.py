@@ -62,7 +62,8 @@ def use_native() -> str:
     import tempfile
     # a private directory (mode 0700, unique name): nothing else can replace the file between the compile and the
     # dlopen, and concurrent ranks / tests never overwrite a library another process has mapped
-    out = os.path.join(tempfile.mkdtemp(prefix="liboracle_native_"), f"liboracle_native_{platform.node()}.so")
+    tmp = tempfile.mkdtemp(prefix="liboracle_native_")
+    out = os.path.join(tmp, f"liboracle_native_{platform.node()}.so")
     try:
         subprocess.run(["g++", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC",
                         "-fvisibility=hidden", "-pthread", "-shared", "-o", out, os.path.join(_HERE, "oracle.cpp")],
@@ -72,6 +73,11 @@ def use_native() -> str:
     except Exception:
         lib()
         return "-O3 -march=x86-64-v3 -ffp-contract=off (native build failed)"
+    finally:
+        # the mapping stays valid after the unlink: nothing is left behind in /tmp, however many bench ranks and test
+        # processes run on the box
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _suf(dtype) -> str:

@@ -1,4 +1,4 @@
-//! `extern "C"` bindings of libndinterp_hip.so -- one to one with `include/ndinterp.h` (v0.4).
+//! `extern "C"` bindings of libndinterp_hip.so -- one to one with `include/ndinterp.h` (v0.3).
 //!
 //! Every `#[repr(C)]` struct and every function below is compared with the header by
 //! `tests/test_rust_ffi_abi.py`: field / argument ORDER and C TYPE, not only names.  Keep one field

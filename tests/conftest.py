@@ -9,6 +9,9 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library re-reads its kernel-variant knobs on every evaluation (instead of once) when this is set at its first
+# evaluation: tests/test_gpu_short_rows.py switches the variants inside one process
+os.environ.setdefault("NDI_TUNE_LIVE", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")

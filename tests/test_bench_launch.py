@@ -82,6 +82,23 @@ def test_bench_two_ranks_on_one_gpu_line_carries_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_force_dist_runs_the_collectives_on_rccl_with_one_rank():
+    """`--gpus 1 --force-dist`: init_process_group("nccl", device_id=...), the barrier, the MAX all-reduce and
+    all_gather_object of the N > 1 path execute on RCCL with world size 1 -- environment / API breakage shows up on
+    the 1-GPU box, before the driver's 8-GPU run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--knots", "512",
+                        "--lanes", "1024", "--queries", "400000", "--chunk", "100000", "--steps", "3", "--warmup", "1",
+                        "--placement-probe", "0", "--no-gather-leg", "--no-pmc", "--no-secondary", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _one_json_line(r.stdout)
+    rk = line["ranks"]
+    assert line["n_gpus"] == 1 and rk["world"] == 1 and rk["backend"] == "nccl" and rk["distinct_devices"] == 1
+    assert rk["per_rank_ms"][0] > 0 and rk["devices"][0]["ordinal"] == 0 and line["check"]["bit_exact"]
+
+
+@pytest.mark.gpu
 def test_bench_in_process_sharded_leg():
     """The leg the N = 1 run adds when its one process sees several devices (one ndi_interp1d_eval_ring_sharded call
     per step over all of them), rehearsed on the 1-GPU box with two replicas on device 0 and a small workload."""
@@ -93,4 +110,6 @@ def test_bench_in_process_sharded_leg():
     line = _one_json_line(r.stdout)
     leg = line["in_process_sharded"]
     assert leg["devices"] == [0, 0] and "error" not in leg and leg["Mpoints_s"] > 0 and leg["queries_per_device"] == 400000
-    assert set(line["secondary"]) == {"c3", "c5_share", "c1"}
+    assert set(line["secondary"]) == {"c3", "c5_share", "c1", "short_rows"}
+    # the leg is bounded in wall-clock time and says what it timed
+    assert leg["leg_wall_s"] <= leg["budget_s"] + 30 and "timed" in leg and leg["first_step_s"] > 0

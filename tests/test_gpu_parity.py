@@ -6,6 +6,8 @@ Bar: the device code is compiled without FMA contraction and written in the refe
 so f32/f64 results are expected to be BIT-IDENTICAL to the oracle; the tests assert exact equality where
 that holds and never accept more than the north-star tolerance (1e-10 rel f64, 1e-5 rel f32).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -43,6 +45,20 @@ def check_equal(got, ref, what):
     assert_rel(got, ref, tol * scale, tol, what + " (not bit-identical, checking tolerance)")
     raise AssertionError(f"{what}: within tolerance but not bit-identical "
                          f"(max abs diff {np.max(np.abs(got.astype(np.float64) - ref.astype(np.float64))):.3e})")
+
+
+def blocked_build(n, L):
+    """Shapes whose CubicSpline build takes the blocked Thomas sweeps by default (ndinterp_api.hip, build_spline):
+    narrow trailing axes on many knots.  The one path that is not bit-identical to the reference order."""
+    return n >= 2048 and L <= 256 and os.environ.get("NDI_SPLINE_BLOCKED", "-1") != "0"
+
+
+def table_close(got, ref, dt, what):
+    """north-star bar for a coefficient table: |got - ref| <= rtol * max|ref| (1e-10 f64, 1e-5 f32)"""
+    got = np.asarray(got, dtype=np.float64).reshape(-1); ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+    scale = np.max(np.abs(ref)) if ref.size else 1.0
+    err = np.max(np.abs(got - ref)) if ref.size else 0.0
+    assert err <= TOL[np.dtype(dt)] * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e}"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -216,6 +232,10 @@ def test_spline_coefficients_bit_exact(pkg, dt, n, L):
         a, b = interp.strategy.coefficients()
         st, ra, rb = oracle.cubic_build(x, yy, periodic=per, left=left, right=right)
         assert st == oracle.OK
+        if blocked_build(n, L) and not per:   # the blocked sweeps: a few ulp of the largest entry, not bit-identical
+            table_close(a, ra, dt, f"a[{name}] n={n} L={L} {np.dtype(dt)} (blocked build)")
+            table_close(b, rb, dt, f"b[{name}] n={n} L={L} {np.dtype(dt)} (blocked build)")
+            continue
         check_equal(a, ra, f"a[{name}] n={n} L={L} {np.dtype(dt)}")
         check_equal(b, rb, f"b[{name}] n={n} L={L} {np.dtype(dt)}")
 

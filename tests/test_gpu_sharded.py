@@ -167,6 +167,87 @@ def test_sharded_raw_c_abi_contract(pkg):
     assert "replicas" in cap.last_error()
 
 
+def test_sharded_refuses_handles_that_are_not_replicas(pkg):
+    """Same element type and lanes is not enough: every shard range-checks and evaluates with its own handle, so
+    knots, strategy and extrapolation mode must match shard 0's (a mismatched set would mix interpolators and report
+    a first-error index no serial loop produces)."""
+    rng = np.random.default_rng(173)
+    x = knots("rand", 40, rng, np.float64); y = rng.uniform(0, 1, (40, 8))
+    base = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new()).build()
+    twin = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new()).build()
+    x2 = x.copy(); x2[7] = 0.5 * (x[7] + x[8])
+    others = {"knots": pkg.Interp1DBuilder.new(y).x(x2).strategy(pkg.CubicSpline.new()).build(),
+              "knot count": pkg.Interp1DBuilder.new(y[:39]).x(x[:39]).strategy(pkg.CubicSpline.new()).build(),
+              "strategy": pkg.Interp1DBuilder.new(y).x(x).build(),
+              "extrapolate": pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().extrapolate(True)).build()}
+    q = rng.uniform(x[0], x[-1], 100)
+    out = np.empty((100, 8))
+    pkg.sharding.interp_array_sharded([base, twin], q, out=out)          # true replicas built separately: accepted
+    for what, h in others.items():
+        with pytest.raises(pkg.DeviceError, match="replicas of one interpolator"):
+            pkg.sharding.interp_array_sharded([base, h], q, out=out)
+    g = rng.random((12, 10, 4), dtype=np.float32)
+    b0 = pkg.Interp2DBuilder.new(g).build()
+    b1 = pkg.Interp2DBuilder.new(g).y(np.linspace(0, 20, 10, dtype=np.float32)).build()
+    qx = rng.uniform(0, 11, 50).astype(np.float32); qy = rng.uniform(0, 9, 50).astype(np.float32)
+    with pytest.raises(pkg.DeviceError, match="replicas of one interpolator"):
+        pkg.sharding.interp_array_sharded([b0, b1], qx, qy)
+
+
+def test_nested_sharded_call_from_the_consumer_is_refused(pkg):
+    """The persistent workers of a calling thread are busy for the whole sharded call: a ring consumer that issues
+    another sharded call on the calling thread (shard 0's consumer runs there) gets NDI_BAD_ARG instead of a hang;
+    the outer call completes."""
+    rng = np.random.default_rng(174)
+    n, L, Q, chunk = 64, 512, 9_000, 2048
+    x = knots("rand", n, rng, np.float64); y = rng.uniform(0, 1, (n, L))
+    reps = _replicas(pkg, x, y, [0, 0])
+    q = rng.uniform(x[0], x[-1], Q)
+    main = threading.get_ident()
+    refused, rows = [], {"n": 0}
+    lock = threading.Lock()
+
+    def consumer(c, view):
+        with lock:
+            rows["n"] += c.q_count
+        if threading.get_ident() == main and not refused:
+            try:
+                pkg.sharding.interp_array_sharded(reps, q[:100], out=np.empty((100, L)))
+            except pkg.DeviceError as e:
+                refused.append(str(e))
+    pkg.sharding.interp_array_ring_sharded(reps, q, chunk_queries=chunk, consumer=consumer, n_slots=2)
+    assert rows["n"] == Q and len(refused) == 1 and "nested sharded call" in refused[0]
+    out = np.empty((100, L))
+    pkg.sharding.interp_array_sharded(reps, q[:100], out=out)            # and the thread can shard again afterwards
+    st, a, b = oracle.cubic_build(x, y)
+    assert np.array_equal(out, oracle.interp1d_cubic(x, y, a, b, q[:100])[2])
+
+
+def test_clone_falls_back_to_a_staged_copy(pkg, monkeypatch):
+    """ndi_interp{1,2}d_clone between devices that cannot address each other (hipDeviceCanAccessPeer == 0) stages the
+    tables through pinned host memory; NDI_CLONE_STAGED=1 forces that path so that the 1-GPU box exercises it."""
+    rng = np.random.default_rng(175)
+    x = knots("rand", 500, rng, np.float64); y = rng.uniform(0, 1, (500, 40_000))     # 3 x 160 MB: several pieces
+    src = pkg.Interp1DBuilder.new(y[:, :4096]).x(x).strategy(pkg.CubicSpline.new()).build()
+    big = pkg.Interp1DBuilder.new(y).x(x).build()                                      # Linear, 160 MB of data
+    q = rng.uniform(x[0], x[-1], 2_000)
+    monkeypatch.setenv("NDI_CLONE_STAGED", "1")
+    rep = src.replicate(_devices(pkg, 2)[1:])[0]
+    rep_big = big.replicate(_devices(pkg, 2)[1:])[0]
+    monkeypatch.delenv("NDI_CLONE_STAGED")
+    ca, cb = rep.strategy.coefficients()
+    ca0, cb0 = src.strategy.coefficients()
+    assert np.array_equal(ca, ca0) and np.array_equal(cb, cb0)
+    assert np.array_equal(rep.interp_array(q), src.interp_array(q))
+    assert np.array_equal(rep_big.interp_array(q[:200]), big.interp_array(q[:200]))
+    g = rng.random((64, 48, 4), dtype=np.float32)                                       # pair-packed 2-D grid
+    bi = pkg.Interp2DBuilder.new(g).build()
+    qx = rng.uniform(0, 63, 3000).astype(np.float32); qy = rng.uniform(0, 47, 3000).astype(np.float32)
+    monkeypatch.setenv("NDI_CLONE_STAGED", "1")
+    r2 = bi.replicate(_devices(pkg, 2)[1:])[0]
+    assert np.array_equal(r2.interp_array(qx, qy), bi.interp_array(qx, qy))
+
+
 def test_sharded_calls_from_concurrent_host_threads(pkg):
     """Two host threads each issue sharded calls on their own replica sets at the same time (per-handle, per-thread
     scratch; the library's worker threads are per call)."""

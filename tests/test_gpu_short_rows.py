@@ -1,0 +1,250 @@
+"""GPU parity of the short-row 1-D formulations (rows under 256 vectors; the reference's own data shapes -- scalar
+data, (100, 5): benches/bench_interp1d.rs:82-122) against the CPU oracle, bit for bit, through the C ABI:
+
+  * flat     locate_kernel + eval_flat_kernel (round 3's only form for these shapes)
+  * fused    eval_fused_kernel: query order, search fused in; tables from L2 (plain / interval-packed) or from LDS
+  * grouped  eval_bucketed_short_kernel: grouped by interval, operand vectors in registers
+
+The variants are selected with the library's tuning knobs (NDI_TUNE_LIVE is set by conftest, so one process can
+switch them); `auto` is what ships.  Linear = linear.rs:73-98, CubicSpline = cubic_spline.rs:791-830."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from test_gpu_parity import check_equal, knots
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = ("NDI_SHORT_MODE", "NDI_FUSED_UNR", "NDI_FUSED_TB", "NDI_FUSED_LDS", "NDI_FUSED_WGS", "NDI_SHORT_CQ",
+         "NDI_FUSED_PACK", "NDI_SHORT_ROWB")
+
+
+class knobs:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        for k, v in self.kw.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k in KNOBS:
+            os.environ.pop(k, None)
+
+
+def variants(pkg):
+    return [
+        ("auto", pkg.PATH_AUTO, {}),
+        ("gather", pkg.PATH_GATHER, {}),
+        ("bucketed", pkg.PATH_BUCKETED, {}),
+        ("flat", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=1)),
+        ("fused_l2_u1", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_PACK=0, NDI_FUSED_UNR=1)),
+        ("fused_l2_u4_tb512", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_PACK=0, NDI_FUSED_UNR=4,
+                                                     NDI_FUSED_TB=512)),
+        ("fused_pack", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_PACK=1)),
+        ("fused_lds", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=1)),
+        ("fused_lds_tb256_u4", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=1, NDI_FUSED_TB=256, NDI_FUSED_UNR=4)),
+        ("grouped_cq16", pkg.PATH_BUCKETED, dict(NDI_SHORT_MODE=3, NDI_SHORT_CQ=16)),
+        ("grouped_cq64", pkg.PATH_AUTO, dict(NDI_SHORT_MODE=3, NDI_SHORT_CQ=64)),
+    ]
+
+
+def _device_eval(pkg, interp, q, L, path, tdt, fill=None):
+    import torch
+    dev = torch.device("cuda:0")
+    interp.strategy.path = path
+    qd = torch.as_tensor(q, device=dev)
+    out = torch.empty((q.size, L), dtype=tdt, device=dev) if fill is None else \
+        torch.full((q.size, L), fill, dtype=tdt, device=dev)
+    interp.interp_array_into(qd, out)
+    return out
+
+
+# (n, L): scalar data, the reference's (100, 5), unaligned and aligned short rows, both sides of every vector /
+# group-size boundary, rows just under one workgroup pass
+SHAPES = [(100, 1), (100, 5), (1024, 8), (300, 9), (64, 30), (1024, 32), (129, 64), (77, 128), (40, 254), (33, 500)]
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("n,L", SHAPES)
+def test_short_rows_every_variant_bit_exact(pkg, dt, n, L):
+    import torch
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n * 1009 + L)
+    if dt == np.float32 and L == 500:
+        L = 1000   # LV = 250 for both types
+    Q = 150_001     # ragged last batch, more than 5 (n - 1) queries, above the bucket-index threshold
+    x = knots("rand", n, rng, dt)
+    y = rng.uniform(-1.0, 1.0, (n, L)).astype(dt)
+    q = rng.uniform(x[0], x[-1], Q).astype(dt)
+    q[:4] = [x[0], x[-1], x[n // 2], np.nextafter(x[-1], x[0])]
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref_c = oracle.interp1d_cubic(x, y, a, b, q)
+    _, _, ref_l = oracle.interp1d_linear(x, y, q)
+    cub = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
+        .strategy(pkg.CubicSpline.new()).build()
+    lin = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)).build()
+    taken = set()
+    for name, path, kn in variants(pkg):
+        with knobs(**kn):
+            pkg.profile_enable(True); pkg.profile_read(reset=True)
+            got = _device_eval(pkg, cub, q, L, path, tdt).cpu().numpy()
+            taken.add(pkg.profile_read(reset=True)["last_path"]); pkg.profile_enable(False)
+            check_equal(got, ref_c.reshape(Q, L), f"cubic {name} n={n} L={L}")
+            got = _device_eval(pkg, lin, q, L, path, tdt).cpu().numpy()
+            check_equal(got, ref_l.reshape(Q, L), f"linear {name} n={n} L={L}")
+    if L > 2 and L % (16 // np.dtype(dt).itemsize) == 0:   # 16-byte vector rows: the grouped form exists
+        assert "bucketed" in taken and "gather" in taken, taken   # both formulations really ran
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_short_rows_small_batches_and_pyramid_search(pkg, dt):
+    """Below 4096 queries the fused kernel searches with the wave-cooperative pyramid (no bucket index); even and
+    uneven axes, n <= 64 (one pyramid level) and n > 64."""
+    import torch
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    for kind, n, L, Q in (("lin", 100, 5, 1000), ("rand", 50, 12, 3000), ("log", 2000, 8, 4000), ("jit", 5000, 20, 70)):
+        x = knots(kind, n, rng, dt)
+        y = rng.uniform(-1.0, 1.0, (n, L)).astype(dt)
+        q = rng.uniform(x[0], x[-1], Q).astype(dt)
+        st, a, b = oracle.cubic_build(x, y)
+        _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+        os.environ["NDI_SPLINE_BLOCKED"] = "0"   # this test is about the evaluation kernels: bit-identical tables
+        try:
+            it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
+                .strategy(pkg.CubicSpline.new()).build()
+        finally:
+            del os.environ["NDI_SPLINE_BLOCKED"]
+        for name, path, kn in variants(pkg):
+            with knobs(**kn):
+                got = _device_eval(pkg, it, q, L, path, tdt).cpu().numpy()
+                check_equal(got, ref.reshape(Q, L), f"{kind} n={n} L={L} {name}")
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_short_rows_first_error_and_extrapolation(pkg, dt):
+    """Rows before the first failing query are written, later rows untouched (interp1d/mod.rs:334-342), in every
+    variant; extrapolation with the end interval, periodic wrap, NaN under extrapolation = panic-equivalent."""
+    import torch
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    for n, L in ((100, 5), (300, 16), (64, 192)):
+        Q = 60_000
+        x = knots("rand", n, rng, dt)
+        y = rng.uniform(-1.0, 1.0, (n, L)).astype(dt)
+        y[-1] = y[0]
+        q = rng.uniform(x[0], x[-1], Q).astype(dt)
+        st, a, b = oracle.cubic_build(x, y)
+        _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+        ref = ref.reshape(Q, L)
+        qb = q.copy()
+        qb[41_003] = x[-1] + 1; qb[52_000] = np.nan; qb[59_999] = x[0] - 1
+        span = x[-1] - x[0]
+        qe = rng.uniform(x[0] - 2.5 * span, x[-1] + 2.5 * span, Q).astype(dt)
+        _, _, ref_e = oracle.interp1d_cubic(x, y, a, b, qe, oracle.EXTRAPOLATE_YES)
+        _, _, ref_le = oracle.interp1d_linear(x, y, qe, True)
+        stp, ap, bp = oracle.cubic_build(x, y, periodic=True)
+        _, _, ref_p = oracle.interp1d_cubic(x, y, ap, bp, qe, oracle.EXTRAPOLATE_PERIODIC)
+        yd, xd = torch.as_tensor(y, device=dev), torch.as_tensor(x, device=dev)
+        cub = pkg.Interp1DBuilder.new(yd).x(xd).strategy(pkg.CubicSpline.new()).build()
+        cube = pkg.Interp1DBuilder.new(yd).x(xd).strategy(pkg.CubicSpline.new().extrapolate(True)).build()
+        line = pkg.Interp1DBuilder.new(yd).x(xd).strategy(pkg.Linear.new().extrapolate(True)).build()
+        per = pkg.Interp1DBuilder.new(yd).x(xd).strategy(
+            pkg.CubicSpline.new().extrapolate(True).boundary(pkg.BoundaryCondition.Periodic)).build()
+        for name, path, kn in variants(pkg):
+            with knobs(**kn):
+                cub.strategy.path = path
+                buf = torch.full((Q, L), -4.0, dtype=tdt, device=dev)
+                with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+                    cub.interp_array_into(torch.as_tensor(qb, device=dev), buf)
+                assert ei.value.index == 41_003, name
+                h = buf.cpu().numpy()
+                assert np.array_equal(h[:41_003], ref[:41_003]), name
+                assert np.all(h[41_003:] == -4.0), name
+                check_equal(_device_eval(pkg, cube, qe, L, path, tdt).cpu().numpy(), ref_e.reshape(Q, L), f"extrap {name}")
+                check_equal(_device_eval(pkg, line, qe, L, path, tdt).cpu().numpy(), ref_le.reshape(Q, L), f"lin extrap {name}")
+                check_equal(_device_eval(pkg, per, qe, L, path, tdt).cpu().numpy(), ref_p.reshape(Q, L), f"periodic {name}")
+                qn = qe.copy(); qn[777] = np.nan
+                cube.strategy.path = path
+                buf = torch.full((Q, L), -4.0, dtype=tdt, device=dev)
+                with pytest.raises(pkg.Panic):
+                    cube.interp_array_into(torch.as_tensor(qn, device=dev), buf)
+                h = buf.cpu().numpy()
+                assert np.array_equal(h[:777], ref_e.reshape(Q, L)[:777]) and np.all(h[777:] == -4.0), name
+
+
+def test_reference_bench_shapes_at_1e7_queries(pkg):
+    """The reference's own data shapes at Q = 1e7 on device buffers: scalar data and (100, 5) f64, both strategies
+    (benches/bench_interp1d.rs:12-47, 82-122 with 1e7 instead of 1e4 queries).  Every output of the shipped path
+    equals the two-kernel flat form's bit for bit; 20 000 sampled rows equal the oracle; knot hits return the data."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(42)
+    Q = 10_000_000
+    for shape in ((100,), (100, 5)):
+        n = shape[0]
+        L = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        y = rng.uniform(0.0, 1.0, shape)
+        x = np.arange(n, dtype=np.float64)               # the default index axis of the benches
+        q = rng.uniform(0.0, n - 1.0, Q)
+        q[:n] = x                                         # every knot once
+        sample = rng.choice(Q, 20_000, replace=False)
+        sample[:n] = np.arange(n)
+        yd = torch.as_tensor(y, device=dev)
+        qd = torch.as_tensor(q, device=dev)
+        st, a, b = oracle.cubic_build(x, y.reshape(n, L))
+        for strat_name, strat in (("linear", pkg.Linear.new()), ("cubic", pkg.CubicSpline.new())):
+            it = pkg.Interp1DBuilder.new(yd).strategy(strat).build()
+            if strat_name == "linear":
+                _, _, ref = oracle.interp1d_linear(x, y.reshape(n, L), q[sample])
+            else:
+                _, _, ref = oracle.interp1d_cubic(x, y.reshape(n, L), a, b, q[sample])
+            with knobs():
+                out = it.interp_array(qd)
+            with knobs(NDI_SHORT_MODE=1):
+                flat = it.interp_array(qd)
+            assert torch.equal(out, flat), (shape, strat_name)
+            got = out.reshape(Q, L)[torch.as_tensor(sample, device=dev)].cpu().numpy()
+            check_equal(got, ref.reshape(-1, L), f"{shape} {strat_name} sampled rows")
+            assert np.array_equal(got[:n], y.reshape(n, L)), "knot hits return the data rows"
+            del out, flat
+        torch.cuda.empty_cache()
+
+
+def test_short_rows_in_the_ring_and_strided_buffers(pkg):
+    """The same kernels behind the ring evaluation (chunks, side-stream preparation) and with a padded row stride."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    n, L, Q = 200, 24, 90_000
+    x = knots("jit", n, rng, np.float64)
+    y = rng.uniform(-1.0, 1.0, (n, L))
+    q = rng.uniform(x[0], x[-1], Q)
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref = oracle.interp1d_cubic(x, y, a, b, q)
+    it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
+        .strategy(pkg.CubicSpline.new()).build()
+    for name, path, kn in variants(pkg):
+        with knobs(**kn):
+            it.strategy.path = path
+            got = np.zeros((Q, L))
+            ring = pkg.striped_ring(20_000, L, 2, np.float64, 0)
+
+            def consume(c, rows):
+                got[c.q_begin:c.q_begin + c.q_count] = rows.cpu().numpy()
+
+            it.interp_array_ring(torch.as_tensor(q, device=dev), 20_000, consume, slots=ring)
+            check_equal(got, ref.reshape(Q, L), f"ring {name}")
+            wide = torch.full((Q, L + 8), -9.0, dtype=torch.float64, device=dev)
+            it.strategy.interp_array_into(it, torch.as_tensor(q, device=dev), wide[:, :L])   # row stride L + 8
+            h = wide.cpu().numpy()
+            check_equal(h[:, :L], ref.reshape(Q, L), f"strided {name}")
+            assert np.all(h[:, L:] == -9.0), name

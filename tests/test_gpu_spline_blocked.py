@@ -1,0 +1,95 @@
+"""GPU parity of the BLOCKED Thomas sweeps (CubicSpline::build for narrow trailing axes on many knots,
+cubic_spline.rs:409-721): the one path whose results are not bit-identical to the reference order -- the two sweeps
+are evaluated block-wise with precomputed coefficient products and the back substitution as r'/mid' + (-up/mid') k
+instead of (r' - up k)/mid'.  Bar = the north star's: 1e-10 (f64) / 1e-5 (f32) relative to the largest magnitude,
+on the coefficient tables and on evaluated rows; with NDI_SPLINE_BLOCKED=0 the same shapes are bit-exact again."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import assert_rel
+from test_gpu_parity import BCS, TOL, check_equal, knots, table_close
+
+pytestmark = pytest.mark.gpu
+
+
+class blocked:
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        self.old = os.environ.get("NDI_SPLINE_BLOCKED")
+        if self.v is None:
+            os.environ.pop("NDI_SPLINE_BLOCKED", None)
+        else:
+            os.environ["NDI_SPLINE_BLOCKED"] = str(self.v)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("NDI_SPLINE_BLOCKED", None)
+        else:
+            os.environ["NDI_SPLINE_BLOCKED"] = self.old
+
+
+def _bc(pkg, L, left, right):
+    S, R, B = pkg.SingleBoundary, pkg.RowBoundary, pkg.BoundaryCondition
+
+    def single(kind, val):
+        return {0: S.NotAKnot, 1: S.Natural, 2: S.Clamped}.get(kind) or (S.FirstDeriv(val) if kind == 3 else S.SecondDeriv(val))
+    rows = np.empty((1, L), dtype=object)
+    for i in range(L):
+        rows[0, i] = R.Mixed(single(*left), single(*right))
+    return B.Individual(rows)       # identical rows are one global boundary (interp1d.py)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("kind,n,L", [("rand", 2048, 1), ("jit", 4096, 8), ("rand", 5000, 3), ("log", 20_000, 5),
+                                       ("jit", 100_000, 1), ("lin", 65_537, 2), ("jit", 3000, 256)])
+def test_blocked_build_tables_and_rows_within_the_bar(pkg, dt, kind, n, L):
+    rng = np.random.default_rng(n + L)
+    x = knots(kind, n, rng, dt) if kind != "log" else np.unique(np.logspace(-2, 0, n).astype(dt))
+    n = x.size
+    y = rng.uniform(-1.0, 1.0, (n, L)).astype(dt)
+    q = rng.uniform(x[0], x[-1], 20_000).astype(dt)
+    q[:2] = [x[0], x[-1]]
+    for name, (per, left, right) in BCS.items():
+        if per:
+            continue                      # periodic keeps its own (serial, bit-exact) kernel
+        st, ra, rb = oracle.cubic_build(x, y, left=left, right=right)
+        assert st == oracle.OK
+        _, _, ref = oracle.interp1d_cubic(x, y, ra, rb, q)
+        with blocked(None):               # default: this shape takes the blocked sweeps
+            it = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().boundary(_bc(pkg, L, left, right))).build()
+        a, b = it.strategy.coefficients()
+        table_close(a, ra, dt, f"a[{name}] {kind} n={n} L={L}")
+        table_close(b, rb, dt, f"b[{name}] {kind} n={n} L={L}")
+        got = np.asarray(it.interp_array(q), dtype=np.float64).reshape(ref.shape)
+        # the reference's own assertion form (approx's assert_relative_eq!): absolute OR relative -- splines
+        # on sorted-random knots overshoot by orders of magnitude between near-coincident knots
+        tol = TOL[np.dtype(dt)]
+        assert_rel(got, ref.astype(np.float64), tol * float(np.max(np.abs(y))), tol, f"rows [{name}] {kind} n={n} L={L}")
+        assert np.array_equal(got[:2], y[[0, -1]].astype(np.float64).reshape(2, -1)), "knot hits return the data rows"
+        with blocked(0):                  # the serial kernels on the same shape: bit-identical again
+            it0 = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().boundary(_bc(pkg, L, left, right))).build()
+        a0, b0 = it0.strategy.coefficients()
+        check_equal(a0, ra, f"serial a[{name}] n={n} L={L}")
+        check_equal(b0, rb, f"serial b[{name}] n={n} L={L}")
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_blocked_build_forced_on_small_and_wide_shapes(pkg, dt):
+    """NDI_SPLINE_BLOCKED=1: every block size / remainder combination (n just above a block multiple, one block,
+    many lanes) against the oracle."""
+    rng = np.random.default_rng(9)
+    with blocked(1):
+        for n, L in ((16, 1), (17, 4), (63, 2), (64, 3), (65, 1), (129, 70), (1000, 300), (4097, 2), (70_000, 1)):
+            x = knots("jit", n, rng, dt)
+            y = rng.uniform(-1.0, 1.0, (n, L)).astype(dt)
+            for left, right in (((0, 0.0), (0, 0.0)), ((3, 0.25), (4, -0.5)), ((1, 0.0), (2, 0.0))):
+                st, ra, rb = oracle.cubic_build(x, y, left=left, right=right)
+                it = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().boundary(_bc(pkg, L, left, right))).build()
+                a, b = it.strategy.coefficients()
+                table_close(a, ra, dt, f"a n={n} L={L} {left} {right}")
+                table_close(b, rb, dt, f"b n={n} L={L} {left} {right}")

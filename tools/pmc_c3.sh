@@ -1,10 +1,11 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE of the C3 bilinear evaluation, gather order vs tile-grouped order (separate --pmc passes).
 cd /tmp && export TMPDIR=/tmp
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
 R=$GRAFT_REPO_ROOT
 for path in gather bucketed; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmc_$path_$c
+    rm -rf "/tmp/pmc_${path}_${c}"
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${path}_$c -- python3 $R/bench.py --workload c3 --path $path --steps 3 --warmup 1 > /dev/null 2>&1
     f=$(find /tmp/pmc_${path}_$c -name "*counter_collection.csv" | head -1)
     python3 - "$f" "$path" "$c" <<'PY'

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-3 profile set: the default bench line, rocprofv3 per-kernel stats of the same workload, PMC traffic.
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R && python bench.py --steps 20 --warmup 5 > $O/r03_bench_default.json 2> $O/r03_bench_default.err

@@ -24,7 +24,7 @@ import __graft_entry__ as g
 pkg = g.load_package()
 dev = torch.device("cuda:0")
 
-KNOBS = ("NDI_SHORT_MODE", "NDI_FUSED_UNR", "NDI_FUSED_TB", "NDI_FUSED_LDS", "NDI_FUSED_WGS", "NDI_SHORT_CQ", "NDI_FUSED_PACK")
+KNOBS = ("NDI_SHORT_MODE", "NDI_FUSED_UNR", "NDI_FUSED_TB", "NDI_FUSED_LDS", "NDI_FUSED_WGS", "NDI_SHORT_CQ", "NDI_FUSED_PACK", "NDI_FUSED_DEBUG")
 
 
 def set_knobs(**kw):
@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--strategy", type=str, default="cubic")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--only", type=str, default="", help="run only the variants whose name starts with this")
+    ap.add_argument("--debug-bits", type=str, default="", help="tuning build only (NDI_LIB=libndinterp_hip_tune.so): "
+                    "comma-separated NDI_FUSED_DEBUG values, each variant is run once per value (bit 0 no search, "
+                    "1 operands always from 8 hot intervals, 2 no stores, 3 no operand loads)")
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     lanes = [int(v) for v in args.lanes.split(",")]
@@ -93,6 +96,11 @@ def main():
                 if L * el < 128:
                     for unr in unrs:
                         variants.append((f"fused_l2pack_u{unr}", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_UNR=unr, NDI_FUSED_PACK=1)))
+                if not args.quick and L * el < 128:
+                    for tb in (512, 1024):
+                        for unr in (2, 4):
+                            variants.append((f"fused_l2pack_u{unr}_tb{tb}", pkg.PATH_GATHER,
+                                             dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_UNR=unr, NDI_FUSED_PACK=1, NDI_FUSED_TB=tb)))
                 if not args.quick:
                     variants.append(("fused_l2_u2_tb512", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_UNR=2, NDI_FUSED_TB=512)))
                     variants.append(("fused_l2_u2_wgs8", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_UNR=2, NDI_FUSED_WGS=8)))
@@ -107,6 +115,9 @@ def main():
                 variants.append(("auto", pkg.PATH_AUTO, {}))
             if args.only:
                 variants = [v for v in variants if v[0].startswith(args.only)]
+            if args.debug_bits:
+                variants = [(f"{nm}@dbg{b}", pth, dict(kn, NDI_FUSED_DEBUG=b)) for nm, pth, kn in variants
+                            for b in args.debug_bits.split(",")]
             for name, path, knobs in variants:
                 set_knobs(**knobs)
                 out.fill_(-1.0)

@@ -1863,6 +1863,7 @@ struct BuildArgs {
   const T* dco;     // [n] -up[i] / mid'[i]
   const T* bP;      // [n] prod_{j = i .. block end} dco[j]
   uint64_t S, nblocks;
+  uint64_t rows;    // rows of the system being swept (n; n - 2 for the condensed periodic system)
 };
 
 // SPLINE_GENERAL: rows 0 and n-1 from the boundary kinds (cubic_spline.rs:597-670), interior
@@ -2099,7 +2100,7 @@ __global__ __launch_bounds__(BLOCK) void spline_blocked_coef_kernel(const T* w, 
 
 template <class T>
 __global__ __launch_bounds__(BLOCK) void spline_blocked_local_kernel(BuildArgs<T> A, int backward) {
-  const uint64_t L = A.lanes, n = A.n;
+  const uint64_t L = A.lanes, n = A.rows;
   const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;   // = block * L + lane
   if (t >= A.nblocks * L) return;
   const uint64_t b = t / L, l = t - b * L;
@@ -2138,7 +2139,7 @@ template <class T>
 __global__ __launch_bounds__(64) void spline_blocked_carry_kernel(BuildArgs<T> A, int backward) {
   const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= A.lanes) return;
-  const uint64_t L = A.lanes, n = A.n, nb = A.nblocks;
+  const uint64_t L = A.lanes, n = A.rows, nb = A.nblocks;
   T c = T(0);
   if (!backward) {
     for (uint64_t b = 0; b < nb; ++b) {
@@ -2157,7 +2158,7 @@ __global__ __launch_bounds__(64) void spline_blocked_carry_kernel(BuildArgs<T> A
 // forward correction fused with the division of the back substitution: rfull[i] = (r'_local[i] + fP[i] carry) / mid'[i]
 template <class T>
 __global__ __launch_bounds__(BLOCK) void spline_blocked_fix_forward_kernel(BuildArgs<T> A) {
-  const uint64_t L = A.lanes, total = A.n * A.lanes;
+  const uint64_t L = A.lanes, total = A.rows * A.lanes;
   for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
     const uint64_t i = e / L, l = e - i * L;
     const T rp = A.rfull[e] + const_load(A.fP, i) * A.carry[(i / A.S) * L + l];
@@ -2177,6 +2178,73 @@ __global__ __launch_bounds__(BLOCK) void spline_blocked_finish_kernel(BuildArgs<
     const T dxi = const_load(A.dx, i);
     A.ca[e] = k0 * dxi - dy;
     A.cb[e] = dy - k1 * dxi;
+  }
+}
+
+// ---- periodic boundary (cubic_spline.rs:498-565) with the blocked sweeps: the condensed system of order m = n - 2
+// is swept exactly as above (rows = m), then k = k1 + k_{n-2} k2 with the lane-independent k2 of the host plan.
+// Right-hand sides of the condensed system, one thread per (row, lane); also the y[0] == y[n-1] check (:501-507).
+template <class T>
+__global__ __launch_bounds__(BLOCK) void spline_periodic_rhs_kernel(BuildArgs<T> A) {
+  const uint64_t n = A.n, L = A.lanes, m = n - 2;
+  const T three = T(3);
+  const uint64_t total = m * L;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t i = e / L, l = e - i * L;
+    const T* y = A.data + l;
+    T r;
+    if (i == 0) {
+      const T y0 = y[0], y1 = y[L], yn1 = y[(n - 1) * L], yn2 = y[(n - 2) * L];
+      if (y0 != yn1) atomicAdd(&A.status->periodic_mismatch, 1ull);
+      const T dx0 = A.dx[0], dxl = A.dx[n - 2];
+      const T slope0 = (y1 - y0) / dx0;
+      const T slope_1 = (yn1 - yn2) / dxl;
+      r = (slope_1 * dx0 + slope0 * dxl) * three;
+    } else {
+      const T a0 = y[(i - 1) * L], a1 = y[i * L], a2 = y[(i + 1) * L];
+      const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
+      r = three * (dxn * (a1 - a0) / dxn_1 + dxn_1 * (a2 - a1) / dxn);
+    }
+    A.rfull[e] = r;
+  }
+}
+
+// k_{n-2} per lane (:537-547) from the corrected k1[0] and k1[m-1]; stored in ends[lane]
+template <class T>
+__global__ __launch_bounds__(64) void spline_periodic_km1_kernel(BuildArgs<T> A) {
+  const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= A.lanes) return;
+  const uint64_t n = A.n, L = A.lanes, m = n - 2;
+  const T three = T(3);
+  const T* y = A.data + l;
+  const T dxl = A.dx[n - 2], dxl2 = A.dx[n - 3];
+  const T yn1 = y[(n - 1) * L], yn2 = y[(n - 2) * L], yn3 = y[(n - 3) * L];
+  const T slope_1 = (yn1 - yn2) / dxl;
+  const T slope_2 = (yn2 - yn3) / dxl2;
+  const T rhs_last = (slope_2 * dxl + slope_1 * dxl2) * three;
+  const T k1_first = A.rfull[l] + A.bP[0] * A.carry[l];
+  const T k1_last = A.rfull[(m - 1) * L + l] + A.bP[m - 1] * A.carry[((m - 1) / A.S) * L + l];
+  A.ends[l] = (rhs_last - k1_first * dxl2 - k1_last * dxl) / A.per_den;
+}
+
+// a / b (:354-365) with k[i] = k1[i] + k_{n-2} k2[i] (i < m), k[m] = k_{n-2}, k[n-1] = k[0]
+template <class T>
+__global__ __launch_bounds__(BLOCK) void spline_periodic_finish_kernel(BuildArgs<T> A) {
+  const uint64_t n = A.n, L = A.lanes, m = n - 2, total = (n - 1) * L;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t i = e / L, l = e - i * L;
+    const T km1 = A.ends[l];
+    auto kval = [&](uint64_t j) -> T {
+      if (j == n - 1) j = 0;
+      if (j == m) return km1;
+      const T k1 = A.rfull[j * L + l] + const_load(A.bP, j) * A.carry[(j / A.S) * L + l];
+      return k1 + km1 * const_load(A.k2, j);
+    };
+    const T k0 = kval(i), k1v = kval(i + 1);
+    const T dy = A.data[e + L] - A.data[e];
+    const T dxi = const_load(A.dx, i);
+    A.ca[e] = k0 * dxi - dy;
+    A.cb[e] = dy - k1v * dxi;
   }
 }
 

@@ -590,8 +590,10 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 //   NDI_SHORT_ROWB   auto: the grouped form is taken from rows of this many bytes upwards
 //   NDI_FUSED_PACK   interval-packed table copy for the fused kernel: -1 = rows shorter than a cache line,
 //                    0 = never, 1 = always
+//   NDI_FUSED_MAXLV  the gather formulation of rows of fewer than this many 16-byte vectors is the fused kernel
+//                    (longer rows: locate_kernel + eval_rows_kernel)
 struct ShortKnobs {
-  int mode = 0, unr = 2, tb = 0, lds = -1, wgs = 0, cq = 64, rowb = 1024, pack = -1;
+  int mode = 0, unr = 2, tb = 0, lds = -1, wgs = 0, cq = 64, rowb = 1024, pack = -1, maxlv = 256;
   static int env(const char* name, int dflt) {
     const char* e = std::getenv(name);
     return e && *e ? std::atoi(e) : dflt;
@@ -606,6 +608,7 @@ struct ShortKnobs {
     k.cq = env("NDI_SHORT_CQ", k.cq);
     k.rowb = env("NDI_SHORT_ROWB", k.rowb);
     k.pack = env("NDI_FUSED_PACK", k.pack);
+    k.maxlv = env("NDI_FUSED_MAXLV", k.maxlv);
     return k;
   }
 };
@@ -769,14 +772,16 @@ struct Interp1DImpl final : Interp1DBase {
     static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
     static const int blocked_once = ShortKnobs::env("NDI_SPLINE_BLOCKED", -1);
     const int blocked_env = tune_live ? ShortKnobs::env("NDI_SPLINE_BLOCKED", -1) : blocked_once;
-    const bool blocked = P.mode == SPLINE_GENERAL && n >= 16 &&
+    const bool blocked = (P.mode == SPLINE_GENERAL || P.mode == SPLINE_PERIODIC) && n >= 16 &&
                          (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256));
     if (blocked) {
+      const bool per = P.mode == SPLINE_PERIODIC;
+      const uint64_t rows = per ? n - 2 : n;   // order of the system the two sweeps run over
       uint64_t S = 64;
-      while (S * S < n && S < 2048) S *= 2;          // ~sqrt(n) rows per block: local sweeps and carry chain balance
+      while (S * S < rows && S < 2048) S *= 2;       // ~sqrt(n) rows per block: local sweeps and carry chain balance
       // one scratch allocation: [fP | dco | bP | rfull | ends | carry]; the coefficient products are formed on the
       // device from the plan already uploaded
-      const uint64_t nblk = (n + S - 1) / S;
+      const uint64_t nblk = (rows + S - 1) / S;
       DevBuf scratch;
       scratch.reserve((3 * (size_t)n + (size_t)n * lanes + 2 * (size_t)nblk * lanes) * sizeof(T));
       T* sp = scratch.as<T>();
@@ -788,19 +793,31 @@ struct Interp1DImpl final : Interp1DBase {
       A.carry = A.ends + nblk * lanes;
       A.S = S;
       A.nblocks = nblk;
+      A.rows = rows;
       const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * lanes + BLOCK - 1) / BLOCK, 65536));
       const unsigned gl = (unsigned)((nblk * lanes + BLOCK - 1) / BLOCK);
       hipLaunchKernelGGL(spline_blocked_coef_kernel<T>, dim3((unsigned)((nblk + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
-                         A.w, A.up, A.midp, sp, sp + n, sp + 2 * n, n, S, nblk);
-      hipLaunchKernelGGL((spline_rhs_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, s, A);
+                         A.w, A.up, A.midp, sp, sp + n, sp + 2 * n, rows, S, nblk);
+      if (per) hipLaunchKernelGGL(spline_periodic_rhs_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, A);
+      else hipLaunchKernelGGL((spline_rhs_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, s, A);
       hipLaunchKernelGGL(spline_blocked_local_kernel<T>, dim3(gl), dim3(BLOCK), 0, s, A, 0);
       hipLaunchKernelGGL(spline_blocked_carry_kernel<T>, dim3(grid), dim3(64), 0, s, A, 0);
       hipLaunchKernelGGL(spline_blocked_fix_forward_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, A);
       hipLaunchKernelGGL(spline_blocked_local_kernel<T>, dim3(gl), dim3(BLOCK), 0, s, A, 1);
       hipLaunchKernelGGL(spline_blocked_carry_kernel<T>, dim3(grid), dim3(64), 0, s, A, 1);
-      hipLaunchKernelGGL(spline_blocked_finish_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, A);
+      if (per) {
+        hipLaunchKernelGGL(spline_periodic_km1_kernel<T>, dim3(grid), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(spline_periodic_finish_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, A);
+      } else {
+        hipLaunchKernelGGL(spline_blocked_finish_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, A);
+      }
       NDI_HIP(hipGetLastError());
-      NDI_HIP(hipDeviceSynchronize());   // the scratch above is freed on return
+      StatusBlock hs{};
+      NDI_HIP(hipMemcpy(&hs, status.p, sizeof(hs), hipMemcpyDeviceToHost));   // synchronises; the scratch is freed on return
+      if (hs.periodic_mismatch != 0)
+        return fail(NDI_VALUE,
+                    "for periodic boundary condition the first and last value must be equal "
+                    "(%llu lane(s) differ)", hs.periodic_mismatch);
       if (mode != EX_NO && periodic) mode = EX_PERIODIC;
       return NDI_OK;
     }
@@ -1023,8 +1040,8 @@ struct Interp1DImpl final : Interp1DBase {
     const ShortKnobs K = short_knobs();
     // rows shorter than one workgroup pass (or unaligned): grouped from a few hundred bytes per row upwards when the
     // batch has enough queries per interval, else query order with the search fused in
-    const bool short_rows = !rows_ok;
-    const bool group_ok = nq < 0xffffffffull && P.vec_ok && lds_sort_fits(pyr, n - 1);
+    const bool short_rows = !rows_ok || (P.vec_ok && P.LV < (uint64_t)K.maxlv);
+    const bool group_ok = nq < 0xffffffffull && P.vec_ok && P.LV < (uint64_t)BLOCK && lds_sort_fits(pyr, n - 1);
     bool bucketed = false, grouped_short = false;
     if (path == NDI_PATH_BUCKETED) {
       bucketed = rows_ok && nq < 0xffffffffull;
@@ -1034,7 +1051,7 @@ struct Interp1DImpl final : Interp1DBase {
       grouped_short = short_rows && group_ok && nq >= 5 * (n - 1) &&
                       (K.mode == 3 || (K.mode == 0 && lanes * sizeof(T) >= (uint64_t)K.rowb));
     }
-    if (short_rows && !grouped_short && K.mode != 1 && K.mode != 3 && plan_fused(s, sc, P, K)) return P;
+    if (short_rows && !grouped_short && !bucketed && K.mode != 1 && K.mode != 3 && plan_fused(s, sc, P, K)) return P;
     g_last_path.store(bucketed || grouped_short ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
     sc.idx.reserve(nq * sizeof(uint32_t));   // the two-kernel forms: interval index (and t) per query
     if (strategy == NDI_CUBIC_SPLINE) sc.t.reserve(nq * sizeof(T));

@@ -54,14 +54,17 @@ def test_blocked_build_tables_and_rows_within_the_bar(pkg, dt, kind, n, L):
     y = rng.uniform(-1.0, 1.0, (n, L)).astype(dt)
     q = rng.uniform(x[0], x[-1], 20_000).astype(dt)
     q[:2] = [x[0], x[-1]]
+    y0 = y
     for name, (per, left, right) in BCS.items():
-        if per:
-            continue                      # periodic keeps its own (serial, bit-exact) kernel
-        st, ra, rb = oracle.cubic_build(x, y, left=left, right=right)
+        y = y0
+        if per:                           # the condensed (n - 2) system through the same blocked sweeps
+            y = y0.copy(); y[-1] = y[0]
+        bc = pkg.BoundaryCondition.Periodic if per else _bc(pkg, L, left, right)
+        st, ra, rb = oracle.cubic_build(x, y, periodic=per, left=left, right=right)
         assert st == oracle.OK
         _, _, ref = oracle.interp1d_cubic(x, y, ra, rb, q)
         with blocked(None):               # default: this shape takes the blocked sweeps
-            it = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().boundary(_bc(pkg, L, left, right))).build()
+            it = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().boundary(bc)).build()
         a, b = it.strategy.coefficients()
         table_close(a, ra, dt, f"a[{name}] {kind} n={n} L={L}")
         table_close(b, rb, dt, f"b[{name}] {kind} n={n} L={L}")
@@ -72,7 +75,7 @@ def test_blocked_build_tables_and_rows_within_the_bar(pkg, dt, kind, n, L):
         assert_rel(got, ref.astype(np.float64), tol * float(np.max(np.abs(y))), tol, f"rows [{name}] {kind} n={n} L={L}")
         assert np.array_equal(got[:2], y[[0, -1]].astype(np.float64).reshape(2, -1)), "knot hits return the data rows"
         with blocked(0):                  # the serial kernels on the same shape: bit-identical again
-            it0 = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().boundary(_bc(pkg, L, left, right))).build()
+            it0 = pkg.Interp1DBuilder.new(y).x(x).strategy(pkg.CubicSpline.new().boundary(bc)).build()
         a0, b0 = it0.strategy.coefficients()
         check_equal(a0, ra, f"serial a[{name}] n={n} L={L}")
         check_equal(b0, rb, f"serial b[{name}] n={n} L={L}")
@@ -93,3 +96,12 @@ def test_blocked_build_forced_on_small_and_wide_shapes(pkg, dt):
                 a, b = it.strategy.coefficients()
                 table_close(a, ra, dt, f"a n={n} L={L} {left} {right}")
                 table_close(b, rb, dt, f"b n={n} L={L} {left} {right}")
+            yp = y.copy(); yp[-1] = yp[0]
+            st, ra, rb = oracle.cubic_build(x, yp, periodic=True)
+            it = pkg.Interp1DBuilder.new(yp).x(x).strategy(pkg.CubicSpline.new().boundary(pkg.BoundaryCondition.Periodic)).build()
+            a, b = it.strategy.coefficients()
+            table_close(a, ra, dt, f"periodic a n={n} L={L}")
+            table_close(b, rb, dt, f"periodic b n={n} L={L}")
+            yp[-1] += 1.0                 # y[0] != y[n-1]: BuilderError::ValueError (cubic_spline.rs:501-507)
+            with pytest.raises(pkg.BuilderError.ValueError):
+                pkg.Interp1DBuilder.new(yp).x(x).strategy(pkg.CubicSpline.new().boundary(pkg.BoundaryCondition.Periodic)).build()

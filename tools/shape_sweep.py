@@ -1,4 +1,6 @@
-"""Sweep of row lengths: effective output rate of both formulations (finds weak launch shapes)."""
+"""Sweep of row lengths: effective output rate of both formulations and of what AUTO picks (finds weak launch
+shapes).  1024 random knots, CubicSpline, 4 GB of device-resident output per call; "out" = output bytes / wall time of
+the whole interp_array_into call, "alg" = the 40 B/point (5 x sizeof T) gather model of SURVEY 8(d)."""
 import sys, os, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
@@ -18,7 +20,7 @@ for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
         qd = (torch.rand(Q, dtype=tdt, device=dev) * (xd[-1] - xd[0]) * 0.999 + xd[0]).clamp(xd[0], xd[-1])
         out = torch.empty((Q, L), dtype=tdt, device=dev)
         line = f"{np.dtype(dt).name} L={L:6d} Q={Q:10d}"
-        for name, path in (("gather", pkg.PATH_GATHER), ("bucketed", pkg.PATH_BUCKETED)):
+        for name, path in (("gather", pkg.PATH_GATHER), ("bucketed", pkg.PATH_BUCKETED), ("auto", pkg.PATH_AUTO)):
             interp.strategy.path = path
             interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
             torch.cuda.synchronize()

@@ -8,6 +8,7 @@
 // Compiled with -ffp-contract=off like the device code: rustc never fuses a*b+c.
 #pragma once
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -133,11 +134,11 @@ inline void specialize_end(int kind, double val, int& out_kind, double& out_val)
 
 // Forward elimination of CubicSpline::thomas on the diagonals alone (:690-692).
 template <class T>
-void eliminate(const std::vector<T>& up, const std::vector<T>& mid, const std::vector<T>& low,
+void eliminate(const std::vector<T>& up, std::vector<T>& mid, const std::vector<T>& low,
                std::vector<T>& w, std::vector<T>& midp) {
   const size_t m = mid.size();
   w.assign(m, T(0));
-  midp = mid;
+  midp = std::move(mid);   // (the caller is done with the uneliminated diagonal)
   for (size_t i = 1; i < m; ++i) {
     w[i] = low[i] / midp[i - 1];
     midp[i] -= w[i] * up[i - 1];
@@ -195,13 +196,13 @@ SplinePlan<T> make_spline_plan(const T* x, uint64_t n, bool periodic, int lkind,
     mid[0] = two * (dxl + dx0);
     up[0] = dxl;
     P.m = m;
-    P.up = up;
-    eliminate(up, mid, low, P.w, P.midp);
+    P.up = std::move(up);
+    eliminate(P.up, mid, low, P.w, P.midp);
     std::vector<T> rhs2(m, T(0));
     const T dx_3 = x[n - 3] - x[n - 4];
     rhs2[0] = -dx0;
     rhs2[m - 1] = -dx_3;
-    P.k2 = thomas_host(up, P.w, P.midp, rhs2);
+    P.k2 = thomas_host(P.up, P.w, P.midp, rhs2);
     P.per_den = P.k2[0] * dxl2 + P.k2[m - 1] * dxl + two * (dxl + dxl2);
     return P;
   }
@@ -246,8 +247,8 @@ SplinePlan<T> make_spline_plan(const T* x, uint64_t n, bool periodic, int lkind,
     }
   }
   P.m = n;
-  P.up = up;
-  eliminate(up, mid, low, P.w, P.midp);
+  P.up = std::move(up);
+  eliminate(P.up, mid, low, P.w, P.midp);
   return P;
 }
 

@@ -1885,6 +1885,18 @@ struct BuildArgs {
 // precomputed elimination plan (what solve_for_k_individual :370-403 does one column at a time).
 constexpr int SB = 16;
 
+// dx[i] = x[i+1] - x[i] (i < n - 1) and the upper diagonal of the system being swept -- up[0] and up[len - 1] are
+// boundary-specific scalars from the host plan, up[i] = x[i] - x[i-1] between them (cubic_spline.rs:440-451) -- formed on
+// the device from the knots that are already there (the host plan states the same subtractions in T: host_logic.hpp).
+template <class T>
+__global__ __launch_bounds__(BLOCK) void spline_dx_up_kernel(const T* x, T* dx, T* up, uint64_t n, uint64_t up_len,
+                                                             T up_first, T up_last) {
+  for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+    if (i + 1 < n) dx[i] = x[i + 1] - x[i];
+    if (i < up_len) up[i] = (i == 0) ? up_first : ((i + 1 == up_len) ? up_last : x[i] - x[i - 1]);
+  }
+}
+
 template <class T, bool PER_LANE>
 __global__ __launch_bounds__(BLOCK) void spline_rhs_kernel(BuildArgs<T> A) {
   const uint64_t n = A.n, L = A.lanes;

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cmath>
 #include <cstdlib>
@@ -643,6 +644,21 @@ static ndi_status check_ring_desc(const ndi_ring_desc* ring, uint64_t lanes, uin
 // ---------------------------------------------------------------------------------------------
 // Interp1D
 // ---------------------------------------------------------------------------------------------
+// NDI_BUILD_TIMING=1: wall-clock milestones of create() on stderr (where a build's milliseconds go: tools/build_probe.py)
+struct BuildClock {
+  bool on;
+  std::chrono::steady_clock::time_point t0, last;
+  BuildClock() : on(std::getenv("NDI_BUILD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), last(t0) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[ndi build] %-28s +%8.3f ms  (%8.3f)\n", what,
+                 std::chrono::duration<double, std::milli>(now - last).count(),
+                 std::chrono::duration<double, std::milli>(now - t0).count());
+    last = now;
+  }
+};
+
 // What makes two handles replicas of ONE interpolator beyond element type and lanes: knot count and values,
 // strategy, extrapolation mode.  (Data and coefficient tables live on the devices and are not compared.)
 static uint64_t fnv1a(uint64_t h, const void* p, size_t bytes) {
@@ -717,41 +733,63 @@ struct Interp1DImpl final : Interp1DBase {
       return build_spline_individual(d);
     }
     const bool periodic = d.periodic != 0;
+    BuildClock clk;
     SplinePlan<T> P = make_spline_plan<T>(pyr.host_knots.data(), n, periodic, d.left.kind,
                                           d.left.value, d.right.kind, d.right.value);
+    clk.mark("  host plan");
     const size_t tab = (size_t)(n - 1) * lanes * sizeof(T);
     ca.reserve(tab);
     cb.reserve(tab);
-    // scalars of the plan, packed into one upload: dx | up | w | midp | k2
-    const size_t m = P.m;
-    std::vector<T> pack;
-    pack.reserve(P.dx.size() + P.up.size() + P.w.size() + P.midp.size() + P.k2.size());
-    pack.insert(pack.end(), P.dx.begin(), P.dx.end());
-    const size_t o_up = pack.size();
-    pack.insert(pack.end(), P.up.begin(), P.up.end());
-    const size_t o_w = pack.size();
-    pack.insert(pack.end(), P.w.begin(), P.w.end());
-    const size_t o_mid = pack.size();
-    pack.insert(pack.end(), P.midp.begin(), P.midp.end());
-    const size_t o_k2 = pack.size();
-    pack.insert(pack.end(), P.k2.begin(), P.k2.end());
-    (void)m;
-    DevBuf plan;
-    plan.reserve(std::max<size_t>(pack.size(), 1) * sizeof(T));
-    NDI_HIP(hipMemcpy(plan.p, pack.data(), pack.size() * sizeof(T), hipMemcpyHostToDevice));
-    DevBuf status;
-    status.reserve(sizeof(StatusBlock));
-    NDI_HIP(hipMemset(status.p, 0, sizeof(StatusBlock)));
+    // Blocked sweeps or serial kernels?  Narrow trailing axes with many knots: the per-lane serial kernel would be one
+    // or two waves doing 2n dependent steps.  The blocked sweeps (kernels.hpp, spline_blocked_*) take over -- the one
+    // path whose tables are not bit-identical to the reference order (a few ulp; NDI_SPLINE_BLOCKED=0 keeps the serial
+    // kernels, =1 forces the blocked ones wherever they apply).
+    static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
+    static const int blocked_once = ShortKnobs::env("NDI_SPLINE_BLOCKED", -1);
+    const int blocked_env = tune_live ? ShortKnobs::env("NDI_SPLINE_BLOCKED", -1) : blocked_once;
+    const bool blocked = (P.mode == SPLINE_GENERAL || P.mode == SPLINE_PERIODIC) && n >= 16 &&
+                         (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256));
+    const bool per = P.mode == SPLINE_PERIODIC;
+    const uint64_t rows = per ? n - 2 : n;   // order of the system the two sweeps run over
+    uint64_t S = 64;
+    while (S * S < rows && S < 2048) S *= 2;         // ~sqrt(n) rows per block: local sweeps and carry chain balance
+    const uint64_t nblk = (rows + S - 1) / S;
+    // ONE temporary allocation (one hipMalloc, one hipFree -- each costs as much as the kernels of a small build):
+    //   [status | dx (n) | up (n) | w (n) | mid' (n) | k2 (n) | blocked: fP | dco | bP | rfull | ends | carry]
+    // dx and up are formed on the device from the knots already there (the same subtractions in T as the host plan's);
+    // w, mid' and k2 -- the results of the host's division chain -- are uploaded straight from their vectors.
+    const size_t plan_elems = 5 * (size_t)n;
+    const size_t blk_elems = blocked ? 3 * (size_t)n + (size_t)n * lanes + 2 * (size_t)nblk * lanes : 0;
+    DevBuf tmp;
+    tmp.reserve(256 + (plan_elems + blk_elems) * sizeof(T));
+    NDI_HIP(hipMemsetAsync(tmp.p, 0, sizeof(StatusBlock), nullptr));
+    T* const plan = reinterpret_cast<T*>((char*)tmp.p + 256);
+    T* const d_dx = plan;
+    T* const d_up = plan + n;
+    T* const d_w = plan + 2 * (size_t)n;
+    T* const d_mid = plan + 3 * (size_t)n;
+    T* const d_k2 = plan + 4 * (size_t)n;
+    if (!P.w.empty()) NDI_HIP(hipMemcpyAsync(d_w, P.w.data(), P.w.size() * sizeof(T), hipMemcpyHostToDevice, nullptr));
+    if (!P.midp.empty()) NDI_HIP(hipMemcpyAsync(d_mid, P.midp.data(), P.midp.size() * sizeof(T), hipMemcpyHostToDevice, nullptr));
+    if (!P.k2.empty()) NDI_HIP(hipMemcpyAsync(d_k2, P.k2.data(), P.k2.size() * sizeof(T), hipMemcpyHostToDevice, nullptr));
+    {
+      const uint64_t up_len = P.up.size();
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + BLOCK - 1) / BLOCK, 4096));
+      hipLaunchKernelGGL(spline_dx_up_kernel<T>, dim3(g), dim3(BLOCK), 0, (hipStream_t) nullptr, (const T*)pyr.view.lv0, d_dx, d_up,
+                         n, up_len, up_len ? P.up[0] : T(0), up_len ? P.up[up_len - 1] : T(0));
+      NDI_HIP(hipGetLastError());
+    }
+    clk.mark("  tables alloc + plan upload");
 
     BuildArgs<T> A{};
     A.data = data.as<T>();
     A.ca = ca.as<T>();
     A.cb = cb.as<T>();
-    A.dx = plan.as<T>();
-    A.up = plan.as<T>() + o_up;
-    A.w = plan.as<T>() + o_w;
-    A.midp = plan.as<T>() + o_mid;
-    A.k2 = plan.as<T>() + o_k2;
+    A.dx = d_dx;
+    A.up = d_up;
+    A.w = d_w;
+    A.midp = d_mid;
+    A.k2 = d_k2;
     A.n = n;
     A.lanes = lanes;
     A.left_kind = P.left_kind;
@@ -762,29 +800,11 @@ struct Interp1DImpl final : Interp1DBase {
     A.nkR_tmp1 = P.nkR_tmp1; A.nkR_d = P.nkR_d;
     A.dx0_sq = P.dx0_sq; A.dxl_sq = P.dxl_sq;
     A.per_den = P.per_den;
-    A.status = status.as<StatusBlock>();
+    A.status = tmp.as<StatusBlock>();
     const unsigned grid = (unsigned)((lanes + 63) / 64);
     hipStream_t s = nullptr;
-    // Narrow trailing axes with many knots: the per-lane serial kernel would be one or two waves doing 2n dependent
-    // steps.  The blocked sweeps (kernels.hpp, spline_blocked_*) take over -- the one path whose tables are not
-    // bit-identical to the reference order (a few ulp; NDI_SPLINE_BLOCKED=0 keeps the serial kernels, =1 forces the
-    // blocked ones wherever they apply).
-    static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
-    static const int blocked_once = ShortKnobs::env("NDI_SPLINE_BLOCKED", -1);
-    const int blocked_env = tune_live ? ShortKnobs::env("NDI_SPLINE_BLOCKED", -1) : blocked_once;
-    const bool blocked = (P.mode == SPLINE_GENERAL || P.mode == SPLINE_PERIODIC) && n >= 16 &&
-                         (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256));
     if (blocked) {
-      const bool per = P.mode == SPLINE_PERIODIC;
-      const uint64_t rows = per ? n - 2 : n;   // order of the system the two sweeps run over
-      uint64_t S = 64;
-      while (S * S < rows && S < 2048) S *= 2;       // ~sqrt(n) rows per block: local sweeps and carry chain balance
-      // one scratch allocation: [fP | dco | bP | rfull | ends | carry]; the coefficient products are formed on the
-      // device from the plan already uploaded
-      const uint64_t nblk = (rows + S - 1) / S;
-      DevBuf scratch;
-      scratch.reserve((3 * (size_t)n + (size_t)n * lanes + 2 * (size_t)nblk * lanes) * sizeof(T));
-      T* sp = scratch.as<T>();
+      T* sp = plan + plan_elems;     // [fP | dco | bP | rfull | ends | carry]; the coefficient products are formed on the device
       A.fP = sp;
       A.dco = sp + n;
       A.bP = sp + 2 * n;
@@ -813,7 +833,8 @@ struct Interp1DImpl final : Interp1DBase {
       }
       NDI_HIP(hipGetLastError());
       StatusBlock hs{};
-      NDI_HIP(hipMemcpy(&hs, status.p, sizeof(hs), hipMemcpyDeviceToHost));   // synchronises; the scratch is freed on return
+      NDI_HIP(hipMemcpy(&hs, tmp.p, sizeof(hs), hipMemcpyDeviceToHost));   // synchronises; the scratch is freed on return
+      clk.mark("  blocked sweeps");
       if (hs.periodic_mismatch != 0)
         return fail(NDI_VALUE,
                     "for periodic boundary condition the first and last value must be equal "
@@ -840,7 +861,7 @@ struct Interp1DImpl final : Interp1DBase {
     }
     NDI_HIP(hipGetLastError());
     StatusBlock hs{};
-    NDI_HIP(hipMemcpy(&hs, status.p, sizeof(hs), hipMemcpyDeviceToHost));  // synchronises
+    NDI_HIP(hipMemcpy(&hs, tmp.p, sizeof(hs), hipMemcpyDeviceToHost));  // synchronises
     if (hs.periodic_mismatch != 0)
       return fail(NDI_VALUE,
                   "for periodic boundary condition the first and last value must be equal "
@@ -1722,7 +1743,9 @@ static ndi_status create1d(const ndi_interp1d_desc& d, Interp1DBase** out) {
   h->mode = d.extrapolate ? EX_YES : EX_NO;
   h->n = d.n;
   h->lanes = d.lanes;
+  BuildClock clk;
   std::vector<T> x = d.x ? fetch_axis<T>(d.x, d.x_len, d.memspace) : default_axis<T>(d.n);
+  clk.mark("fetch axis");
   const uint64_t x_len = d.x ? d.x_len : d.n;
   if (d.validate) {
     ndi_status st = check_axis_1d<T>(x.data(), x_len, d.n, d.strategy);
@@ -1734,14 +1757,18 @@ static ndi_status create1d(const ndi_interp1d_desc& d, Interp1DBase** out) {
   if (d.lanes == 0) return fail(NDI_BAD_ARG, "lanes must be >= 1");
   if (d.n > MAX_KNOTS) return fail(NDI_UNSUPPORTED, "more than %llu knots", (unsigned long long)MAX_KNOTS);
   if (!d.data) return fail(NDI_BAD_ARG, "null data pointer");
+  clk.mark("validate");
   h->pyr.upload(x.data(), d.n);
+  clk.mark("knot pyramid");
   const size_t bytes = (size_t)d.n * d.lanes * sizeof(T);
   h->data.reserve(bytes);
   NDI_HIP(hipMemcpy(h->data.p, d.data, bytes,
                     d.memspace == NDI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  clk.mark("data copy");
   if (d.strategy == NDI_CUBIC_SPLINE) {
     ndi_status st = h->build_spline(d);
     if (st != NDI_OK) return st;
+    clk.mark("build_spline");
   }
   *out = h.release();
   return NDI_OK;

@@ -1540,7 +1540,12 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
 // with its own 74 KiB tile, the same 16 waves per CU but no shared barriers -- was measured at C3 and is SLOWER
 // (1.54 vs 1.17 ms, profiles/r04_c3_tiles_ab.jsonl: twice the tile staging per CU and half the rows per trip); it
 // stays selectable with NDI_TILE_WG=512 for A/B runs.
-template <class T, int VEC, int TB, int RB = TB, int MAXI = 6, bool COMPACT = false>
+// SLOPE: the x-direction slopes m = (z[x+1][y] - z[x][y]) / (kx[x+1] - kx[x]) of every grid point of the tile are formed
+// ONCE when the tile is staged (IEEE division, the reference's operands and operation: linear.rs:33) and kept in LDS
+// next to the values: a query then needs ONE division per channel (the y direction, whose operands depend on the
+// query) instead of three -- the same bits, because the slope of a grid cell does not depend on the query.  At C3
+// (2.4 queries per cell) the tile kernel is bound by the arithmetic of those divisions.
+template <class T, int VEC, int TB, int RB = TB, int MAXI = 6, bool COMPACT = false, bool SLOPE = false, int NREC = 1>
 __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A) {
   using V = typename VecT<T, VEC>::type;
   static_assert(RB <= TB, "the first RB threads of the workgroup load the records");
@@ -1551,7 +1556,8 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
   const uint32_t S = 1u << A.ts, S1 = S + 1u;
   const uint32_t LV = (uint32_t)(A.lanes / VEC);
   V* s_tile = reinterpret_cast<V*>(smem_raw);                              // [S1][S1][LV]
-  T* s_kx = reinterpret_cast<T*>(smem_raw + (size_t)S1 * S1 * LV * sizeof(V));   // [S1]
+  V* s_mx = s_tile + (size_t)S1 * S1 * LV;                                 // SLOPE: [S][S1][LV]
+  T* s_kx = reinterpret_cast<T*>(smem_raw + ((size_t)S1 * S1 + (SLOPE ? (size_t)S * S1 : 0)) * LV * sizeof(V));   // [S1]
   T* s_ky = s_kx + S1;
   T* s_rx = s_ky + S1;   // RN(1 / (kx[i+1] - kx[i])) per interval of the tile, 0 when the spacing is outside the
   T* s_ry = s_rx + S1;   // divisor window (then the IEEE division is used)
@@ -1663,6 +1669,20 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
       const TileGeo nxt = find_tile(cur.b + 1u);
       if (nxt.valid) prefetch(nxt);                 // in flight while this tile's records are evaluated
       __syncthreads();
+      if constexpr (SLOPE) {                        // the tile's values and knots are in LDS: form its x slopes
+        const uint32_t row_vecs = cur.cols * LV;
+        const uint32_t items = (cur.rows - 1u) * row_vecs;
+        for (uint32_t it = tid; it < items; it += TB) {
+          const uint32_t r = it / row_vecs, j = it - r * row_vecs;
+          const uint32_t o = r * S1 * LV + j;
+          // Linear::calc_frac's m (linear.rs:33) -- every vector of grid row r divides by the same knot spacing: the
+          // correctly rounded shared-divisor division (IEEE division outside its window), as in the evaluation
+          SharedDivisor<T> dx;
+          dx.d = s_kx[r + 1u] - s_kx[r]; dx.r = s_rx[r]; dx.ok = dx.r > T(0);
+          s_mx[o] = div_shared<T, V>(s_tile[o + S1 * LV] - s_tile[o], dx);
+        }
+        __syncthreads();
+      }
       // The tile's records are brought in TB at a time (one coalesced 16-byte load per thread) and handed to the
       // LV-lane groups through LDS; the next block's loads are in flight while the current block is evaluated, so a
       // workgroup pays one memory latency per 256 queries instead of one per trip.
@@ -1688,6 +1708,58 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
           r_in = A.rec_i[nxt_p + tid];
           if (!compact) { rx_in = A.rec_q[2 * (nxt_p + tid)]; ry_in = A.rec_q[2 * (nxt_p + tid) + 1]; }
         }
+        if constexpr (SLOPE) {
+          // (NREC records per thread and trip with their LDS reads issued together: measured equal for 1 and 2 at C3,
+          // profiles/r04_tuning.md -- the kernel is not bound by the LDS round trip per record)
+          struct Rec { bool live; uint64_t qi; T ddx, y, y1, dyd, ryr; V m1, m2, b1, b2; };
+          auto fetch = [&](uint32_t j) {
+            Rec R;
+            R.live = j < cnt;
+            const uint32_t jc = R.live ? j : 0u;
+            const uint4 r = s_rec[jc];
+            uint32_t xi, yi;
+            T x;
+            if (compact) {
+              if constexpr (std::is_same<T, float>::value) {
+                x = __builtin_bit_cast(float, r.z);
+                R.y = __builtin_bit_cast(float, r.w);
+              }
+              xi = r.y & 0xffffu;
+              yi = r.y >> 16;
+            } else {
+              x = s_rq[2 * jc];
+              R.y = s_rq[2 * jc + 1];
+              xi = r.y;
+              yi = r.z;
+            }
+            R.qi = NDI_CHK((uint64_t)r.x, A.nq, BC_QUERY);
+            R.live = R.live && R.qi < limit;
+            const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
+            const size_t zo = ((size_t)lx * S1 + ly) * LV + v;
+            R.m1 = s_mx[zo]; R.m2 = s_mx[zo + LV];
+            R.b1 = s_tile[zo]; R.b2 = s_tile[zo + LV];
+            R.ddx = x - s_kx[lx];
+            R.y1 = s_ky[ly];
+            R.dyd = s_ky[ly + 1u] - R.y1;
+            R.ryr = s_ry[ly];
+            return R;
+          };
+          auto finish = [&](const Rec& R) {
+            SharedDivisor<T> dy;
+            dy.d = R.dyd; dy.r = R.ryr; dy.ok = dy.r > T(0);
+            const V z1 = R.m1 * R.ddx + R.b1;   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
+            const V z2 = R.m2 * R.ddx + R.b2;
+            V* o = reinterpret_cast<V*>(A.out + R.qi * A.out_stride);
+            if (R.live) __builtin_nontemporal_store(frac_shared<T, V>(R.y1, z1, dy, z2, R.y), o + v);
+          };
+          for (uint32_t j = ql; j < cnt; j += (uint32_t)NREC * qpt) {
+            Rec R[NREC];
+#pragma unroll
+            for (int u = 0; u < NREC; ++u) R[u] = fetch(j + (uint32_t)u * qpt);
+#pragma unroll
+            for (int u = 0; u < NREC; ++u) finish(R[u]);
+          }
+        } else
         for (uint32_t j = ql; j < cnt; j += qpt) {
           const uint4 r = s_rec[j];
           uint32_t xi, yi;
@@ -1708,15 +1780,26 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
           const uint64_t qi = NDI_CHK((uint64_t)r.x, A.nq, BC_QUERY);
           if (qi >= limit) continue;
           const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
-          const V* z11 = s_tile + ((size_t)lx * S1 + ly) * LV + v;
-          const V a11 = z11[0], a12 = z11[LV], a21 = z11[(size_t)S1 * LV], a22 = z11[(size_t)S1 * LV + LV];
-          const T x1 = s_kx[lx], x2 = s_kx[lx + 1u], y1 = s_ky[ly], y2 = s_ky[ly + 1u];
+          const size_t zo = ((size_t)lx * S1 + ly) * LV + v;
+          const V* z11 = s_tile + zo;
+          const T y1 = s_ky[ly], y2 = s_ky[ly + 1u];
           V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
-          SharedDivisor<T> dx, dy;
-          dx.d = x2 - x1; dx.r = s_rx[lx]; dx.ok = dx.r > T(0);
+          SharedDivisor<T> dy;
           dy.d = y2 - y1; dy.r = s_ry[ly]; dy.ok = dy.r > T(0);
-          const V z1 = frac_shared<T, V>(x1, a11, dx, a21, x);   // bilinear.rs:88-97
-          const V z2 = frac_shared<T, V>(x1, a12, dx, a22, x);
+          V z1, z2;
+          if constexpr (SLOPE) {   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
+            const T x1 = s_kx[lx];
+            const T ddx = x - x1;
+            z1 = s_mx[zo] * ddx + z11[0];
+            z2 = s_mx[zo + LV] * ddx + z11[LV];
+          } else {
+            const V a11 = z11[0], a12 = z11[LV], a21 = z11[(size_t)S1 * LV], a22 = z11[(size_t)S1 * LV + LV];
+            const T x1 = s_kx[lx], x2 = s_kx[lx + 1u];
+            SharedDivisor<T> dx;
+            dx.d = x2 - x1; dx.r = s_rx[lx]; dx.ok = dx.r > T(0);
+            z1 = frac_shared<T, V>(x1, a11, dx, a21, x);   // bilinear.rs:88-97
+            z2 = frac_shared<T, V>(x1, a12, dx, a22, x);
+          }
           __builtin_nontemporal_store(frac_shared<T, V>(y1, z1, dy, z2, y), o + v);
         }
         pb = nxt_p;

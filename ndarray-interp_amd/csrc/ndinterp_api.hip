@@ -2039,19 +2039,33 @@ struct Interp2DImpl final : Interp2DBase {
       const size_t static512 = 256 * 16 + (P.compact ? 2 : 2 * 256) * sizeof(T) + 64;
       const bool two_wg = wg_env == 512 && tile_vecs <= 10 * 512 && 2 * (shm + static512) <= 160 * 1024 &&
                           (lanes / VNt) <= 512 && 512 % (lanes / VNt) == 0;
-#define NDI_TILES(TTB, RB, MX, CP)                                                                            \
+      // x slopes of the tile staged next to its values (one division per channel and query instead of three): needs a
+      // second tile-sized array in LDS, so the records are handed over 256 at a time.  NDI_TILE_SLOPES=0: A/B.
+      static const int slope_env = [] { const char* e = std::getenv("NDI_TILE_SLOPES"); return e ? std::atoi(e) : 1; }();
+      const size_t shm_slope = (s1 * s1 + (s1 - 1) * s1) * lanes * sizeof(T) + 4 * s1 * sizeof(T) + 16;
+      const bool slopes = slope_env != 0 && !two_wg && shm_slope + static512 <= 160 * 1024;
+      // ... 1024 at a time when that still fits (compact f32 records at C3: 143.9 KiB + 16 KiB)
+      const size_t static1024 = 1024 * 16 + (P.compact ? 2 : 2 * 1024) * sizeof(T) + 64;
+      const bool slopes_rb1024 = slopes && shm_slope + static1024 <= 160 * 1024 && slope_env != 256;
+#define NDI_TILES(TTB, RB, MX, CP, SL)                                                                        \
   do {                                                                                                        \
-    auto kern = eval_bilinear_tiles_kernel<T, VNt, TTB, RB, MX, CP>;                                          \
+    auto kern = eval_bilinear_tiles_kernel<T, VNt, TTB, RB, MX, CP, SL>;                                      \
     allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024 - RB * (16 + 2 * sizeof(T)) - 512)); \
-    launch1<T>(s, PC_EVAL, dim3(gx), dim3(TTB), shm, kern, A);                                                \
+    launch1<T>(s, PC_EVAL, dim3(gx), dim3(TTB), (SL) ? shm_slope : shm, kern, A);                             \
   } while (0)
       if constexpr (std::is_same<T, float>::value) {
         if (P.compact) {
-          if (two_wg) NDI_TILES(512, 256, 10, true); else NDI_TILES(1024, 1024, 6, true);
+          if (slopes_rb1024) NDI_TILES(1024, 1024, 6, true, true);
+          else if (slopes) NDI_TILES(1024, 256, 6, true, true);
+          else if (two_wg) NDI_TILES(512, 256, 10, true, false);
+          else NDI_TILES(1024, 1024, 6, true, false);
           return;
         }
       }
-      if (two_wg) NDI_TILES(512, 256, 10, false); else NDI_TILES(1024, 1024, 6, false);
+      if (slopes_rb1024) NDI_TILES(1024, 1024, 6, false, true);
+      else if (slopes) NDI_TILES(1024, 256, 6, false, true);
+      else if (two_wg) NDI_TILES(512, 256, 10, false, false);
+      else NDI_TILES(1024, 1024, 6, false, false);
 #undef NDI_TILES
       return;
     }

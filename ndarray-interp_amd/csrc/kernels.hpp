@@ -1299,6 +1299,8 @@ struct Eval2Args {
   // tiles of 2^ts x 2^ts cells, ntx x nty of them, `chunk` grouped positions per unit of work
   const uint32_t* bin_start;
   uint32_t nb, ts, nty, chunk;
+  const uint32_t* chunk_bin;   // [chunks] the tile that holds each chunk's first grouped position (tile_chunk_bins_kernel)
+  int debug;                   // NDI_TUNING builds only: bit 2 = no stores (measurement aid)
 };
 
 template <class T, bool LDS>
@@ -1339,6 +1341,22 @@ __global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* x
       rec_q[2 * (uint64_t)pos + 1] = y;
     }
   }
+}
+
+// For every chunk of `chunk` grouped positions the tile that holds its first position: the last b with
+// bin_start[b] <= c * chunk (bin_start[0] = 0).  One thread per chunk, part of the grouping stage.
+__global__ __launch_bounds__(BLOCK) void tile_chunk_bins_kernel(const uint32_t* bin_start, uint32_t nb, uint64_t n_pos,
+                                                                uint32_t chunk, uint32_t* chunk_bin) {
+  const uint64_t nchunks = (n_pos + chunk - 1) / chunk;
+  const uint64_t c = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= nchunks) return;
+  const uint64_t p0 = c * chunk;
+  uint32_t lo = 0, hi = nb;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((uint64_t)bin_start[mid] <= p0) lo = mid; else hi = mid;
+  }
+  chunk_bin[c] = lo;
 }
 
 // Pair-packed grid for short trailing axes: P[xi][yi] = { z[xi][yi], z[xi][yi+1] }, yi < ny-1.  The two
@@ -1550,7 +1568,8 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
   using V = typename VecT<T, VEC>::type;
   static_assert(RB <= TB, "the first RB threads of the workgroup load the records");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ uint32_t s_b0;
+  constexpr uint32_t BW = 64;                       // tiles whose start offsets are staged per chunk
+  __shared__ uint32_t s_bs[BW + 1];
   __shared__ uint4 s_rec[RB];
   __shared__ T s_rq[COMPACT ? 2 : 2 * RB];   // {qx, qy} of non-compact records (f64, or an axis with more than 65536 knots)
   const uint32_t S = 1u << A.ts, S1 = S + 1u;
@@ -1580,13 +1599,14 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
     if (c >= nchunks) break;
     const uint64_t p0 = c * A.chunk;
     const uint64_t p1 = (p0 + A.chunk < n_pos) ? p0 + A.chunk : n_pos;
-    if (tid == 0) {   // the tile that holds position p0: the last b with bin_start[b] <= p0
-      uint32_t lo = 0, hi = A.nb;   // invariant bin_start[lo] <= p0 (bin_start[0] = 0)
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if ((uint64_t)A.bin_start[mid] <= p0) lo = mid; else hi = mid;
-      }
-      s_b0 = lo;
+    // The tile that holds position p0 comes from tile_chunk_bins_kernel (a 14-step binary search by one thread, with the
+    // whole workgroup waiting, cost 6 % of the kernel at C3); the start offsets of the next BW tiles are staged in LDS
+    // with one coalesced load, so that finding the next non-empty tile is LDS reads, not dependent global loads.
+    __syncthreads();                                // (the previous chunk's window is no longer being read)
+    const uint32_t b0 = A.chunk_bin[c];
+    if (tid <= BW) {
+      const uint32_t bb = b0 + tid;
+      s_bs[tid] = (bb < A.nb) ? A.bin_start[bb] : (uint32_t)n_pos;   // (n_pos < 2^32: checked by the host)
     }
     __syncthreads();
     // Tiles are double-buffered through REGISTERS: while the records of the current tile are evaluated out of LDS,
@@ -1600,8 +1620,14 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
       TileGeo g{};
       g.valid = false;
       for (uint32_t bb = b_from; bb < A.nb; ++bb) {
-        const uint64_t bs = const_load(A.bin_start, bb);
-        const uint64_t be = (bb + 1u < A.nb) ? (uint64_t)const_load(A.bin_start, bb + 1u) : n_pos;
+        uint64_t bs, be;
+        if (bb - b0 < BW) {                         // inside the staged window (entry BW is the window's upper neighbour)
+          bs = s_bs[bb - b0];
+          be = s_bs[bb - b0 + 1u];
+        } else {
+          bs = const_load(A.bin_start, bb);
+          be = (bb + 1u < A.nb) ? (uint64_t)const_load(A.bin_start, bb + 1u) : n_pos;
+        }
         if (bs >= p1) break;
         const uint64_t lo = bs > p0 ? bs : p0, hi = be < p1 ? be : p1;
         if (lo >= hi) continue;                     // empty tile (workgroup-uniform)
@@ -1621,24 +1647,30 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
     auto prefetch = [&](const TileGeo& g) {
       const uint32_t row_vecs = g.cols * LV;        // one contiguous segment per grid row
       const uint32_t items = g.rows * row_vecs;
+      // Every thread issues exactly MAXI + 2 loads, whatever its share of the tile (indices are clamped, surplus values
+      // are dropped at the commit): with the loads under conditions the compiler cannot count the operations behind
+      // the record load that precedes them and waits for ALL of them -- the whole tile -- before the first records
+      // are handed over (vmcnt is in-order).
 #pragma unroll
       for (int k = 0; k < MAXI; ++k) {
         const uint32_t it = tid + (uint32_t)k * TB;
-        pre_off[k] = 0xffffffffu;
-        if (it < items) {
-          const uint32_t r = it / row_vecs, j = it - r * row_vecs;
-          const V* src = reinterpret_cast<const V*>(A.data + ((g.gx0 + r) * A.ny + g.gy0) * A.lanes);
-          pre[k] = src[j];
-          pre_off[k] = r * S1 * LV + j;
-        }
+        const bool mine = it < items;
+        const uint32_t itc = mine ? it : 0u;
+        const uint32_t r = itc / row_vecs, j = itc - r * row_vecs;
+        const V* src = reinterpret_cast<const V*>(A.data + ((g.gx0 + r) * A.ny + g.gy0) * A.lanes);
+        pre[k] = src[j];
+        pre_off[k] = mine ? r * S1 * LV + j : 0xffffffffu;
       }
-      // threads 0 .. rows-1 carry the x knots (and their right neighbours, for the spacing), 64 .. 64+cols-1 the y knots
-      if (tid < g.rows) {
-        pk0 = A.xk[g.gx0 + tid];
-        if (tid + 1u < g.rows) pk1 = A.xk[g.gx0 + tid + 1u];
-      } else if (tid >= 64u && tid - 64u < g.cols) {
-        pk0 = A.yk[g.gy0 + (tid - 64u)];
-        if (tid - 64u + 1u < g.cols) pk1 = A.yk[g.gy0 + (tid - 64u) + 1u];
+      // threads 0 .. rows-1 carry the x knots (and their right neighbours, for the spacing), 128 .. 128+cols-1 the y
+      // knots (a tile has at most 2^6 + 1 = 65 grid points per side)
+      {
+        const bool isy = tid >= 128u;
+        const uint32_t t = isy ? tid - 128u : tid;
+        const uint32_t len = isy ? g.cols : g.rows;
+        const T* kk = isy ? A.yk + g.gy0 : A.xk + g.gx0;
+        const uint32_t i0 = t < len ? t : len - 1u, i1 = t + 1u < len ? t + 1u : len - 1u;
+        pk0 = kk[i0];
+        pk1 = kk[i1];
       }
     };
     auto commit = [&](const TileGeo& g) {
@@ -1652,22 +1684,35 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
           const SharedDivisor<T> sd = shared_divisor<T>(pk1 - pk0);
           s_rx[tid] = sd.ok ? sd.r : T(0);
         }
-      } else if (tid >= 64u && tid - 64u < g.cols) {
-        s_ky[tid - 64u] = pk0;
-        if (tid - 64u + 1u < g.cols) {
+      } else if (tid >= 128u && tid - 128u < g.cols) {
+        s_ky[tid - 128u] = pk0;
+        if (tid - 128u + 1u < g.cols) {
           const SharedDivisor<T> sd = shared_divisor<T>(pk1 - pk0);
-          s_ry[tid - 64u] = sd.ok ? sd.r : T(0);
+          s_ry[tid - 128u] = sd.ok ? sd.r : T(0);
         }
       }
     };
-    TileGeo cur = find_tile(s_b0);
+    TileGeo cur = find_tile(b0);
     if (cur.valid) prefetch(cur);
     while (cur.valid) {
       const uint64_t gx0 = cur.gx0, gy0 = cur.gy0, lo = cur.lo, hi = cur.hi;
       __syncthreads();                              // the previous tile is no longer being read
       commit(cur);
+      // the tile's first block of records is requested BEFORE the next tile: the wait for it then leaves the
+      // MAXI + 2 loads of the prefetch outstanding (in-order vmcnt, static count) instead of draining them
+      constexpr bool compact = COMPACT;
+      const bool loader = (RB == TB) || tid < (uint32_t)RB;
+      uint64_t pb = lo;
+      uint4 r_in = make_uint4(0u, 0u, 0u, 0u);
+      T rx_in = T(0), ry_in = T(0);
+      {
+        const uint64_t pc = (loader && pb + tid < hi) ? pb + tid : lo;   // clamped: one load per thread, always
+        r_in = A.rec_i[pc];
+        if (!compact) { rx_in = A.rec_q[2 * pc]; ry_in = A.rec_q[2 * pc + 1]; }
+      }
       const TileGeo nxt = find_tile(cur.b + 1u);
-      if (nxt.valid) prefetch(nxt);                 // in flight while this tile's records are evaluated
+      prefetch(nxt.valid ? nxt : cur);              // in flight while this tile's records are evaluated (after the
+                                                    // chunk's last tile: the current one again, dropped -- never a branch)
       __syncthreads();
       if constexpr (SLOPE) {                        // the tile's values and knots are in LDS: form its x slopes
         const uint32_t row_vecs = cur.cols * LV;
@@ -1686,15 +1731,6 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
       // The tile's records are brought in TB at a time (one coalesced 16-byte load per thread) and handed to the
       // LV-lane groups through LDS; the next block's loads are in flight while the current block is evaluated, so a
       // workgroup pays one memory latency per 256 queries instead of one per trip.
-      constexpr bool compact = COMPACT;
-      const bool loader = (RB == TB) || tid < (uint32_t)RB;
-      uint64_t pb = lo;
-      uint4 r_in = make_uint4(0u, 0u, 0u, 0u);
-      T rx_in = T(0), ry_in = T(0);
-      if (loader && pb + tid < hi) {
-        r_in = A.rec_i[pb + tid];
-        if (!compact) { rx_in = A.rec_q[2 * (pb + tid)]; ry_in = A.rec_q[2 * (pb + tid) + 1]; }
-      }
       while (pb < hi) {
         const uint32_t cnt = (hi - pb < (uint64_t)RB) ? (uint32_t)(hi - pb) : (uint32_t)RB;
         __syncthreads();                            // the previous block's records are no longer being read
@@ -1750,6 +1786,13 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
             const V z1 = R.m1 * R.ddx + R.b1;   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
             const V z2 = R.m2 * R.ddx + R.b2;
             V* o = reinterpret_cast<V*>(A.out + R.qi * A.out_stride);
+#ifdef NDI_TUNING
+            if (A.debug & 4) {
+              const V r = frac_shared<T, V>(R.y1, z1, dy, z2, R.y);
+              if (R.live && r[0] == T(-123.456)) __builtin_nontemporal_store(r, o + v);
+              return;
+            }
+#endif
             if (R.live) __builtin_nontemporal_store(frac_shared<T, V>(R.y1, z1, dy, z2, R.y), o + v);
           };
           for (uint32_t j = ql; j < cnt; j += (uint32_t)NREC * qpt) {
@@ -1806,7 +1849,6 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
       }
       cur = nxt;
     }
-    __syncthreads();                                // s_b0 is rewritten by the next chunk
   }
 }
 

@@ -328,7 +328,7 @@ constexpr size_t FUSED_LDS_LIMIT = 160 * 1024;          // eval_fused_kernel wit
 // workspace carries two, so that the ring evaluation can locate + group chunk k+1 on a side stream while chunk k is
 // being evaluated (the set is handed back by the eval_done event).
 struct Scratch {
-  DevBuf idx, idx2, t, perm, counts, cursor, hist, status, recq;
+  DevBuf idx, idx2, t, perm, counts, cursor, hist, status, recq, chunkbin;
   hipEvent_t prep_done = nullptr, eval_done = nullptr;
   Scratch() = default;
   Scratch(const Scratch&) = delete;
@@ -1960,10 +1960,23 @@ struct Interp2DImpl final : Interp2DBase {
                            (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
                            slice, (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(),
                            nb, sx, sy, nty, sc.perm.as<uint4>(), sc.recq.as<T>());
+      {   // the tile each evaluation chunk starts in
+        const uint32_t chunk = tile_chunk();
+        const uint64_t nchunks = (nq + chunk - 1) / chunk;
+        sc.chunkbin.reserve(nchunks * sizeof(uint32_t));
+        hipLaunchKernelGGL(tile_chunk_bins_kernel, dim3((unsigned)((nchunks + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                           (const uint32_t*)sc.cursor.as<uint32_t>(), nb, nq, chunk, sc.chunkbin.as<uint32_t>());
+      }
       NDI_HIP(hipGetLastError());
       ps.done();
     }
     return P;
+  }
+
+  // grouped positions per unit of work of eval_bilinear_tiles_kernel (sweep: profiles/r03_c3_grouped.md)
+  static uint32_t tile_chunk() {
+    static const int chunk_env = [] { const char* e = std::getenv("NDI_TILE_CHUNK"); return e ? std::atoi(e) : 0; }();
+    return chunk_env > 0 ? (uint32_t)chunk_env : 8192u;
   }
 
   // AUTO for 2-D: tile-grouped order when the batch has enough queries per grid cell to pay for staging every
@@ -2024,8 +2037,12 @@ struct Interp2DImpl final : Interp2DBase {
       A.rec_q = P.compact ? nullptr : sc.recq.as<T>();
       A.bin_start = sc.cursor.as<uint32_t>();
       A.nb = P.nb; A.ts = P.ts; A.nty = P.nty;
-      static const int chunk_env = [] { const char* e = std::getenv("NDI_TILE_CHUNK"); return e ? std::atoi(e) : 0; }();
-      A.chunk = chunk_env > 0 ? (uint32_t)chunk_env : 8192u;   // grouped positions per unit of work (sweep: r03_c3_grouped.md)
+      A.chunk = tile_chunk();
+      A.chunk_bin = sc.chunkbin.as<uint32_t>();
+      A.debug = 0;
+#ifdef NDI_TUNING
+      A.debug = ShortKnobs::env("NDI_FUSED_DEBUG", 0);
+#endif
       const size_t s1 = ((size_t)1 << P.ts) + 1;
       const size_t shm = s1 * s1 * lanes * sizeof(T) + 4 * s1 * sizeof(T) + 16;
       const uint64_t nchunks = (nq + A.chunk - 1) / A.chunk;
@@ -2036,7 +2053,7 @@ struct Interp2DImpl final : Interp2DBase {
       // slower at C3 (1.54 vs 1.17 ms: twice the tile staging per CU, half the rows per trip).
       static const int wg_env = [] { const char* e = std::getenv("NDI_TILE_WG"); return e ? std::atoi(e) : 0; }();
       const size_t tile_vecs = s1 * s1 * (lanes / VNt);
-      const size_t static512 = 256 * 16 + (P.compact ? 2 : 2 * 256) * sizeof(T) + 64;
+      const size_t static512 = 256 * 16 + (P.compact ? 2 : 2 * 256) * sizeof(T) + 320;
       const bool two_wg = wg_env == 512 && tile_vecs <= 10 * 512 && 2 * (shm + static512) <= 160 * 1024 &&
                           (lanes / VNt) <= 512 && 512 % (lanes / VNt) == 0;
       // x slopes of the tile staged next to its values (one division per channel and query instead of three): needs a
@@ -2045,7 +2062,7 @@ struct Interp2DImpl final : Interp2DBase {
       const size_t shm_slope = (s1 * s1 + (s1 - 1) * s1) * lanes * sizeof(T) + 4 * s1 * sizeof(T) + 16;
       const bool slopes = slope_env != 0 && !two_wg && shm_slope + static512 <= 160 * 1024;
       // ... 1024 at a time when that still fits (compact f32 records at C3: 143.9 KiB + 16 KiB)
-      const size_t static1024 = 1024 * 16 + (P.compact ? 2 : 2 * 1024) * sizeof(T) + 64;
+      const size_t static1024 = 1024 * 16 + (P.compact ? 2 : 2 * 1024) * sizeof(T) + 320;
       const bool slopes_rb1024 = slopes && shm_slope + static1024 <= 160 * 1024 && slope_env != 256;
 #define NDI_TILES(TTB, RB, MX, CP, SL)                                                                        \
   do {                                                                                                        \

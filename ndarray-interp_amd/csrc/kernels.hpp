@@ -820,8 +820,12 @@ __global__ __launch_bounds__(BLOCK) void eval_flat_kernel(Eval1Args<T> A, uint32
 // whole batch is one sequential write stream, with no idx[] / t[] round trip through memory (12 B written + 12-20 B
 // re-read per query by the two-kernel form: a third of the traffic at 8 f64 lanes).  UNR trips are issued together:
 // scalars, then all 4 * UNR operand loads, then arithmetic and stores.
-// TLDS: the tables themselves (data, a, b) are staged in LDS once per workgroup -- when they fit (the reference's
+// TLDS == 1: the tables themselves (data, a, b) are staged in LDS once per workgroup -- when they fit (the reference's
 // bench shapes do many times over) the operand gathers never leave the CU.
+// TLDS == 2 (CubicSpline): {data, k} are staged instead -- two thirds of the bytes, so table sets up to 1.5 x larger
+// fit (8 f64 lanes on 1024 knots: 128 KiB) and smaller ones leave room for a second workgroup -- and every item
+// re-forms a = k[i] dx - dy, b = dy - k[i+1] dx (cubic_spline.rs:354-365) with the build's own operations in the
+// build's order (no contraction: -ffp-contract=off), i.e. the very bits the a / b tables hold.
 // The first failing query of the batch is known before the launch (range_check_kernel): rows at / after it are
 // never written, as in the reference's serial loop (interp1d/mod.rs:334-342).
 template <class T>
@@ -831,6 +835,7 @@ struct EvalFusedArgs {
   const T* data;
   const T* ca;
   const T* cb;
+  const T* ck;           // the derivatives k, [n][lanes] (TLDS == 2 only)
   const T* q;
   T* out;
   uint64_t nq, out_stride;
@@ -851,10 +856,12 @@ struct TabPtr { using type = const V*; };
 template <class V>
 struct TabPtr<V, true> { using type = const __attribute__((address_space(3))) V*; };
 
-template <class T, int STRAT, int VEC, int UNR, int TB, bool TLDS>
+template <class T, int STRAT, int VEC, int UNR, int TB, int TLDS>
 __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
+  static_assert(TLDS != 2 || STRAT == ST_CUBIC, "the {y, k} form is the spline's");
   using V = typename VecT<T, VEC>::type;
-  using tab_ptr = typename TabPtr<V, TLDS>::type;
+  using tab_ptr = typename TabPtr<V, TLDS != 0>::type;
+  constexpr bool STRIP2 = STRAT == ST_LINEAR || TLDS == 2;   // a second per-query scalar: (x - x1) / the interval's dx
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr uint32_t WAVES = TB / 64;
   const uint32_t tid = threadIdx.x;
@@ -881,11 +888,22 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
   T* w_c0 = reinterpret_cast<T*>(smem_raw + off) + (tid >> 6) * 64u;
   off += (size_t)WAVES * 64u * sizeof(T);
   T* w_c1 = reinterpret_cast<T*>(smem_raw + off) + (tid >> 6) * 64u;
-  off += (size_t)WAVES * 64u * sizeof(T);
+  if (STRIP2) off += (size_t)WAVES * 64u * sizeof(T);
   const uint32_t LV = A.lv;
   const uint32_t RS = TLDS ? LV : A.rec_stride;
   tab_ptr t_y, t_a, t_b;
-  if constexpr (TLDS) {
+  if constexpr (TLDS == 2) {
+    V* sy = reinterpret_cast<V*>(smem_raw + off);
+    const uint32_t ny = n * LV;
+    V* sk = sy + ny;
+    const V* gy = reinterpret_cast<const V*>(A.data);
+    const V* gk = reinterpret_cast<const V*>(A.ck);
+    for (uint32_t i = tid; i < ny; i += TB) sy[i] = gy[i];
+    for (uint32_t i = tid; i < ny; i += TB) sk[i] = gk[i];
+    t_y = (tab_ptr)(smem_raw + off);
+    t_a = t_y + ny;          // k
+    t_b = t_a;
+  } else if constexpr (TLDS == 1) {
     V* sy = reinterpret_cast<V*>(smem_raw + off);
     const uint32_t ny = n * LV, nab = (STRAT == ST_CUBIC) ? (n - 1u) * LV : 0u;
     V* sa = sy + ny;
@@ -935,6 +953,7 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
     w_i[lane] = NDI_CHK(i, n - 1u, BC_INTERVAL);
     if (STRAT == ST_CUBIC) {
       w_c0[lane] = (xs - xl) / (xr - xl);   // t, cubic_spline.rs:818
+      if (TLDS == 2) w_c1[lane] = xr - xl;  // dx of the interval, as the build formed it (spline_dx_up_kernel)
     } else {
       w_c0[lane] = xr - xl;                 // linear.rs:33-35: (x2 - x1), (x - x1)
       w_c1[lane] = x - xl;
@@ -957,7 +976,7 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
         v[k] = itc - ql[k] * LV;
         ii[k] = w_i[ql[k]];
         s0[k] = w_c0[ql[k]];
-        s1[k] = (STRAT == ST_LINEAR) ? w_c1[ql[k]] : T(0);
+        s1[k] = STRIP2 ? w_c1[ql[k]] : T(0);
       }
       V yl[UNR], yr[UNR], a[UNR], b[UNR];
 #pragma unroll
@@ -969,7 +988,10 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
         const uint32_t e = ii[k] * RS + v[k];
         yl[k] = t_y[e];
         yr[k] = t_y[e + LV];
-        if (STRAT == ST_CUBIC) {
+        if (TLDS == 2) {
+          a[k] = t_a[e];          // k[i], k[i+1]: a / b are re-formed below
+          b[k] = t_a[e + LV];
+        } else if (STRAT == ST_CUBIC) {
           a[k] = t_a[e];
           b[k] = t_b[e];
         } else {
@@ -989,6 +1011,14 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
           c.c0 = s0[k];
           c.c1 = s1[k];
           c.c2 = T(0);
+        }
+        if (TLDS == 2) {       // cubic_spline.rs:354-365, the operations of the build's epilogue
+          const V dy = yr[k] - yl[k];
+          const V dxv = V(s1[k]);
+          const V ak = a[k] * dxv - dy;
+          const V bk = dy - b[k] * dxv;
+          a[k] = ak;
+          b[k] = bk;
         }
         V* o = reinterpret_cast<V*>(o_base + (uint64_t)ql[k] * A.out_stride) + v[k];
 #ifdef NDI_TUNING
@@ -1989,6 +2019,9 @@ struct BuildArgs {
   const T* bP;      // [n] prod_{j = i .. block end} dco[j]
   uint64_t S, nblocks;
   uint64_t rows;    // rows of the system being swept (n; n - 2 for the condensed periodic system)
+  // the derivatives k themselves, [n][lanes] (nullptr: not kept).  Kept for table sets small enough that the
+  // query-order kernel can hold {y, k} in LDS and re-form a / b per item (eval_fused_kernel, TLDS == 2).
+  T* kout;
 };
 
 // SPLINE_GENERAL: rows 0 and n-1 from the boundary kinds (cubic_spline.rs:597-670), interior
@@ -2066,7 +2099,7 @@ __global__ __launch_bounds__(BLOCK) void spline_rhs_kernel(BuildArgs<T> A) {
   }
 }
 
-template <class T, bool PER_LANE>
+template <class T, bool PER_LANE, bool KOUT = false>
 __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A) {
   const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= A.lanes) return;
@@ -2138,6 +2171,7 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
   }
   const T r_last = rhs_last - w_last * r_prev;
   T k_next = r_last / mid_last;
+  if (KOUT) A.kout[(n - 1) * L + l] = k_next;
   T y_hi = y[(n - 1) * L];
   // ---- back substitution fused with a/b, rows n-2 .. 0, SB rows at a time, next block's loads in flight
   T ri_next[SB], yl_next[SB], up_next[SB], mid_next[SB], dx_next[SB];
@@ -2192,6 +2226,7 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
         const T dy = y_hi - yl[b];
         sa[i * L] = k * dxc[b] - dy;
         sb[i * L] = dy - k_next * dxc[b];
+        if (KOUT) A.kout[i * L + l] = k;
         k_next = k;
         y_hi = yl[b];
       }
@@ -2315,6 +2350,10 @@ __global__ __launch_bounds__(BLOCK) void spline_blocked_finish_kernel(BuildArgs<
     const T dxi = const_load(A.dx, i);
     A.ca[e] = k0 * dxi - dy;
     A.cb[e] = dy - k1 * dxi;
+    if (A.kout) {
+      A.kout[e] = k0;
+      if (i + 2 == A.n) A.kout[e + L] = k1;
+    }
   }
 }
 
@@ -2382,6 +2421,10 @@ __global__ __launch_bounds__(BLOCK) void spline_periodic_finish_kernel(BuildArgs
     const T dxi = const_load(A.dx, i);
     A.ca[e] = k0 * dxi - dy;
     A.cb[e] = dy - k1v * dxi;
+    if (A.kout) {
+      A.kout[e] = k0;
+      if (i + 2 == n) A.kout[e + L] = k1v;
+    }
   }
 }
 
@@ -2413,6 +2456,11 @@ __global__ __launch_bounds__(64) void spline_build_n3_kernel(BuildArgs<T> A, int
   A.cb[l] = (y1 - y0) - k1 * dx0;
   A.ca[L + l] = k1 * dx1 - (y2 - y1);
   A.cb[L + l] = (y2 - y1) - k2 * dx1;
+  if (A.kout) {
+    A.kout[l] = k0;
+    A.kout[L + l] = k1;
+    A.kout[2 * L + l] = k2;
+  }
 }
 
 // SPLINE_PERIODIC, n >= 4 (:498-565): condensed (n-2) system, k = k1 + k_{n-2} * k2.
@@ -2472,6 +2520,10 @@ __global__ __launch_bounds__(64) void spline_build_periodic_kernel(BuildArgs<T> 
     const T dxi = const_load(A.dx, i);
     sa[i * L] = k_i * dxi - dy;
     sb[i * L] = dy - k_r * dxi;
+    if (A.kout) {
+      A.kout[i * L + l] = k_i;
+      if (i + 2 == n) A.kout[(i + 1) * L + l] = k_r;
+    }
     k_i = k_r;
     y_lo = y_hi;
   }

@@ -691,6 +691,7 @@ struct Interp1DImpl final : Interp1DBase {
   uint64_t n = 0;
   DevicePyramid<T> pyr;
   DevBuf data, ca, cb;
+  DevBuf ck;   // the spline's derivatives k [n][lanes]: kept by builds whose {y, k} fit LDS (eval_fused_kernel, TLDS == 2)
   SpaceSet spaces;
   OwnedRing ring_own;
   // interval-packed copy of the tables for rows shorter than a cache line (pack_intervals_kernel), built on first
@@ -720,6 +721,18 @@ struct Interp1DImpl final : Interp1DBase {
     uint64_t h = fnv1a(FNV_SEED, pyr.host_knots.data(), pyr.host_knots.size() * sizeof(T));
     const uint64_t f[3] = {n, (uint64_t)strategy, (uint64_t)mode};
     return fnv1a(h, f, sizeof(f));
+  }
+
+  // The derivatives k are kept next to a / b when {y, k} (2 n lanes elements) can sit in LDS beside the knots and the
+  // smallest strip set: the query-order kernel then re-forms a / b per item instead of gathering them (TLDS == 2).
+  // NDI_SPLINE_KEEP_K=0 drops them.
+  T* reserve_k() {
+    static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
+    static const int once = ShortKnobs::env("NDI_SPLINE_KEEP_K", 1);
+    const int keep = tune_live ? ShortKnobs::env("NDI_SPLINE_KEEP_K", 1) : once;
+    if (!keep || lanes > 2048 || fused_lds_bytes(false, 256, 2) > FUSED_LDS_LIMIT) return nullptr;
+    ck.reserve((size_t)n * lanes * sizeof(T));
+    return ck.as<T>();
   }
 
   // ---- build (CubicSpline::build, cubic_spline.rs:754-771) --------------------------------
@@ -801,6 +814,7 @@ struct Interp1DImpl final : Interp1DBase {
     A.dx0_sq = P.dx0_sq; A.dxl_sq = P.dxl_sq;
     A.per_den = P.per_den;
     A.status = tmp.as<StatusBlock>();
+    A.kout = reserve_k();
     const unsigned grid = (unsigned)((lanes + 63) / 64);
     hipStream_t s = nullptr;
     if (blocked) {
@@ -846,7 +860,8 @@ struct Interp1DImpl final : Interp1DBase {
       case SPLINE_GENERAL: {
         const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * lanes + BLOCK - 1) / BLOCK, 65536));
         hipLaunchKernelGGL((spline_rhs_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, s, A);
-        hipLaunchKernelGGL((spline_build_general_kernel<T, false>), dim3(grid), dim3(64), 0, s, A);
+        if (A.kout) hipLaunchKernelGGL((spline_build_general_kernel<T, false, true>), dim3(grid), dim3(64), 0, s, A);
+        else hipLaunchKernelGGL((spline_build_general_kernel<T, false, false>), dim3(grid), dim3(64), 0, s, A);
         break;
       }
       case SPLINE_PARABOLA3:
@@ -940,8 +955,13 @@ struct Interp1DImpl final : Interp1DBase {
     A.dx0_sq = ref.dx0_sq; A.dxl_sq = ref.dxl_sq;
     const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * lanes + BLOCK - 1) / BLOCK, 65536));
     hipLaunchKernelGGL((spline_rhs_kernel<T, true>), dim3(gr), dim3(BLOCK), 0, (hipStream_t) nullptr, A);
-    hipLaunchKernelGGL((spline_build_general_kernel<T, true>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0,
-                       (hipStream_t) nullptr, A);
+    A.kout = reserve_k();
+    if (A.kout)
+      hipLaunchKernelGGL((spline_build_general_kernel<T, true, true>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0,
+                         (hipStream_t) nullptr, A);
+    else
+      hipLaunchKernelGGL((spline_build_general_kernel<T, true, false>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0,
+                         (hipStream_t) nullptr, A);
     NDI_HIP(hipGetLastError());
     NDI_HIP(hipDeviceSynchronize());
     return NDI_OK;
@@ -959,7 +979,8 @@ struct Interp1DImpl final : Interp1DBase {
     bool vec_ok = false;
     uint64_t LV = 0;
     // FUSED (eval_fused_kernel)
-    bool f_lut = false, f_tlds = false, f_pack = false;
+    bool f_lut = false, f_pack = false;
+    int f_tlds = 0;   // 0: tables from memory, 1: {y, a, b} in LDS, 2: {y, k} in LDS
     unsigned f_tb = 256, f_grid = 1;
     int f_unr = 2;
     size_t f_lds = 0;
@@ -967,12 +988,13 @@ struct Interp1DImpl final : Interp1DBase {
   };
 
   // LDS footprint of eval_fused_kernel: [pyramid | lut | per-wave strips | tables]
-  size_t fused_lds_bytes(bool with_lut, unsigned tb, bool tables) const {
+  size_t fused_lds_bytes(bool with_lut, unsigned tb, int tables) const {
     size_t b = (pyr.lds_bytes + 15) & ~(size_t)15;
     if (with_lut) b += pyr.lut_bytes;
-    b += (size_t)(tb / 64) * 64 * (sizeof(uint32_t) + 2 * sizeof(T));
+    const bool strip2 = strategy != NDI_CUBIC_SPLINE || tables == 2;
+    b += (size_t)(tb / 64) * 64 * (sizeof(uint32_t) + (strip2 ? 2 : 1) * sizeof(T));
     if (tables) {
-      const size_t rows = strategy == NDI_CUBIC_SPLINE ? 3 * n - 2 : n;
+      const size_t rows = tables == 2 ? 2 * n : (strategy == NDI_CUBIC_SPLINE ? 3 * n - 2 : n);
       b += rows * lanes * sizeof(T);
     }
     return b;
@@ -992,24 +1014,32 @@ struct Interp1DImpl final : Interp1DBase {
     // Tables in LDS when they fit beside everything else, and when the batch gives every workgroup several times the
     // table size to write (the staging pass is per workgroup).  Workgroup size: the one that keeps most waves on a
     // CU beside the tables; among equals the largest (fewest staging passes).
-    P.f_tlds = false;
+    // {y, k} (the spline's derivatives, kept by small builds) is two thirds of {y, a, b}: it fits where the latter
+    // does not, and leaves room for more waves where both do.  NDI_FUSED_LDS = 1 / 2 pins the form.
+    P.f_tlds = 0;
     P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : 256u;
     if (K.lds != 0) {
       size_t best_waves = 0;
-      for (unsigned tb : {1024u, 512u, 256u}) {
-        if (K.tb && (unsigned)K.tb != tb) continue;
-        const size_t need = fused_lds_bytes(P.f_lut, tb, true);
-        if (need > FUSED_LDS_LIMIT) continue;
-        const size_t waves = std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
-        if (waves > best_waves) {
-          best_waves = waves;
-          P.f_tlds = true;
-          P.f_tb = tb;
+      const bool yk_ok = strategy == NDI_CUBIC_SPLINE && ck.p;
+      const int pinned = (K.lds == 2 && !yk_ok) ? 1 : K.lds;
+      for (int form : {1, 2}) {   // equal wave counts: {y, a, b} (no per-item re-forming; 2-3 % faster where both fit)
+        if (form == 2 && !yk_ok) continue;
+        if (pinned > 0 && pinned <= 2 && pinned != form) continue;
+        for (unsigned tb : {1024u, 512u, 256u}) {
+          if (K.tb && (unsigned)K.tb != tb) continue;
+          const size_t need = fused_lds_bytes(P.f_lut, tb, form);
+          if (need > FUSED_LDS_LIMIT) continue;
+          const size_t waves = std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
+          if (waves > best_waves) {
+            best_waves = waves;
+            P.f_tlds = form;
+            P.f_tb = tb;
+          }
         }
       }
-      const size_t tab = fused_lds_bytes(false, 64, true);
+      const size_t tab = fused_lds_bytes(false, 64, P.f_tlds) - fused_lds_bytes(false, 64, 0);
       if (P.f_tlds && K.lds < 0 && P.nq * lanes * sizeof(T) < 8 * (size_t)cu_count() * tab) {
-        P.f_tlds = false;
+        P.f_tlds = 0;
         P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : 256u;
       }
     }
@@ -1264,6 +1294,7 @@ struct Interp1DImpl final : Interp1DBase {
     F.data = data.as<T>();
     F.ca = ca.as<T>();
     F.cb = cb.as<T>();
+    F.ck = ck.as<T>();
     F.rec_stride = (uint32_t)P.LV;
     if (P.f_pack) {   // {y[i], y[i+1], a[i], b[i]} per interval
       F.data = packed.as<T>();
@@ -1310,9 +1341,13 @@ struct Interp1DImpl final : Interp1DBase {
     else NDI_FU_UNR(ST_LINEAR, VEC, TL);                                                \
   } while (0)
     if (P.vec_ok) {
-      if (P.f_tlds) NDI_FU_ST(VN, true); else NDI_FU_ST(VN, false);
+      if (P.f_tlds == 2) NDI_FU_UNR(ST_CUBIC, VN, 2);
+      else if (P.f_tlds) NDI_FU_ST(VN, 1);
+      else NDI_FU_ST(VN, 0);
     } else {
-      if (P.f_tlds) NDI_FU_ST(1, true); else NDI_FU_ST(1, false);
+      if (P.f_tlds == 2) NDI_FU_UNR(ST_CUBIC, 1, 2);
+      else if (P.f_tlds) NDI_FU_ST(1, 1);
+      else NDI_FU_ST(1, 0);
     }
 #undef NDI_FU_ST
 #undef NDI_FU_UNR
@@ -1699,6 +1734,7 @@ struct Interp1DImpl final : Interp1DBase {
     copy(h->data, data);
     copy(h->ca, ca);
     copy(h->cb, cb);
+    copy(h->ck, ck);
     *out = h.release();
     return NDI_OK;
   }

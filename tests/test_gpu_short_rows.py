@@ -3,6 +3,7 @@ data, (100, 5): benches/bench_interp1d.rs:82-122) against the CPU oracle, bit fo
 
   * flat     locate_kernel + eval_flat_kernel (round 3's only form for these shapes)
   * fused    eval_fused_kernel: query order, search fused in; tables from L2 (plain / interval-packed) or from LDS
+             ({y, a, b}, or {y, k} with a / b re-formed per item by the build's own operations)
   * grouped  eval_bucketed_short_kernel: grouped by interval, operand vectors in registers
 
 The variants are selected with the library's tuning knobs (NDI_TUNE_LIVE is set by conftest, so one process can
@@ -48,6 +49,9 @@ def variants(pkg):
         ("fused_pack", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_PACK=1)),
         ("fused_lds", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=1)),
         ("fused_lds_tb256_u4", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=1, NDI_FUSED_TB=256, NDI_FUSED_UNR=4)),
+        # {y, k} in LDS, a / b re-formed per item (CubicSpline; Linear falls back to {y})
+        ("fused_lds_yk", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=2)),
+        ("fused_lds_yk_tb512_u1", pkg.PATH_GATHER, dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=2, NDI_FUSED_TB=512, NDI_FUSED_UNR=1)),
         ("grouped_cq16", pkg.PATH_BUCKETED, dict(NDI_SHORT_MODE=3, NDI_SHORT_CQ=16)),
         ("grouped_cq64", pkg.PATH_AUTO, dict(NDI_SHORT_MODE=3, NDI_SHORT_CQ=64)),
     ]

@@ -110,6 +110,11 @@ def main():
                         for tb in ((0,) if args.quick else (0, 256, 1024)):
                             variants.append((f"fused_lds_u{unr}_tb{tb}", pkg.PATH_GATHER,
                                              dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=1, NDI_FUSED_UNR=unr, NDI_FUSED_TB=tb)))
+                if args.strategy == "cubic" and 2 * n * L * el <= 140 * 1024:   # {y, k} in LDS, a / b re-formed per item
+                    for unr in unrs:
+                        for tb in ((0,) if args.quick else (0, 256, 512, 1024)):
+                            variants.append((f"fused_ldsyk_u{unr}_tb{tb}", pkg.PATH_GATHER,
+                                             dict(NDI_SHORT_MODE=2, NDI_FUSED_LDS=2, NDI_FUSED_UNR=unr, NDI_FUSED_TB=tb)))
                 for cq in ((64,) if args.quick else (16, 64)):
                     variants.append((f"grouped_cq{cq}", pkg.PATH_BUCKETED, dict(NDI_SHORT_MODE=3, NDI_SHORT_CQ=cq)))
                 variants.append(("auto", pkg.PATH_AUTO, {}))

@@ -425,7 +425,7 @@ struct Locate2Args {
   const T* qy;
   uint64_t nq;
   uint32_t* xi;
-  uint32_t* yi;
+  uint32_t* yi;                    // nullptr: xi[q] receives the cell word xi | yi << 16
   unsigned long long* first_fail;  // [2]: x, y
   int mode;
   uint64_t slice;
@@ -500,8 +500,12 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
     const bool bady = (A.mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
     if (badx) atomicMin(&A.first_fail[0], (unsigned long long)qi);
     if (bady) atomicMin(&A.first_fail[1], (unsigned long long)qi);
-    A.xi[qi] = NDI_CHK(ix, PX.n - 1u, BC_CELL_X);
-    A.yi[qi] = NDI_CHK(iy, PY.n - 1u, BC_CELL_Y);
+    if (A.yi) {
+      A.xi[qi] = NDI_CHK(ix, PX.n - 1u, BC_CELL_X);
+      A.yi[qi] = NDI_CHK(iy, PY.n - 1u, BC_CELL_Y);
+    } else {   // tile-grouped order with compact records: one cell word per query (both axes < 65536 knots)
+      A.xi[qi] = NDI_CHK(ix, PX.n - 1u, BC_CELL_X) | (NDI_CHK(iy, PY.n - 1u, BC_CELL_Y) << 16);
+    }
     if (s_hist) atomicAdd(&s_hist[NDI_CHK((ix >> A.sx) * A.nty + (iy >> A.sy), A.nb, BC_BIN)], 1u);
   }
   if (s_hist) {
@@ -1331,6 +1335,9 @@ struct Eval2Args {
   uint32_t nb, ts, nty, chunk;
   const uint32_t* chunk_bin;   // [chunks] the tile that holds each chunk's first grouped position (tile_chunk_bins_kernel)
   int debug;                   // NDI_TUNING builds only: bit 2 = no stores (measurement aid)
+  // ceil(2^32 / (cols * LV)) for a full tile row (2^ts + 1 grid points) and for the last tile column's shorter rows:
+  // item -> (grid row, vector) of the tile staging by one v_mul_hi instead of an emulated division
+  uint32_t rvm_full, rvm_edge;
 };
 
 template <class T, bool LDS>
@@ -1349,22 +1356,31 @@ __global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* x
                                                                 const T* qy, uint64_t nq, uint64_t slice,
                                                                 const uint32_t* slice_off, const uint32_t* base,
                                                                 uint32_t nb, uint32_t sx, uint32_t sy, uint32_t nty,
-                                                                uint4* rec_i, T* rec_q) {
+                                                                uint4* rec_i, T* rec_q, int xcd_map = 1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem_raw);
-  const uint32_t* off = slice_off + (uint64_t)blockIdx.x * nb;
+  // Consecutive slices own consecutive pieces of every tile's run of records, i.e. they write into the same cache
+  // lines; workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so slice s = blockIdx would leave
+  // every line partially dirty in up to 8 L2s.  With a grid that is a multiple of 8, XCD x takes the slices
+  // [x * grid / 8, (x + 1) * grid / 8): a line's writers share one L2 and their 16-byte records merge there.
+  uint32_t sl = blockIdx.x;
+  if (xcd_map && (gridDim.x & 7u) == 0u) sl = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t* off = slice_off + (uint64_t)sl * nb;
   for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cur[i] = off[i] + base[i];
   __syncthreads();
-  const uint64_t q_begin = (uint64_t)blockIdx.x * slice;
+  const uint64_t q_begin = (uint64_t)sl * slice;
   uint64_t q_end = q_begin + slice;
   if (q_end > nq) q_end = nq;
   for (uint64_t qi = q_begin + threadIdx.x; qi < q_end; qi += blockDim.x) {
-    const uint32_t ix = xi[qi], iy = yi[qi];
+    uint32_t ix = xi[qi], iy;
+    if (yi) iy = yi[qi];
+    else { iy = ix >> 16; ix &= 0xffffu; }   // locate2_kernel's cell word
     const T x = qx[qi], y = qy[qi];
     const uint32_t pos = NDI_CHK(atomicAdd(&cur[NDI_CHK((ix >> sx) * nty + (iy >> sy), nb, BC_BIN)], 1u), nq, BC_POSITION);
     if constexpr (COMPACT && sizeof(T) == 4) {
-      rec_i[pos] = make_uint4((uint32_t)qi, ix | (iy << 16), __builtin_bit_cast(uint32_t, x),
-                              __builtin_bit_cast(uint32_t, y));
+      const uint4 r = make_uint4((uint32_t)qi, ix | (iy << 16), __builtin_bit_cast(uint32_t, x),
+                                 __builtin_bit_cast(uint32_t, y));
+      rec_i[pos] = r;   // (non-temporal: +0.2 ms at C3 -- the records of a line merge in L2)
     } else {
       rec_i[pos] = make_uint4((uint32_t)qi, ix, iy, 0u);
       rec_q[2 * (uint64_t)pos] = x;
@@ -1609,7 +1625,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
   T* s_kx = reinterpret_cast<T*>(smem_raw + ((size_t)S1 * S1 + (SLOPE ? (size_t)S * S1 : 0)) * LV * sizeof(V));   // [S1]
   T* s_ky = s_kx + S1;
   T* s_rx = s_ky + S1;   // RN(1 / (kx[i+1] - kx[i])) per interval of the tile, 0 when the spacing is outside the
-  T* s_ry = s_rx + S1;   // divisor window (then the IEEE division is used)
+  T* s_dyr = s_rx + S1;  // divisor window (then the IEEE division is used); y direction: {ky[i+1] - ky[i], RN(1 / that)}
   const uint32_t tid = threadIdx.x;
   const uint32_t qpt = TB / LV;                 // queries per trip
   const uint32_t ql = tid / LV, v = tid - ql * LV;
@@ -1677,6 +1693,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
     auto prefetch = [&](const TileGeo& g) {
       const uint32_t row_vecs = g.cols * LV;        // one contiguous segment per grid row
       const uint32_t items = g.rows * row_vecs;
+      const uint32_t rvm = g.cols == S1 ? A.rvm_full : A.rvm_edge;
       // Every thread issues exactly MAXI + 2 loads, whatever its share of the tile (indices are clamped, surplus values
       // are dropped at the commit): with the loads under conditions the compiler cannot count the operations behind
       // the record load that precedes them and waits for ALL of them -- the whole tile -- before the first records
@@ -1686,7 +1703,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
         const uint32_t it = tid + (uint32_t)k * TB;
         const bool mine = it < items;
         const uint32_t itc = mine ? it : 0u;
-        const uint32_t r = itc / row_vecs, j = itc - r * row_vecs;
+        const uint32_t r = __umulhi(itc, rvm), j = itc - r * row_vecs;   // itc / row_vecs (itc * row_vecs < 2^32)
         const V* src = reinterpret_cast<const V*>(A.data + ((g.gx0 + r) * A.ny + g.gy0) * A.lanes);
         pre[k] = src[j];
         pre_off[k] = mine ? r * S1 * LV + j : 0xffffffffu;
@@ -1718,7 +1735,8 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
         s_ky[tid - 128u] = pk0;
         if (tid - 128u + 1u < g.cols) {
           const SharedDivisor<T> sd = shared_divisor<T>(pk1 - pk0);
-          s_ry[tid - 128u] = sd.ok ? sd.r : T(0);
+          s_dyr[2u * (tid - 128u)] = sd.d;
+          s_dyr[2u * (tid - 128u) + 1u] = sd.ok ? sd.r : T(0);
         }
       }
     };
@@ -1747,8 +1765,9 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
       if constexpr (SLOPE) {                        // the tile's values and knots are in LDS: form its x slopes
         const uint32_t row_vecs = cur.cols * LV;
         const uint32_t items = (cur.rows - 1u) * row_vecs;
+        const uint32_t rvm = cur.cols == S1 ? A.rvm_full : A.rvm_edge;
         for (uint32_t it = tid; it < items; it += TB) {
-          const uint32_t r = it / row_vecs, j = it - r * row_vecs;
+          const uint32_t r = __umulhi(it, rvm), j = it - r * row_vecs;
           const uint32_t o = r * S1 * LV + j;
           // Linear::calc_frac's m (linear.rs:33) -- every vector of grid row r divides by the same knot spacing: the
           // correctly rounded shared-divisor division (IEEE division outside its window), as in the evaluation
@@ -1765,8 +1784,43 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
         const uint32_t cnt = (hi - pb < (uint64_t)RB) ? (uint32_t)(hi - pb) : (uint32_t)RB;
         __syncthreads();                            // the previous block's records are no longer being read
         if (loader) {
-          s_rec[tid] = r_in;
-          if (!compact) { s_rq[2 * tid] = rx_in; s_rq[2 * tid + 1] = ry_in; }
+          if constexpr (SLOPE) {
+            // Every record is decoded ONCE, by the thread that hands it over, instead of by each of the LV lanes that
+            // evaluate it: {query index (all ones: at / after the batch's first failure), offset of the cell's corner in
+            // the tile | y cell << 16, x - kx[cell], y - ky[cell]}.  (A thread past the end of the tile's records holds
+            // a clamped / earlier record of this tile: decodable, never read.)
+            uint32_t xi, yi;
+            T x, y;
+            if (compact) {
+              if constexpr (std::is_same<T, float>::value) {
+                x = __builtin_bit_cast(float, r_in.z);
+                y = __builtin_bit_cast(float, r_in.w);
+              }
+              xi = r_in.y & 0xffffu;
+              yi = r_in.y >> 16;
+            } else {
+              x = rx_in;
+              y = ry_in;
+              xi = r_in.y;
+              yi = r_in.z;
+            }
+            const uint64_t qi = NDI_CHK((uint64_t)r_in.x, A.nq, BC_QUERY);
+            const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
+            const uint32_t zo = (lx * S1 + ly) * LV;            // < MAXI * TB <= 2^16
+            const T ddx = x - s_kx[lx], yd = y - s_ky[ly];      // linear.rs:35's (x - x1) of both directions
+            const uint32_t qw = qi < limit ? (uint32_t)qi : 0xffffffffu;
+            if (compact) {
+              if constexpr (std::is_same<T, float>::value)
+                s_rec[tid] = make_uint4(qw, zo | (ly << 16), __builtin_bit_cast(uint32_t, ddx), __builtin_bit_cast(uint32_t, yd));
+            } else {
+              s_rec[tid] = make_uint4(qw, zo | (ly << 16), 0u, 0u);
+              s_rq[2 * tid] = ddx;
+              s_rq[2 * tid + 1] = yd;
+            }
+          } else {
+            s_rec[tid] = r_in;
+            if (!compact) { s_rq[2 * tid] = rx_in; s_rq[2 * tid + 1] = ry_in; }
+          }
         }
         __syncthreads();                            // (also: the tile staged above is complete)
         const uint64_t nxt_p = pb + RB;
@@ -1775,62 +1829,35 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
           if (!compact) { rx_in = A.rec_q[2 * (nxt_p + tid)]; ry_in = A.rec_q[2 * (nxt_p + tid) + 1]; }
         }
         if constexpr (SLOPE) {
-          // (NREC records per thread and trip with their LDS reads issued together: measured equal for 1 and 2 at C3,
-          // profiles/r04_tuning.md -- the kernel is not bound by the LDS round trip per record)
-          struct Rec { bool live; uint64_t qi; T ddx, y, y1, dyd, ryr; V m1, m2, b1, b2; };
-          auto fetch = [&](uint32_t j) {
-            Rec R;
-            R.live = j < cnt;
-            const uint32_t jc = R.live ? j : 0u;
-            const uint4 r = s_rec[jc];
-            uint32_t xi, yi;
-            T x;
+          for (uint32_t j = ql; j < cnt; j += qpt) {
+            const uint4 r = s_rec[j];
+            if (r.x == 0xffffffffu) continue;
+            const uint32_t ly = r.y >> 16, zo = (r.y & 0xffffu) + v;
+            T ddx, yd;
             if (compact) {
               if constexpr (std::is_same<T, float>::value) {
-                x = __builtin_bit_cast(float, r.z);
-                R.y = __builtin_bit_cast(float, r.w);
+                ddx = __builtin_bit_cast(float, r.z);
+                yd = __builtin_bit_cast(float, r.w);
               }
-              xi = r.y & 0xffffu;
-              yi = r.y >> 16;
             } else {
-              x = s_rq[2 * jc];
-              R.y = s_rq[2 * jc + 1];
-              xi = r.y;
-              yi = r.z;
+              ddx = s_rq[2 * j];
+              yd = s_rq[2 * j + 1];
             }
-            R.qi = NDI_CHK((uint64_t)r.x, A.nq, BC_QUERY);
-            R.live = R.live && R.qi < limit;
-            const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
-            const size_t zo = ((size_t)lx * S1 + ly) * LV + v;
-            R.m1 = s_mx[zo]; R.m2 = s_mx[zo + LV];
-            R.b1 = s_tile[zo]; R.b2 = s_tile[zo + LV];
-            R.ddx = x - s_kx[lx];
-            R.y1 = s_ky[ly];
-            R.dyd = s_ky[ly + 1u] - R.y1;
-            R.ryr = s_ry[ly];
-            return R;
-          };
-          auto finish = [&](const Rec& R) {
+            const V m1 = s_mx[zo], m2 = s_mx[zo + LV], b1 = s_tile[zo], b2 = s_tile[zo + LV];
             SharedDivisor<T> dy;
-            dy.d = R.dyd; dy.r = R.ryr; dy.ok = dy.r > T(0);
-            const V z1 = R.m1 * R.ddx + R.b1;   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
-            const V z2 = R.m2 * R.ddx + R.b2;
-            V* o = reinterpret_cast<V*>(A.out + R.qi * A.out_stride);
+            dy.d = s_dyr[2u * ly]; dy.r = s_dyr[2u * ly + 1u]; dy.ok = dy.r > T(0);
+            const V z1 = m1 * ddx + b1;   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
+            const V z2 = m2 * ddx + b2;
+            const V m = div_shared<T, V>(z2 - z1, dy);
+            V* o = reinterpret_cast<V*>(A.out + (uint64_t)r.x * A.out_stride) + v;
 #ifdef NDI_TUNING
             if (A.debug & 4) {
-              const V r = frac_shared<T, V>(R.y1, z1, dy, z2, R.y);
-              if (R.live && r[0] == T(-123.456)) __builtin_nontemporal_store(r, o + v);
-              return;
+              const V w = m * yd + z1;
+              if (w[0] == T(-123.456)) __builtin_nontemporal_store(w, o);
+              continue;
             }
 #endif
-            if (R.live) __builtin_nontemporal_store(frac_shared<T, V>(R.y1, z1, dy, z2, R.y), o + v);
-          };
-          for (uint32_t j = ql; j < cnt; j += (uint32_t)NREC * qpt) {
-            Rec R[NREC];
-#pragma unroll
-            for (int u = 0; u < NREC; ++u) R[u] = fetch(j + (uint32_t)u * qpt);
-#pragma unroll
-            for (int u = 0; u < NREC; ++u) finish(R[u]);
+            __builtin_nontemporal_store(m * yd + z1, o);
           }
         } else
         for (uint32_t j = ql; j < cnt; j += qpt) {
@@ -1858,7 +1885,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
           const T y1 = s_ky[ly], y2 = s_ky[ly + 1u];
           V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
           SharedDivisor<T> dy;
-          dy.d = y2 - y1; dy.r = s_ry[ly]; dy.ok = dy.r > T(0);
+          dy.d = y2 - y1; dy.r = s_dyr[2u * ly + 1u]; dy.ok = dy.r > T(0);
           V z1, z2;
           if constexpr (SLOPE) {   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
             const T x1 = s_kx[lx];

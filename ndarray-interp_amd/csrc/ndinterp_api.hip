@@ -1903,7 +1903,7 @@ struct Interp2DImpl final : Interp2DBase {
     auto ntiles_of = [&](uint64_t pts, uint32_t sh) { return (uint32_t)(((pts - 1) + ((uint64_t)1 << sh) - 1) >> sh); };
     auto tile_bytes = [&](uint32_t sh) {
       const size_t s1 = ((size_t)1 << sh) + 1;
-      return s1 * s1 * lanes * sizeof(T) + 4 * s1 * sizeof(T) + 16;
+      return s1 * s1 * lanes * sizeof(T) + 5 * s1 * sizeof(T) + 16;
     };
     uint32_t ts = 0, nty = 0, nb = 0;
     bool shape_ok = false;
@@ -1933,6 +1933,9 @@ struct Interp2DImpl final : Interp2DBase {
     if (path == NDI_PATH_BUCKETED) tiled = can_tile;
     else if (path == NDI_PATH_AUTO) tiled = can_tile && auto_tiles(nq);
     const uint32_t sx = ts, sy = ts;
+    const bool compact_records = std::is_same<T, float>::value && nx <= 65536 && ny <= 65536;
+    static const int cw_env = [] { const char* e = std::getenv("NDI_TILE_CELLWORDS"); return e ? std::atoi(e) : 1; }();   // A/B
+    const bool cell_words = tiled && compact_records && both <= LDS_STAGE_LIMIT && cw_env;
     g_last_path.store(tiled ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
     uint64_t slice = 0, blocks = 0;
     if (both <= LDS_STAGE_LIMIT) {   // both axes in one launch
@@ -1940,6 +1943,7 @@ struct Interp2DImpl final : Interp2DBase {
       LA.px = px.view; LA.py = py.view;
       LA.qx = qx; LA.qy = qy; LA.nq = nq;
       LA.xi = sc.idx.as<uint32_t>(); LA.yi = sc.idx2.as<uint32_t>();
+      if (cell_words) LA.yi = nullptr;   // one cell word per query: all the scatter needs
       LA.first_fail = &st->first_fail[0];
       LA.mode = mode;
       LA.bx = BucketIndex<T>{nullptr, 0, T(0)};
@@ -1972,7 +1976,7 @@ struct Interp2DImpl final : Interp2DBase {
     if (tiled) {
       P.kind = Plan2::TILED;
       P.ts = ts; P.nty = nty; P.nb = nb;
-      P.compact = std::is_same<T, float>::value && nx <= 65536 && ny <= 65536;
+      P.compact = compact_records;
       // the scatter is a latency-bound chain (load -> LDS atomic -> scattered store): many waves per CU
       const unsigned gthreads = beside_eval ? 256u : (slice >= 4096 ? 1024u : (unsigned)BLOCK);
       sc.perm.reserve(nq * sizeof(uint4));            // grouped records
@@ -1988,9 +1992,10 @@ struct Interp2DImpl final : Interp2DBase {
                          sc.cursor.as<uint32_t>(), st);
       if (P.compact)
         hipLaunchKernelGGL((group_scatter2d_kernel<T, true>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
-                           (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
+                           (const uint32_t*)sc.idx.as<uint32_t>(),
+                           cell_words ? (const uint32_t*)nullptr : (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
                            slice, (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(),
-                           nb, sx, sy, nty, sc.perm.as<uint4>(), (T*)nullptr);
+                           nb, sx, sy, nty, sc.perm.as<uint4>(), (T*)nullptr, ShortKnobs::env("NDI_SCATTER_XCD", 1));
       else
         hipLaunchKernelGGL((group_scatter2d_kernel<T, false>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
                            (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
@@ -2075,12 +2080,19 @@ struct Interp2DImpl final : Interp2DBase {
       A.nb = P.nb; A.ts = P.ts; A.nty = P.nty;
       A.chunk = tile_chunk();
       A.chunk_bin = sc.chunkbin.as<uint32_t>();
+      {   // item -> (grid row, vector) of the tile staging: ceil(2^32 / vectors per tile row), full and last-column tiles
+        const uint64_t lvv = lanes / Wide<T>::N;
+        const uint64_t full = (((uint64_t)1 << P.ts) + 1) * lvv;
+        const uint64_t edge = (ny - ((uint64_t)(P.nty - 1) << P.ts)) * lvv;
+        A.rvm_full = (uint32_t)((((uint64_t)1 << 32) + full - 1) / full);
+        A.rvm_edge = (uint32_t)((((uint64_t)1 << 32) + edge - 1) / edge);
+      }
       A.debug = 0;
 #ifdef NDI_TUNING
       A.debug = ShortKnobs::env("NDI_FUSED_DEBUG", 0);
 #endif
       const size_t s1 = ((size_t)1 << P.ts) + 1;
-      const size_t shm = s1 * s1 * lanes * sizeof(T) + 4 * s1 * sizeof(T) + 16;
+      const size_t shm = s1 * s1 * lanes * sizeof(T) + 5 * s1 * sizeof(T) + 16;
       const uint64_t nchunks = (nq + A.chunk - 1) / A.chunk;
       const uint64_t resident = (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (shm + 64)));
       const unsigned gx = (unsigned)((std::max<uint64_t>(1, std::min<uint64_t>(nchunks, resident * 4)) + 7) / 8 * 8);
@@ -2095,7 +2107,7 @@ struct Interp2DImpl final : Interp2DBase {
       // x slopes of the tile staged next to its values (one division per channel and query instead of three): needs a
       // second tile-sized array in LDS, so the records are handed over 256 at a time.  NDI_TILE_SLOPES=0: A/B.
       static const int slope_env = [] { const char* e = std::getenv("NDI_TILE_SLOPES"); return e ? std::atoi(e) : 1; }();
-      const size_t shm_slope = (s1 * s1 + (s1 - 1) * s1) * lanes * sizeof(T) + 4 * s1 * sizeof(T) + 16;
+      const size_t shm_slope = (s1 * s1 + (s1 - 1) * s1) * lanes * sizeof(T) + 5 * s1 * sizeof(T) + 16;
       const bool slopes = slope_env != 0 && !two_wg && shm_slope + static512 <= 160 * 1024;
       // ... 1024 at a time when that still fits (compact f32 records at C3: 143.9 KiB + 16 KiB)
       const size_t static1024 = 1024 * 16 + (P.compact ? 2 : 2 * 1024) * sizeof(T) + 320;

@@ -1356,15 +1356,13 @@ __global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* x
                                                                 const T* qy, uint64_t nq, uint64_t slice,
                                                                 const uint32_t* slice_off, const uint32_t* base,
                                                                 uint32_t nb, uint32_t sx, uint32_t sy, uint32_t nty,
-                                                                uint4* rec_i, T* rec_q, int xcd_map = 1) {
+                                                                uint4* rec_i, T* rec_q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem_raw);
-  // Consecutive slices own consecutive pieces of every tile's run of records, i.e. they write into the same cache
-  // lines; workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so slice s = blockIdx would leave
-  // every line partially dirty in up to 8 L2s.  With a grid that is a multiple of 8, XCD x takes the slices
-  // [x * grid / 8, (x + 1) * grid / 8): a line's writers share one L2 and their 16-byte records merge there.
-  uint32_t sl = blockIdx.x;
-  if (xcd_map && (gridDim.x & 7u) == 0u) sl = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  // (Measured at C3 and dropped, profiles/r04_tuning.md: an XCD-aware slice order -- a line's writers on one L2 -- equal;
+  // one cursor row per XCD drawn with device-scope atomics, so that a tile's records arrive as 8 sequential streams -- 2 x
+  // slower, the atomics are served beyond L2; non-temporal record stores -- +0.2 ms, the partial lines do merge in L2.)
+  const uint32_t sl = blockIdx.x;
   const uint32_t* off = slice_off + (uint64_t)sl * nb;
   for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cur[i] = off[i] + base[i];
   __syncthreads();

@@ -1995,7 +1995,7 @@ struct Interp2DImpl final : Interp2DBase {
                            (const uint32_t*)sc.idx.as<uint32_t>(),
                            cell_words ? (const uint32_t*)nullptr : (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
                            slice, (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(),
-                           nb, sx, sy, nty, sc.perm.as<uint4>(), (T*)nullptr, ShortKnobs::env("NDI_SCATTER_XCD", 1));
+                           nb, sx, sy, nty, sc.perm.as<uint4>(), (T*)nullptr);
       else
         hipLaunchKernelGGL((group_scatter2d_kernel<T, false>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
                            (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,

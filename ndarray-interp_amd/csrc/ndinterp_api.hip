@@ -1317,6 +1317,10 @@ struct Interp1DImpl final : Interp1DBase {
 #endif
     constexpr int VN = Wide<T>::N;
     const dim3 grid(P.f_grid), block(P.f_tb);
+    if (std::getenv("NDI_TRACE_PLAN"))   // which variant a batch took (tests assert on it; read per call)
+      std::fprintf(stderr, "[ndi plan] fused tables=%s lut=%d pack=%d unr=%d tb=%u grid=%u lds=%zu\n",
+                   P.f_tlds == 2 ? "lds{y,k}" : (P.f_tlds == 1 ? "lds{y,a,b}" : "memory"), (int)P.f_lut, (int)P.f_pack,
+                   P.f_unr, P.f_tb, P.f_grid, P.f_lds);
 #define NDI_FU(ST, VEC, UNR, TB, TL)                                                                   \
   do {                                                                                                 \
     auto kern = eval_fused_kernel<T, ST, VEC, UNR, TB, TL>;                                            \

@@ -252,3 +252,53 @@ def test_short_rows_in_the_ring_and_strided_buffers(pkg):
             h = wide.cpu().numpy()
             check_equal(h[:, :L], ref.reshape(Q, L), f"strided {name}")
             assert np.all(h[:, L:] == -9.0), name
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_yk_form_after_every_build_kernel(pkg, dt, capfd):
+    """The {y, k} LDS form re-forms a / b from the derivatives every build kernel leaves (serial general / periodic /
+    n == 3 closed forms / per-lane Individual / blocked sweeps, general and periodic): its rows must carry the bits of
+    the a / b tables the same build wrote, whatever the boundary condition (cubic_spline.rs:354-365)."""
+    import torch
+    from test_gpu_parity import BCS
+    from test_gpu_spline_blocked import _bc
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    S, R, B = pkg.SingleBoundary, pkg.RowBoundary, pkg.BoundaryCondition
+    cases = []
+    for name, (per, left, right) in BCS.items():
+        for n, L in ((3, 4), (4, 8), (300, 12), (2100, 3)):      # closed forms, serial kernels, blocked sweeps
+            if n == 3 and name not in ("nk", "per"):
+                continue
+            cases.append((name, n, L, per, (lambda L=L, left=left, right=right: _bc(pkg, L, left, right)) if not per
+                          else (lambda: B.Periodic)))
+    def individual(L=6):    # every lane its own pair of end conditions
+        rows = np.empty((1, L), dtype=object)
+        kinds = [S.NotAKnot, S.Natural, S.Clamped, S.FirstDeriv(0.3), S.SecondDeriv(-0.2), S.NotAKnot]
+        for i in range(L):
+            rows[0, i] = R.Mixed(kinds[i % 6], kinds[(i + 2) % 6])
+        return B.Individual(rows)
+    cases.append(("individual", 200, 6, False, individual))
+    for name, n, L, per, bc in cases:
+        x = knots("jit" if n > 4 else "lin", n, rng, dt) if n > 3 else np.array([-1.0, 0.0, 3.0], dtype=dt)
+        y = rng.uniform(-1.0, 1.0, (n, L)).astype(dt)
+        if per:
+            y[-1] = y[0]
+        it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
+            .strategy(pkg.CubicSpline.new().boundary(bc())).build()
+        q = rng.uniform(x[0], x[-1], 20_001).astype(dt)
+        q[:2] = [x[0], x[-1]]
+        with knobs(NDI_SHORT_MODE=2, NDI_FUSED_LDS=0, NDI_FUSED_PACK=0):
+            ref = _device_eval(pkg, it, q, L, pkg.PATH_GATHER, tdt).cpu().numpy()
+        capfd.readouterr()
+        os.environ["NDI_TRACE_PLAN"] = "1"
+        try:
+            with knobs(NDI_SHORT_MODE=2, NDI_FUSED_LDS=2):
+                got = _device_eval(pkg, it, q, L, pkg.PATH_GATHER, tdt).cpu().numpy()
+        finally:
+            del os.environ["NDI_TRACE_PLAN"]
+        err = capfd.readouterr().err
+        if L > 2:   # (1-2 lanes take the one-thread-per-query kernel)
+            assert "tables=lds{y,k}" in err, (name, n, L, err)
+        assert np.array_equal(got, ref, equal_nan=True), f"{name} n={n} L={L}: {{y, k}} rows differ from the table form"

@@ -1692,6 +1692,8 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
       const uint32_t row_vecs = g.cols * LV;        // one contiguous segment per grid row
       const uint32_t items = g.rows * row_vecs;
       const uint32_t rvm = g.cols == S1 ? A.rvm_full : A.rvm_edge;
+      const T* tile0 = A.data + (g.gx0 * A.ny + g.gy0) * A.lanes;
+      const uint32_t row_elems = (uint32_t)(A.ny * A.lanes);
       // Every thread issues exactly MAXI + 2 loads, whatever its share of the tile (indices are clamped, surplus values
       // are dropped at the commit): with the loads under conditions the compiler cannot count the operations behind
       // the record load that precedes them and waits for ALL of them -- the whole tile -- before the first records
@@ -1702,7 +1704,9 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
         const bool mine = it < items;
         const uint32_t itc = mine ? it : 0u;
         const uint32_t r = __umulhi(itc, rvm), j = itc - r * row_vecs;   // itc / row_vecs (itc * row_vecs < 2^32)
-        const V* src = reinterpret_cast<const V*>(A.data + ((g.gx0 + r) * A.ny + g.gy0) * A.lanes);
+        // workgroup-uniform tile origin + one 32 x 32 -> 64-bit multiply-add per load (a grid row is < 2^32 elements:
+        // checked by the host)
+        const V* src = reinterpret_cast<const V*>(tile0 + (uint64_t)r * row_elems);
         pre[k] = src[j];
         pre_off[k] = mine ? r * S1 * LV + j : 0xffffffffu;
       }
@@ -1773,59 +1777,56 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
           dx.d = s_kx[r + 1u] - s_kx[r]; dx.r = s_rx[r]; dx.ok = dx.r > T(0);
           s_mx[o] = div_shared<T, V>(s_tile[o + S1 * LV] - s_tile[o], dx);
         }
-        __syncthreads();
       }
-      // The tile's records are brought in TB at a time (one coalesced 16-byte load per thread) and handed to the
-      // LV-lane groups through LDS; the next block's loads are in flight while the current block is evaluated, so a
-      // workgroup pays one memory latency per 256 queries instead of one per trip.
-      while (pb < hi) {
-        const uint32_t cnt = (hi - pb < (uint64_t)RB) ? (uint32_t)(hi - pb) : (uint32_t)RB;
-        __syncthreads();                            // the previous block's records are no longer being read
-        if (loader) {
-          if constexpr (SLOPE) {
-            // Every record is decoded ONCE, by the thread that hands it over, instead of by each of the LV lanes that
-            // evaluate it: {query index (all ones: at / after the batch's first failure), offset of the cell's corner in
-            // the tile | y cell << 16, x - kx[cell], y - ky[cell]}.  (A thread past the end of the tile's records holds
-            // a clamped / earlier record of this tile: decodable, never read.)
-            uint32_t xi, yi;
-            T x, y;
-            if (compact) {
-              if constexpr (std::is_same<T, float>::value) {
-                x = __builtin_bit_cast(float, r_in.z);
-                y = __builtin_bit_cast(float, r_in.w);
-              }
-              xi = r_in.y & 0xffffu;
-              yi = r_in.y >> 16;
-            } else {
-              x = rx_in;
-              y = ry_in;
-              xi = r_in.y;
-              yi = r_in.z;
+      // The tile's records are brought in RB at a time (one coalesced 16-byte load per thread) and handed to the
+      // LV-lane groups through LDS; the next block's load is in flight while the current block is evaluated.
+      // SLOPE: every record is decoded ONCE, by the thread that hands it over, instead of by each of the LV lanes that
+      // evaluate it: {query index (all ones: at / after the batch's first failure), offset of the cell's corner in
+      // the tile | y cell << 16, x - kx[cell], y - ky[cell]}.  (A thread past the end of the tile's records holds a
+      // clamped / earlier record of this tile: decodable, never read.)
+      auto hand_over = [&]() {
+        if (!loader) return;
+        if constexpr (SLOPE) {
+          uint32_t xi, yi;
+          T x, y;
+          if (compact) {
+            if constexpr (std::is_same<T, float>::value) {
+              x = __builtin_bit_cast(float, r_in.z);
+              y = __builtin_bit_cast(float, r_in.w);
             }
-            const uint64_t qi = NDI_CHK((uint64_t)r_in.x, A.nq, BC_QUERY);
-            const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
-            const uint32_t zo = (lx * S1 + ly) * LV;            // < MAXI * TB <= 2^16
-            const T ddx = x - s_kx[lx], yd = y - s_ky[ly];      // linear.rs:35's (x - x1) of both directions
-            const uint32_t qw = qi < limit ? (uint32_t)qi : 0xffffffffu;
-            if (compact) {
-              if constexpr (std::is_same<T, float>::value)
-                s_rec[tid] = make_uint4(qw, zo | (ly << 16), __builtin_bit_cast(uint32_t, ddx), __builtin_bit_cast(uint32_t, yd));
-            } else {
-              s_rec[tid] = make_uint4(qw, zo | (ly << 16), 0u, 0u);
-              s_rq[2 * tid] = ddx;
-              s_rq[2 * tid + 1] = yd;
-            }
+            xi = r_in.y & 0xffffu;
+            yi = r_in.y >> 16;
           } else {
-            s_rec[tid] = r_in;
-            if (!compact) { s_rq[2 * tid] = rx_in; s_rq[2 * tid + 1] = ry_in; }
+            x = rx_in;
+            y = ry_in;
+            xi = r_in.y;
+            yi = r_in.z;
           }
+          const uint64_t qi = NDI_CHK((uint64_t)r_in.x, A.nq, BC_QUERY);
+          const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
+          const uint32_t zo = (lx * S1 + ly) * LV;            // < MAXI * TB <= 2^16
+          const T ddx = x - s_kx[lx], yd = y - s_ky[ly];      // linear.rs:35's (x - x1) of both directions
+          const uint32_t qw = qi < limit ? (uint32_t)qi : 0xffffffffu;
+          if (compact) {
+            if constexpr (std::is_same<T, float>::value)
+              s_rec[tid] = make_uint4(qw, zo | (ly << 16), __builtin_bit_cast(uint32_t, ddx), __builtin_bit_cast(uint32_t, yd));
+          } else {
+            s_rec[tid] = make_uint4(qw, zo | (ly << 16), 0u, 0u);
+            s_rq[2 * tid] = ddx;
+            s_rq[2 * tid + 1] = yd;
+          }
+        } else {
+          s_rec[tid] = r_in;
+          if (!compact) { s_rq[2 * tid] = rx_in; s_rq[2 * tid + 1] = ry_in; }
         }
-        __syncthreads();                            // (also: the tile staged above is complete)
-        const uint64_t nxt_p = pb + RB;
-        if (loader && nxt_p + tid < hi) {
-          r_in = A.rec_i[nxt_p + tid];
-          if (!compact) { rx_in = A.rec_q[2 * (nxt_p + tid)]; ry_in = A.rec_q[2 * (nxt_p + tid) + 1]; }
+      };
+      auto request = [&](uint64_t p) {               // the block of records starting at grouped position p
+        if (loader && p + tid < hi) {
+          r_in = A.rec_i[p + tid];
+          if (!compact) { rx_in = A.rec_q[2 * (p + tid)]; ry_in = A.rec_q[2 * (p + tid) + 1]; }
         }
+      };
+      auto evaluate = [&](uint32_t cnt) {
         if constexpr (SLOPE) {
           for (uint32_t j = ql; j < cnt; j += qpt) {
             const uint4 r = s_rec[j];
@@ -1847,7 +1848,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
             const V z1 = m1 * ddx + b1;   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
             const V z2 = m2 * ddx + b2;
             const V m = div_shared<T, V>(z2 - z1, dy);
-            V* o = reinterpret_cast<V*>(A.out + (uint64_t)r.x * A.out_stride) + v;
+            V* o = reinterpret_cast<V*>(A.out + (uint64_t)r.x * (uint32_t)A.out_stride) + v;   // (row stride < 2^32: host)
 #ifdef NDI_TUNING
             if (A.debug & 4) {
               const V w = m * yd + z1;
@@ -1857,50 +1858,63 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
 #endif
             __builtin_nontemporal_store(m * yd + z1, o);
           }
-        } else
-        for (uint32_t j = ql; j < cnt; j += qpt) {
-          const uint4 r = s_rec[j];
-          uint32_t xi, yi;
-          T x, y;
-          if (compact) {
-            if constexpr (std::is_same<T, float>::value) {
-              x = __builtin_bit_cast(float, r.z);
-              y = __builtin_bit_cast(float, r.w);
+        } else {
+          for (uint32_t j = ql; j < cnt; j += qpt) {
+            const uint4 r = s_rec[j];
+            uint32_t xi, yi;
+            T x, y;
+            if (compact) {
+              if constexpr (std::is_same<T, float>::value) {
+                x = __builtin_bit_cast(float, r.z);
+                y = __builtin_bit_cast(float, r.w);
+              }
+              xi = r.y & 0xffffu;
+              yi = r.y >> 16;
+            } else {
+              x = s_rq[2 * j];
+              y = s_rq[2 * j + 1];
+              xi = r.y;
+              yi = r.z;
             }
-            xi = r.y & 0xffffu;
-            yi = r.y >> 16;
-          } else {
-            x = s_rq[2 * j];
-            y = s_rq[2 * j + 1];
-            xi = r.y;
-            yi = r.z;
-          }
-          const uint64_t qi = NDI_CHK((uint64_t)r.x, A.nq, BC_QUERY);
-          if (qi >= limit) continue;
-          const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
-          const size_t zo = ((size_t)lx * S1 + ly) * LV + v;
-          const V* z11 = s_tile + zo;
-          const T y1 = s_ky[ly], y2 = s_ky[ly + 1u];
-          V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
-          SharedDivisor<T> dy;
-          dy.d = y2 - y1; dy.r = s_dyr[2u * ly + 1u]; dy.ok = dy.r > T(0);
-          V z1, z2;
-          if constexpr (SLOPE) {   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
-            const T x1 = s_kx[lx];
-            const T ddx = x - x1;
-            z1 = s_mx[zo] * ddx + z11[0];
-            z2 = s_mx[zo + LV] * ddx + z11[LV];
-          } else {
+            const uint64_t qi = NDI_CHK((uint64_t)r.x, A.nq, BC_QUERY);
+            if (qi >= limit) continue;
+            const uint32_t lx = NDI_CHK(xi - (uint32_t)gx0, S, BC_TILE), ly = NDI_CHK(yi - (uint32_t)gy0, S, BC_TILE);
+            const uint32_t zo = (lx * S1 + ly) * LV + v;
+            const V* z11 = s_tile + zo;
+            const T y1 = s_ky[ly], y2 = s_ky[ly + 1u];
+            V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
+            SharedDivisor<T> dy;
+            dy.d = y2 - y1; dy.r = s_dyr[2u * ly + 1u]; dy.ok = dy.r > T(0);
             const V a11 = z11[0], a12 = z11[LV], a21 = z11[(size_t)S1 * LV], a22 = z11[(size_t)S1 * LV + LV];
             const T x1 = s_kx[lx], x2 = s_kx[lx + 1u];
             SharedDivisor<T> dx;
             dx.d = x2 - x1; dx.r = s_rx[lx]; dx.ok = dx.r > T(0);
-            z1 = frac_shared<T, V>(x1, a11, dx, a21, x);   // bilinear.rs:88-97
-            z2 = frac_shared<T, V>(x1, a12, dx, a22, x);
+            const V z1 = frac_shared<T, V>(x1, a11, dx, a21, x);   // bilinear.rs:88-97
+            const V z2 = frac_shared<T, V>(x1, a12, dx, a22, x);
+            __builtin_nontemporal_store(frac_shared<T, V>(y1, z1, dy, z2, y), o + v);
           }
-          __builtin_nontemporal_store(frac_shared<T, V>(y1, z1, dy, z2, y), o + v);
         }
+      };
+      // The first block is handed over HERE, outside the loop: the only memory operations between its load and this
+      // use are the MAXI + 2 unconditional loads of the prefetch, so the compiler waits with an exact count
+      // (vmcnt(MAXI + 2): the records only) and the next tile stays in flight during the whole evaluation below.
+      // (Inside the loop the same use follows a conditional load and waits for everything -- which, for the first
+      // block of every tile, meant: for the whole next tile, before a single record was evaluated.)
+      uint32_t cnt = (hi - pb < (uint64_t)RB) ? (uint32_t)(hi - pb) : (uint32_t)RB;
+      hand_over();
+      uint64_t nxt_p = pb + RB;
+      request(nxt_p);
+      __syncthreads();                              // records (and slopes) of the tile are in LDS
+      for (;;) {
+        evaluate(cnt);
         pb = nxt_p;
+        if (pb >= hi) break;
+        cnt = (hi - pb < (uint64_t)RB) ? (uint32_t)(hi - pb) : (uint32_t)RB;
+        __syncthreads();                            // the previous block's records are no longer being read
+        hand_over();
+        nxt_p = pb + RB;
+        request(nxt_p);
+        __syncthreads();
       }
       cur = nxt;
     }

@@ -1912,7 +1912,7 @@ struct Interp2DImpl final : Interp2DBase {
     uint32_t ts = 0, nty = 0, nb = 0;
     bool shape_ok = false;
     if (vec_ok_p && !pair_packed && LVp >= 1 && LVp <= 1024 && 1024 % LVp == 0 && both <= LDS_STAGE_LIMIT &&
-        nx < (1ull << 31) && ny < (1ull << 31)) {
+        nx < (1ull << 31) && ny < (1ull << 31) && ny * lanes < (1ull << 32) && out_stride < (1ull << 32)) {
       static const int ts_env = [] { const char* e = std::getenv("NDI_TILE_TS"); return e ? std::atoi(e) : -1; }();
       // the largest tile that leaves room for two workgroups per CU, else the largest that fits at all
       // the tile must fit the kernel's register double-buffer (6 x 1024 16-byte vectors = 96 KiB) next to 24-32 KiB of
@@ -2025,10 +2025,10 @@ struct Interp2DImpl final : Interp2DBase {
   }
 
   // AUTO for 2-D: tile-grouped order when the batch has enough queries per grid cell to pay for staging every
-  // tile once (C3 grid, profiles/r03_c3_grouped.jsonl: 1.4 queries per cell -3 % time, 1.9: -11 %, 2.4 (C3): -18 %,
-  // 4.8: -31 %; below 1 the gather order wins) and the grid is far larger than what the caches hold anyway.
+  // tile once (C3 grid, profiles/r04_c3_qpc_sweep.jsonl: 0.95 queries per cell +5 % time, 1.2: -12 %, 1.4: -23 %,
+  // 1.9: -34 %, 2.4 (C3): -37 %; below 1 the gather order wins) and the grid is far larger than what the caches hold.
   bool auto_tiles(uint64_t nq) const {
-    static const double thr = [] { const char* e = std::getenv("NDI_TILE_QPC"); return e ? std::atof(e) : 1.5; }();
+    static const double thr = [] { const char* e = std::getenv("NDI_TILE_QPC"); return e ? std::atof(e) : 1.1; }();
     const double cells = (double)(nx - 1) * (double)(ny - 1);
     const size_t grid_bytes = (size_t)nx * ny * lanes * sizeof(T);
     return (double)nq >= thr * cells && grid_bytes >= ((size_t)256 << 20) && lanes * sizeof(T) >= 64;

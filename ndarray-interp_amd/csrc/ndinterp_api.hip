@@ -1992,8 +1992,12 @@ struct Interp2DImpl final : Interp2DBase {
       ProfScope ps(s, PC_GROUP);
       hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
                          sc.hist.as<uint32_t>(), (uint32_t)blocks, nb, sc.counts.as<uint32_t>());
-      hipLaunchKernelGGL(bucket_scan_kernel<256>, dim3(1), dim3(256), 0, s, sc.counts.as<uint32_t>(), nb,
-                         sc.cursor.as<uint32_t>(), st);
+      if (beside_eval || nb <= 4096)   // (a 4-wave workgroup finds room beside a running evaluation kernel)
+        hipLaunchKernelGGL(bucket_scan_kernel<256>, dim3(1), dim3(256), 0, s, sc.counts.as<uint32_t>(), nb,
+                           sc.cursor.as<uint32_t>(), st);
+      else
+        hipLaunchKernelGGL(bucket_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, sc.counts.as<uint32_t>(), nb,
+                           sc.cursor.as<uint32_t>(), st);
       if (P.compact)
         hipLaunchKernelGGL((group_scatter2d_kernel<T, true>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
                            (const uint32_t*)sc.idx.as<uint32_t>(),

@@ -8,7 +8,14 @@
 //   eval_rows_kernel       GATHER formulation, long rows: one 256-vector row segment per workgroup pass,
 //                          16-byte coalesced loads of the operand rows fused with the polynomial,
 //                          non-temporal stores                       (linear.rs:94-96, cubic_spline.rs:818-828)
-//   eval_flat_kernel       same arithmetic for short / unaligned rows: one output vector per thread
+//   eval_flat_kernel       same arithmetic for short / unaligned rows: one output vector per thread (two-kernel form;
+//                          the yardstick of the short-row tests)
+//   eval_fused_kernel      short rows (< 256 vectors), QUERY ORDER with the search fused in: 64 queries per wave, one
+//                          sequential write stream; tables from L2 (plain / interval-packed: pack_intervals_kernel)
+//                          or staged in LDS -- {y, a, b}, or {y, k} with a / b re-formed per item
+//   eval_bucketed_short_kernel
+//                          short rows grouped by interval: sub-workgroup groups keep the operand vectors in registers
+//   range_check_kernel     first failing query of a batch before a query-order launch (first-error semantics)
 //   eval_small_kernel / eval_small2d_kernel
 //                          <= 16 lanes with host buffers: search + evaluation fused in one launch, one query
 //                          per thread (latency path for the reference's own bench shapes)
@@ -19,12 +26,14 @@
 //   eval_bilinear_kernel   2-D gather order (bilinear.rs:83-97), plain or pair-packed grid (pack_pairs_kernel)
 //   eval_bilinear_tiles_kernel
 //                          2-D tile-grouped order (locate2_kernel's tile histogram + group_scatter2d_kernel): every
-//                          tile of grid points staged once in LDS (double-buffered through registers), per-row
-//                          divisions as correctly rounded shared-divisor divisions (div_shared); bound by
-//                          occupancy beside the tile, not by HBM
+//                          tile of grid points staged once in LDS (double-buffered through registers) together with
+//                          its x slopes; records decoded once at the hand-over; correctly rounded shared-divisor
+//                          divisions (div_shared); bound by tile staging + arithmetic
 //   probe_gather_kernel    measurement aid: the 2-D gather's memory access mix alone
 //   spline_build_*         batched Thomas solve, one lane of the trailing axes per thread, shared (or
 //                          per-lane selected) elimination factors          (cubic_spline.rs:310-368, 409-721)
+//   spline_blocked_*       the same system for narrow trailing axes on many knots: both sweeps as blocked first-order
+//                          recurrences (the one path that is not bit-identical: a few ulp)
 //
 // Arithmetic is written in the reference's operation order and the translation unit is
 // compiled with -ffp-contract=off, so results are bit-identical to a non-fused CPU evaluation.

@@ -280,6 +280,37 @@ __device__ __forceinline__ uint32_t lut_count_le(lds_ptr<T> k, uint32_t n, lds_u
   return lo;
 }
 
+// The same index for axes whose knots do not fit LDS (more than ~19 000 f64 / 38 000 f32 knots: scalar data on 1e5 - 1e6
+// knots is a shape the reference's users have): u32 entries, read from global memory (L2-resident: 8 B per knot).  The
+// pyramid search from global memory costs log2(block) = 11-14 DEPENDENT L2 reads per query there; this one costs the two
+// adjacent lut reads and then the 1-2 knot reads of the bucket.
+template <class T>
+struct BucketIndex32 {
+  const uint32_t* lut;   // m + 1 entries; nullptr: none
+  uint32_t m;
+  T scale;
+};
+template <class T>
+__device__ __forceinline__ uint32_t lut32_count_le(const T* k, uint32_t n, const uint32_t* lut, uint32_t m, T scale,
+                                                   T k0, T kn, T x) {
+  if (!(x >= k0)) return 0u;   // below the axis, or NaN
+  if (x >= kn) return n;
+  const uint32_t b = bucket_of<T>(x, k0, scale, m);
+  uint32_t lo = lut[b];
+  uint32_t len = lut[b + 1u] - lo;
+  while (len > 0u) {
+    const uint32_t half = len >> 1;
+    const uint32_t mid = lo + half;
+    if (k[mid] <= x) {
+      lo = mid + 1u;
+      len -= half + 1u;
+    } else {
+      len = half;
+    }
+  }
+  return lo;
+}
+
 // Interval index of one query per lane: the O(1) guess of the reference for evenly spaced axes
 // (vector_extensions.rs:68-90: mid = calc_frac((k0,0),(kn,n-1),x), accepted iff k[mid] <= x < k[mid+1]),
 // and the cooperative search for the whole wave as soon as one lane's guess is not accepted.  Either way the
@@ -326,6 +357,7 @@ struct LocateArgs {
   int mode;                // ExtrapMode
   int stage_lds;           // copy the pyramid into LDS first
   BucketIndex<T> bx;       // bucket index, staged behind the pyramid when bx.lut != nullptr (needs stage_lds)
+  BucketIndex32<T> bx32;   // bucket index read from global memory (axes that are not staged)
   // grouping support (BUCKETED formulation): workgroup b handles the contiguous query slice
   // [b*slice, (b+1)*slice) and, if hist != nullptr, leaves its interval histogram in hist[b][nb]
   uint64_t slice;
@@ -360,6 +392,10 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
     uint32_t i;
     if constexpr (std::is_same<PTR, lds_ptr<T>>::value) {
       i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs) : locate_index<T, PTR>(P, k0, kn, xs, lane);
+    } else if (A.bx32.lut) {
+      const uint32_t ub = lut32_count_le<T>(P.lv0, P.n, A.bx32.lut, A.bx32.m, A.bx32.scale, k0, kn, xs);
+      i = (ub == 0) ? 0u : ub - 1u;
+      if (i > P.n - 2u) i = P.n - 2u;
     } else {
       i = locate_index<T, PTR>(P, k0, kn, xs, lane);
     }

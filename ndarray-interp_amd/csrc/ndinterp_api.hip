@@ -286,6 +286,32 @@ struct DevicePyramid {
     });
   }
 
+  // The global-memory form for axes that are not staged in LDS (kernels.hpp, BucketIndex32): u32 entries, 2n <= m < 4n
+  // buckets, at most 256 MiB.  Built on first use by a batch of >= 4096 queries.
+  DevBuf lut32_buf;
+  BucketIndex32<T> bidx32{nullptr, 0, T(0)};
+  mutable std::once_flag lut32_once;
+  void ensure_bucket_index32() const {
+    std::call_once(lut32_once, [this] {
+      DevicePyramid* self = const_cast<DevicePyramid*>(this);
+      const T* knots = host_knots.data();
+      const uint64_t n = host_knots.size();
+      if (guess_is_exact || n <= 64 || n > (1ull << 25)) return;
+      uint32_t m = 1;
+      while (m < 2 * n) m *= 2;
+      const T k0 = knots[0], kn = knots[n - 1];
+      const T scale = T(m) / (kn - k0);
+      if (!(scale > T(0)) || !std::isfinite((double)scale)) return;
+      std::vector<uint32_t> lut((size_t)m + 2, 0);
+      for (uint64_t i = 0; i < n; ++i) lut[bucket_of<T>(knots[i], k0, scale, m) + 1]++;   // counts, shifted by one
+      for (uint32_t b = 0; b < m; ++b) lut[b + 1] += lut[b];                              // lut[b] = knots in buckets < b
+      lut[m + 1] = (uint32_t)n;
+      self->lut32_buf.reserve(lut.size() * sizeof(uint32_t));
+      NDI_HIP(hipMemcpy(self->lut32_buf.p, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      self->bidx32 = BucketIndex32<T>{self->lut32_buf.template as<uint32_t>(), m, scale};
+    });
+  }
+
   // Bucket index (kernels.hpp, BucketIndex): only for axes the O(1) formula guess does not resolve for every x, with
   // u16 entries (n <= 65535) and more than one top-level block.  Built with bucket_of(), the function the device uses.
   DevBuf lut_buf;
@@ -558,6 +584,11 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
     // staging is the fixed cost of a workgroup now: no more workgroups than the chip holds at once
     const size_t total = shmem + (hist ? (size_t)nb * 4 : 0);
     blocks = std::min<uint64_t>(blocks, (uint64_t)cu_count() * std::max<size_t>(1, (160 * 1024) / total));
+  }
+  A.bx32 = BucketIndex32<T>{nullptr, 0, T(0)};
+  if (lut_env && !A.stage_lds && nq >= 4096) {
+    pyr.ensure_bucket_index32();
+    A.bx32 = pyr.bidx32;
   }
   if (hist) shmem += (size_t)nb * 4;
   // beside a running evaluation kernel (ring pipeline) a 4-wave workgroup finds room wherever one evaluation
@@ -1070,7 +1101,22 @@ struct Interp1DImpl final : Interp1DBase {
     reset_status(sc.status.p, s);
     StatusBlock* st = sc.status.as<StatusBlock>();
 
-    if (lanes <= 2 && pyr.lds_bytes <= LDS_STAGE_LIMIT) {   // one thread per query only pays for 1-2 lanes
+    // 1-2 lanes: one thread per query (search + evaluation in one launch, tables gathered from L2) is the latency path
+    // and the faster one up to a few million queries; beyond, the query-order kernel with the tables in LDS takes over
+    // (scalar data at 1e8 queries: 98 -> 157 Gqueries/s f64, 2 lanes 45 -> 141).  Measured crossover
+    // (profiles/r04_scalar_crossover.jsonl): ~8e6 output elements on <= 1024 knots, proportionally earlier on longer
+    // axes (8192 knots: ~1e6), whose table gathers miss L1.  NDI_SMALL_MAXQ overrides the 8e6.
+    static const long small_maxq = ShortKnobs::env("NDI_SMALL_MAXQ", 8000000);
+    const bool small_first = lanes <= 2 && pyr.lds_bytes <= LDS_STAGE_LIMIT;
+    const double small_work = (double)nq * (double)lanes * (double)std::max<uint64_t>(n, 1024) / 1024.0;
+    if (small_first && small_work >= (double)small_maxq) {
+      const ShortKnobs K0 = short_knobs();
+      constexpr int VN0 = Wide<T>::N;
+      P.vec_ok = (lanes % VN0 == 0) && (out_stride % VN0 == 0) && aligned16(out);
+      P.LV = P.vec_ok ? lanes / VN0 : lanes;
+      if (K0.mode != 1 && K0.mode != 3 && plan_fused(s, sc, P, K0)) return P;
+    }
+    if (small_first) {
       // short trailing axes: range pre-check (so rows after the first failing query stay untouched in the
       // caller's buffer), then search + evaluation fused in one launch -- no index / t round trip through HBM
       P.kind = Plan1::SMALL;

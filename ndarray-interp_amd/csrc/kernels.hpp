@@ -345,6 +345,8 @@ __device__ __forceinline__ uint32_t locate_index_lut(const PyramidLds<T>& P, lds
   return s;
 }
 
+constexpr int LOCATE_QB = 4;   // batches of 64 queries per wave whose queries are requested together (locate kernels)
+
 template <class T>
 struct LocateArgs {
   Pyramid<T> pyr;          // global-memory pyramid
@@ -376,14 +378,38 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
   const uint64_t q_begin = (uint64_t)blockIdx.x * A.slice;
   uint64_t q_end = q_begin + A.slice;
   if (q_end > A.nq) q_end = A.nq;
-  // software-pipelined: the next batch's queries are requested before the current batch is searched
+  // Software-pipelined: the queries of QB batches are requested together, one round ahead, with unconditional
+  // (clamped) loads.  The wave's memory-operation counter is in-order and counts stores: the first use of a freshly
+  // loaded query waits for every index the wave has stored before it -- once per QB batches instead of per batch.
+  constexpr int QB = LOCATE_QB;
   const uint64_t first = q_begin + (uint64_t)(tid >> 6) * 64u;
-  T x_next = (first + lane < q_end) ? A.q[first + lane] : k0;
-  for (uint64_t base = first; base < q_end; base += blockDim.x) {
+  const uint64_t q_last = A.nq - 1u;
+  T xq[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const uint64_t p = first + (uint64_t)j * blockDim.x + lane;
+    xq[j] = A.q[p < A.nq ? p : q_last];
+  }
+  for (uint64_t round0 = first; round0 < q_end; round0 += (uint64_t)QB * blockDim.x) {
+  T xc[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) xc[j] = xq[j];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const uint64_t p = round0 + (uint64_t)(QB + j) * blockDim.x + lane;
+    xq[j] = A.q[p < A.nq ? p : q_last];
+  }
+#pragma unroll 1
+  for (int jb = 0; jb < QB; ++jb) {
+    const uint64_t base = round0 + (uint64_t)jb * blockDim.x;
+    if (base >= q_end) break;
     const uint64_t qi = base + lane;
     const bool active = qi < q_end;
-    const T x = x_next;
-    x_next = (qi + blockDim.x < q_end) ? A.q[qi + blockDim.x] : k0;
+    T x = xc[0];
+#pragma unroll
+    for (int j = 1; j < QB; ++j)
+      if (jb == j) x = xc[j];
+    if (!active) x = k0;
     const bool inr = (k0 <= x) && (x <= kn);   // Interp1D::is_in_range, interp1d/mod.rs:384-386
     T xs = x;
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;
@@ -412,6 +438,7 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
     }
     if (s_hist) atomicAdd(&s_hist[NDI_CHK(i, A.nb, BC_BIN)], 1u);
   }
+  }
 }
 
 // One workgroup (256..1024 threads, chosen by the host so that the LDS footprint still allows a full CU of
@@ -420,6 +447,7 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
 template <class T, bool STAGE>
 __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (A.nq == 0) return;   // (the clamped query loads below address q[nq - 1])
   const uint32_t tid = threadIdx.x;
   uint32_t* s_hist = nullptr;
   size_t hist_off = 0;
@@ -484,6 +512,7 @@ struct Locate2Args {
 template <class T>
 __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (A.nq == 0) return;   // (the clamped query loads below address q[nq - 1])
   const uint32_t tid = threadIdx.x;
   const uint32_t nxa = A.px.n + A.px.n1, nya = A.py.n + A.py.n1;
   T* sx = reinterpret_cast<T*>(smem_raw);
@@ -527,14 +556,38 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   uint64_t q_end = q_begin + A.slice;
   if (q_end > A.nq) q_end = A.nq;
   const uint64_t first = q_begin + (uint64_t)(tid >> 6) * 64u;
-  T x_next = (first + lane < q_end) ? A.qx[first + lane] : x0;
-  T y_next = (first + lane < q_end) ? A.qy[first + lane] : y0;
-  for (uint64_t base = first; base < q_end; base += blockDim.x) {
+  constexpr int QB = LOCATE_QB;          // (see locate_slice: one store drain per QB batches instead of per batch)
+  const uint64_t q_last = A.nq - 1u;
+  T xq[QB], yq[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const uint64_t p = first + (uint64_t)j * blockDim.x + lane;
+    const uint64_t pc = p < A.nq ? p : q_last;
+    xq[j] = A.qx[pc];
+    yq[j] = A.qy[pc];
+  }
+  for (uint64_t round0 = first; round0 < q_end; round0 += (uint64_t)QB * blockDim.x) {
+  T xc[QB], yc[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) { xc[j] = xq[j]; yc[j] = yq[j]; }
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const uint64_t p = round0 + (uint64_t)(QB + j) * blockDim.x + lane;
+    const uint64_t pc = p < A.nq ? p : q_last;
+    xq[j] = A.qx[pc];
+    yq[j] = A.qy[pc];
+  }
+#pragma unroll 1
+  for (int jb = 0; jb < QB; ++jb) {
+    const uint64_t base = round0 + (uint64_t)jb * blockDim.x;
+    if (base >= q_end) break;
     const uint64_t qi = base + lane;
     const bool active = qi < q_end;
-    const T x = x_next, y = y_next;
-    x_next = (qi + blockDim.x < q_end) ? A.qx[qi + blockDim.x] : x0;
-    y_next = (qi + blockDim.x < q_end) ? A.qy[qi + blockDim.x] : y0;
+    T x = xc[0], y = yc[0];
+#pragma unroll
+    for (int j = 1; j < QB; ++j)
+      if (jb == j) { x = xc[j]; y = yc[j]; }
+    if (!active) { x = x0; y = y0; }
     const uint32_t ix = lutx ? locate_index_lut<T>(PX, lutx, A.bx.m, A.bx.scale, x0, xn, x)
                              : locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
     const uint32_t iy = luty ? locate_index_lut<T>(PY, luty, A.by.m, A.by.scale, y0, yn, y)
@@ -552,6 +605,7 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
       A.xi[qi] = NDI_CHK(ix, PX.n - 1u, BC_CELL_X) | (NDI_CHK(iy, PY.n - 1u, BC_CELL_Y) << 16);
     }
     if (s_hist) atomicAdd(&s_hist[NDI_CHK((ix >> A.sx) * A.nty + (iy >> A.sy), A.nb, BC_BIN)], 1u);
+  }
   }
   if (s_hist) {
     __syncthreads();
@@ -913,6 +967,7 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
   constexpr bool STRIP2 = STRAT == ST_LINEAR || TLDS == 2;   // a second per-query scalar: (x - x1) / the interval's dx
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr uint32_t WAVES = TB / 64;
+  if (A.nq == 0) return;   // (the clamped query loads below address q[nq - 1])
   const uint32_t tid = threadIdx.x;
   const uint32_t n = A.pyr.n, n1 = A.pyr.n1;
   // LDS: [pyramid | lut | per-wave strips (interval, c0, c1) | tables]

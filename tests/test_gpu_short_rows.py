@@ -302,3 +302,56 @@ def test_yk_form_after_every_build_kernel(pkg, dt, capfd):
         if L > 2:   # (1-2 lanes take the one-thread-per-query kernel)
             assert "tables=lds{y,k}" in err, (name, n, L, err)
         assert np.array_equal(got, ref, equal_nan=True), f"{name} n={n} L={L}: {{y, k}} rows differ from the table form"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_device_buffer_fuzz(pkg, seed):
+    """Seeded fuzz over what AUTO / GATHER / BUCKETED pick for device-resident batches: random knot counts (incl. axes
+    too long for LDS: the global-memory bucket index), lanes from scalar data to 500, batch sizes from 1 to 400 000
+    (both sides of the one-thread-per-query / query-order and of the grouped thresholds), both strategies,
+    extrapolation and the periodic wrap -- every row against the oracle, bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4242 + seed)
+    for _ in range(10):
+        dt = rng.choice([np.float64, np.float32])
+        tdt = torch.float64 if dt == np.float64 else torch.float32
+        cubic = bool(rng.integers(0, 2))
+        n = int(rng.choice([3 if cubic else 2, 5, 64, 65, 100, 777, 1024, 3000, 25_000, 70_000]))
+        L = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 24, 32, 63, 64, 100, 128, 200, 256, 500]))
+        if n >= 25_000:
+            L = min(L, 8)
+        Q = int(rng.choice([1, 63, 64, 65, 1000, 4095, 4096, 50_000, 400_000]))
+        if Q * L > 40_000_000:
+            Q = 40_000_000 // L
+        path = int(rng.choice([pkg.PATH_AUTO, pkg.PATH_GATHER, pkg.PATH_BUCKETED]))
+        x = knots(rng.choice(["rand", "jit", "log", "lin"]), n, rng, dt) if n > 3 else np.arange(n).astype(dt)
+        y = rng.uniform(-1, 1, (n, L)).astype(dt)
+        ext = bool(rng.integers(0, 2))
+        per = cubic and n >= 3 and bool(rng.integers(0, 3) == 0)
+        span = float(x[-1] - x[0])
+        m = 0.4 if ext else 0.0
+        q = rng.uniform(x[0] - m * span, x[-1] + m * span, Q).astype(dt)
+        if not ext:
+            q = np.clip(q, x[0], x[-1])
+        if cubic:
+            if per:
+                y[-1] = y[0]
+            os.environ["NDI_SPLINE_BLOCKED"] = "0"      # bit-identical tables: this test is about the evaluation
+            try:
+                strat = pkg.CubicSpline.new().extrapolate(ext)
+                if per:
+                    strat = strat.boundary(pkg.BoundaryCondition.Periodic)
+                it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)).strategy(strat).build()
+            finally:
+                del os.environ["NDI_SPLINE_BLOCKED"]
+            st, a, b = oracle.cubic_build(x, y, periodic=per)
+            assert st == oracle.OK
+            mode = (2 if per else 1) if ext else 0
+            _, _, ref = oracle.interp1d_cubic(x, y, a, b, q, mode)
+        else:
+            it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
+                .strategy(pkg.Linear.new().extrapolate(ext)).build()
+            _, _, ref = oracle.interp1d_linear(x, y, q, ext)
+        got = _device_eval(pkg, it, q, L, path, tdt, fill=-9.0).cpu().numpy()
+        check_equal(got, ref.reshape(Q, L), f"fuzz seed={seed} dt={np.dtype(dt).name} cubic={cubic} per={per} ext={ext} n={n} L={L} Q={Q} path={path}")

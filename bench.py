@@ -424,6 +424,32 @@ def short_rows_leg(pkg, torch, dev, out_bytes=4e9, steps=5):
     for r in res["shapes"]:
         ref = next(s for s in res["shapes"] if s["dtype"] == r["dtype"] and s["lanes"] * np.dtype(r["dtype"]).itemsize == 32768)
         r["frac_of_long_row_rate"] = round(r["out_TBps"] / ref["out_TBps"], 3)
+    # the reference's own bench shapes scaled up to 1e8 / 5e7 queries: scalar data on 100 and 1024 knots, (100, 5)
+    res["reference_shapes"] = []
+    for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        el = np.dtype(dt).itemsize
+        for n, L, Q in ((100, 1, 100_000_000), (1024, 1, 100_000_000), (100, 5, 50_000_000)):
+            x = np.unique(rng.uniform(0, 1, 2 * n).astype(dt))[:n]
+            xd = torch.as_tensor(x, device=dev)
+            yd = torch.rand((xd.numel(), L), dtype=tdt, device=dev)
+            interp = pkg.Interp1DBuilder.new(yd).x(xd).strategy(pkg.CubicSpline.new()).build()
+            qd = (torch.rand(Q, dtype=tdt, device=dev) * (xd[-1] - xd[0]) * 0.999 + xd[0]).clamp(xd[0], xd[-1])
+            out = torch.empty((Q, L), dtype=tdt, device=dev)
+            call = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
+            call(); interp.strategy.finish()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                call()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / steps
+            interp.strategy.finish()
+            res["reference_shapes"].append({"dtype": np.dtype(dt).name, "knots": int(xd.numel()), "lanes": L, "queries": Q,
+                                            "ms": round(wall * 1e3, 4), "Gqueries_s": round(Q / wall / 1e9, 1),
+                                            "out_TBps": round(Q * L * el / wall / 1e12, 3)})
+            interp.strategy.release()
+            del interp, qd, yd, out
+        torch.cuda.empty_cache()
     return res
 
 

@@ -345,7 +345,7 @@ __device__ __forceinline__ uint32_t locate_index_lut(const PyramidLds<T>& P, lds
   return s;
 }
 
-constexpr int LOCATE_QB = 4;   // batches of 64 queries per wave whose queries are requested together (locate kernels)
+constexpr int LOCATE_QB = 4;   // batches of 64 queries per wave whose queries are requested together (long slices)
 
 template <class T>
 struct LocateArgs {
@@ -368,7 +368,7 @@ struct LocateArgs {
 };
 
 // Body of locate_kernel for one pyramid address space.
-template <class T, class PTR>
+template <class T, class PTR, int QB>
 __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const PyramidT<T, PTR>& P, uint32_t* s_hist,
                                              lds_u16 lut = nullptr) {
   const uint32_t tid = threadIdx.x;
@@ -381,14 +381,16 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
   // Software-pipelined: the queries of QB batches are requested together, one round ahead, with unconditional
   // (clamped) loads.  The wave's memory-operation counter is in-order and counts stores: the first use of a freshly
   // loaded query waits for every index the wave has stored before it -- once per QB batches instead of per batch.
-  constexpr int QB = LOCATE_QB;
+  // QB = 4 for slices of >= 16 batches per wave (the grouped forms, the ring's chunks: two-axis search -17 %); QB = 1
+  // for the many short slices of a plain search, where a round of look-ahead is a quarter of the slice (+18 % there).
   const uint64_t first = q_begin + (uint64_t)(tid >> 6) * 64u;
-  const uint64_t q_last = A.nq - 1u;
+  if (q_begin >= q_end) return;              // (no barrier follows in this function)
+  const uint64_t q_last = q_end - 1u;        // look-ahead past the slice re-reads its last query (one hot line)
   T xq[QB];
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const uint64_t p = first + (uint64_t)j * blockDim.x + lane;
-    xq[j] = A.q[p < A.nq ? p : q_last];
+    xq[j] = A.q[p < q_end ? p : q_last];
   }
   for (uint64_t round0 = first; round0 < q_end; round0 += (uint64_t)QB * blockDim.x) {
   T xc[QB];
@@ -397,7 +399,7 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const uint64_t p = round0 + (uint64_t)(QB + j) * blockDim.x + lane;
-    xq[j] = A.q[p < A.nq ? p : q_last];
+    xq[j] = A.q[p < q_end ? p : q_last];
   }
 #pragma unroll 1
   for (int jb = 0; jb < QB; ++jb) {
@@ -444,7 +446,7 @@ __device__ __forceinline__ void locate_slice(const LocateArgs<T>& A, const Pyram
 // One workgroup (256..1024 threads, chosen by the host so that the LDS footprint still allows a full CU of
 // waves) per contiguous slice of queries.  LDS: [pyramid | histogram].
 // STAGE: the pyramid is copied into LDS first (compile-time, so the search reads are ds_read).
-template <class T, bool STAGE>
+template <class T, bool STAGE, int QB = LOCATE_QB>
 __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (A.nq == 0) return;   // (the clamped query loads below address q[nq - 1])
@@ -478,9 +480,9 @@ __global__ __launch_bounds__(1024) void locate_kernel(LocateArgs<T> A) {
     P.lv0 = (lds_ptr<T>)(smem_raw);
     P.lv1 = P.lv0 + n;
     P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
-    locate_slice<T, lds_ptr<T>>(A, P, s_hist, lut);
+    locate_slice<T, lds_ptr<T>, QB>(A, P, s_hist, lut);
   } else {
-    locate_slice<T, const T*>(A, A.pyr, s_hist);
+    locate_slice<T, const T*, QB>(A, A.pyr, s_hist);
   }
   if (A.hist) {
     __syncthreads();
@@ -509,7 +511,7 @@ struct Locate2Args {
   uint32_t nb, sx, sy, nty;
 };
 
-template <class T>
+template <class T, int QB = LOCATE_QB>
 __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (A.nq == 0) return;   // (the clamped query loads below address q[nq - 1])
@@ -556,13 +558,13 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   uint64_t q_end = q_begin + A.slice;
   if (q_end > A.nq) q_end = A.nq;
   const uint64_t first = q_begin + (uint64_t)(tid >> 6) * 64u;
-  constexpr int QB = LOCATE_QB;          // (see locate_slice: one store drain per QB batches instead of per batch)
-  const uint64_t q_last = A.nq - 1u;
+  // (QB: see locate_slice -- one store drain per QB batches instead of per batch)
+  const uint64_t q_last = (q_end > q_begin ? q_end : q_begin + 1u) - 1u;   // look-ahead past the slice: its last query again
   T xq[QB], yq[QB];
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const uint64_t p = first + (uint64_t)j * blockDim.x + lane;
-    const uint64_t pc = p < A.nq ? p : q_last;
+    const uint64_t pc = p < q_end ? p : q_last;
     xq[j] = A.qx[pc];
     yq[j] = A.qy[pc];
   }
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const uint64_t p = round0 + (uint64_t)(QB + j) * blockDim.x + lane;
-    const uint64_t pc = p < A.nq ? p : q_last;
+    const uint64_t pc = p < q_end ? p : q_last;
     xq[j] = A.qx[pc];
     yq[j] = A.qy[pc];
   }

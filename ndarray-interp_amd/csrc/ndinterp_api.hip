@@ -600,12 +600,17 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
   A.slice = slice;
   A.hist = hist;
   A.nb = nb;
-  allow_dynamic_lds(reinterpret_cast<const void*>(&locate_kernel<T, true>), (int)LDS_STAGE_LIMIT);
-  allow_dynamic_lds(reinterpret_cast<const void*>(&locate_kernel<T, false>), (int)LDS_STAGE_LIMIT);
+  allow_dynamic_lds(reinterpret_cast<const void*>(&locate_kernel<T, true, LOCATE_QB>), (int)LDS_STAGE_LIMIT);
+  allow_dynamic_lds(reinterpret_cast<const void*>(&locate_kernel<T, false, LOCATE_QB>), (int)LDS_STAGE_LIMIT);
+  allow_dynamic_lds(reinterpret_cast<const void*>(&locate_kernel<T, true, 1>), (int)LDS_STAGE_LIMIT);
+  allow_dynamic_lds(reinterpret_cast<const void*>(&locate_kernel<T, false, 1>), (int)LDS_STAGE_LIMIT);
   if (slice_out) *slice_out = slice;
   if (blocks_out) *blocks_out = (uint32_t)blocks;
-  if (A.stage_lds) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, true>, A);
-  else launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, false>, A);
+  const bool deep = slice / threads >= 16;   // batches per wave: queries of 4 batches requested together only then
+  if (A.stage_lds && deep) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, true, LOCATE_QB>, A);
+  else if (A.stage_lds) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, true, 1>, A);
+  else if (deep) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, false, LOCATE_QB>, A);
+  else launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate_kernel<T, false, 1>, A);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -2017,8 +2022,10 @@ struct Interp2DImpl final : Interp2DBase {
       slice = (slice + threads - 1) / threads * threads;
       blocks = (nq + slice - 1) / slice;
       LA.slice = slice;
-      allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T>), (int)LDS_STAGE_LIMIT);
-      launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate2_kernel<T>, LA);
+      allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T, LOCATE_QB>), (int)LDS_STAGE_LIMIT);
+      allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T, 1>), (int)LDS_STAGE_LIMIT);
+      if (slice / threads >= 16) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate2_kernel<T, LOCATE_QB>, LA);
+      else launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate2_kernel<T, 1>, LA);
     } else {
       run_locate<T>(s, px, qx, nq, sc.idx.as<uint32_t>(), nullptr, nullptr, &st->first_fail[0], mode);
       run_locate<T>(s, py, qy, nq, sc.idx2.as<uint32_t>(), nullptr, nullptr, &st->first_fail[1], mode);

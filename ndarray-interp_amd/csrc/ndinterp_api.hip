@@ -1074,7 +1074,11 @@ struct Interp1DImpl final : Interp1DBase {
         }
       }
       const size_t tab = fused_lds_bytes(false, 64, P.f_tlds) - fused_lds_bytes(false, 64, 0);
-      if (P.f_tlds && K.lds < 0 && P.nq * lanes * sizeof(T) < 8 * (size_t)cu_count() * tab) {
+      // not for small batches (the staging pass is per workgroup), and not for Linear rows of 128 B (f32: 64 B) or more:
+      // two operand reads per item from L2 beat the workgroups that fit around a 64-128 KiB table (f32 x 32: 5.6 vs 4.9
+      // TB/s, f32 x 16: 5.25 vs 4.76; f64 x 8 and f32 x 8 stay in LDS: 3.75 vs 2.8, 4.0 vs 2.8)
+      if (P.f_tlds && K.lds < 0 && (P.nq * lanes * sizeof(T) < 8 * (size_t)cu_count() * tab ||
+                                    (strategy != NDI_CUBIC_SPLINE && lanes * sizeof(T) >= (sizeof(T) == 4 ? 64 : 128)))) {
         P.f_tlds = 0;
         P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : 256u;
       }
@@ -1150,8 +1154,10 @@ struct Interp1DImpl final : Interp1DBase {
       grouped_short = short_rows && group_ok && K.mode != 1 && K.mode != 2;
     } else if (path == NDI_PATH_AUTO) {
       bucketed = rows_ok && nq < 0xffffffffull && nq >= 5 * (n - 1);  // measured crossover (tools/auto_threshold.py)
+      // (Linear reads two operand rows per item instead of four: its query-order form already runs at 5-6 TB/s on rows
+      //  of 128 B - 2 KiB and beats the grouped form everywhere: profiles/r04_short_rows_linear_sweep.txt)
       grouped_short = short_rows && group_ok && nq >= 5 * (n - 1) &&
-                      (K.mode == 3 || (K.mode == 0 && lanes * sizeof(T) >= (uint64_t)K.rowb));
+                      (K.mode == 3 || (K.mode == 0 && strategy == NDI_CUBIC_SPLINE && lanes * sizeof(T) >= (uint64_t)K.rowb));
     }
     if (short_rows && !grouped_short && !bucketed && K.mode != 1 && K.mode != 3 && plan_fused(s, sc, P, K)) return P;
     g_last_path.store(bucketed || grouped_short ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);

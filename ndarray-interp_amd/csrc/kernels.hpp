@@ -1600,6 +1600,14 @@ __device__ __forceinline__ bool nums_in_window(flt4 n) {
   const float sum = (fabsf(n.x) + fabsf(n.y)) + (fabsf(n.z) + fabsf(n.w));
   return (lo >= DivWindow<float>::N_LO) & (sum <= DivWindow<float>::N_HI);
 }
+__device__ __forceinline__ bool nums_in_window(float n) {
+  const float a = fabsf(n);
+  return (a >= DivWindow<float>::N_LO) & (a <= DivWindow<float>::N_HI);
+}
+__device__ __forceinline__ bool nums_in_window(double n) {
+  const double a = fabs(n);
+  return (a >= DivWindow<double>::N_LO) & (a <= DivWindow<double>::N_HI);
+}
 __device__ __forceinline__ bool nums_in_window(dbl2 n) {
   const double lo = fmin(fabs(n.x), fabs(n.y));
   const double sum = fabs(n.x) + fabs(n.y);
@@ -2096,6 +2104,9 @@ struct EvalSmall2Args {
   int mode;
   unsigned long long* first_fail;  // [2]
   int prechecked;                  // see EvalSmallArgs
+  BucketIndex<T> bx, by;           // bucket indices staged behind the pyramids when non-null (large device batches)
+  int sdiv;                        // 1: the three divisions of a value share the query's two correctly rounded
+                                   //    reciprocals (div_shared: the same bits as the IEEE divisions)
 };
 
 template <class T>
@@ -2103,11 +2114,23 @@ __global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x;
   const uint32_t nxa = A.px.n + A.px.n1, nya = A.py.n + A.py.n1;
+  lds_u16 lutx = nullptr, luty = nullptr;
   {
     T* sx = reinterpret_cast<T*>(smem_raw);
     T* sy = sx + nxa;
     for (uint32_t i = tid; i < nxa; i += BLOCK) sx[i] = A.px.lv0[i];
     for (uint32_t i = tid; i < nya; i += BLOCK) sy[i] = A.py.lv0[i];
+    if (A.bx.lut || A.by.lut) {   // [x pyramid | y pyramid | x lut | y lut], as in locate2_kernel
+      const size_t off = ((size_t)(nxa + nya) * sizeof(T) + 15u) & ~(size_t)15u;
+      uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
+      const uint32_t wx = A.bx.lut ? (A.bx.m + 2u) / 2u : 0u, wy = A.by.lut ? (A.by.m + 2u) / 2u : 0u;
+      const uint32_t* srcx = reinterpret_cast<const uint32_t*>(A.bx.lut);
+      const uint32_t* srcy = reinterpret_cast<const uint32_t*>(A.by.lut);
+      for (uint32_t i = tid; i < wx; i += BLOCK) sl[i] = srcx[i];
+      for (uint32_t i = tid; i < wy; i += BLOCK) sl[wx + i] = srcy[i];
+      if (wx) lutx = (lds_u16)(smem_raw + off);
+      if (wy) luty = (lds_u16)(smem_raw + off + (size_t)wx * 4u);
+    }
   }
   __syncthreads();
   PyramidLds<T> PX, PY;
@@ -2128,8 +2151,10 @@ __global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A
     const bool active = qi < limit;
     const T x = active ? A.qx[qi] : x0;
     const T y = active ? A.qy[qi] : y0;
-    const uint32_t xi = locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
-    const uint32_t yi = locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
+    const uint32_t xi = lutx ? locate_index_lut<T>(PX, lutx, A.bx.m, A.bx.scale, x0, xn, x)
+                             : locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
+    const uint32_t yi = luty ? locate_index_lut<T>(PY, luty, A.by.m, A.by.scale, y0, yn, y)
+                             : locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
     if (!active) continue;
     const bool badx = (A.mode == EX_NO) ? !((x0 <= x) && (x <= xn)) : !(x == x);
     const bool bady = (A.mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
@@ -2142,10 +2167,19 @@ __global__ __launch_bounds__(BLOCK) void eval_small2d_kernel(EvalSmall2Args<T> A
     const T* z21 = A.data + ((uint64_t)(xi + 1) * A.row_cells + yi) * A.cell_elems;
     const T* z22 = z21 + L;
     T* o = A.out + qi * A.out_stride;
-    for (uint32_t l = 0; l < L; ++l) {
-      const T z1 = frac_v<T, T>(x1, z11[l], x2, z21[l], x);
-      const T z2 = frac_v<T, T>(x1, z12[l], x2, z22[l], x);
-      o[l] = frac_v<T, T>(y1, z1, y2, z2, y);
+    if (A.sdiv) {   // one IEEE reciprocal per direction and query, three correctly rounded shared-divisor divisions per value
+      const SharedDivisor<T> dx = shared_divisor<T>(x2 - x1), dy = shared_divisor<T>(y2 - y1);
+      for (uint32_t l = 0; l < L; ++l) {
+        const T z1 = frac_shared<T, T>(x1, z11[l], dx, z21[l], x);   // bilinear.rs:88-97
+        const T z2 = frac_shared<T, T>(x1, z12[l], dx, z22[l], x);
+        o[l] = frac_shared<T, T>(y1, z1, dy, z2, y);
+      }
+    } else {
+      for (uint32_t l = 0; l < L; ++l) {
+        const T z1 = frac_v<T, T>(x1, z11[l], x2, z21[l], x);
+        const T z2 = frac_v<T, T>(x1, z12[l], x2, z22[l], x);
+        o[l] = frac_v<T, T>(y1, z1, y2, z2, y);
+      }
     }
   }
 }

@@ -1930,7 +1930,15 @@ struct Interp2DImpl final : Interp2DBase {
     reset_status(sc.status.p, s);
     StatusBlock* st = sc.status.as<StatusBlock>();
     const size_t both = ((px.lds_bytes + py.lds_bytes + 15) & ~(size_t)15);
-    if (lanes <= 2 && both <= LDS_STAGE_LIMIT && path != NDI_PATH_BUCKETED) {
+    // 1-2 values per grid point: one query per thread -- both searches and the evaluation in one launch, no (xi, yi)
+    // round trip, two reciprocals per query instead of three divisions per value.  (NDI_SMALL2D_LANES extends it to
+    // unaligned rows of up to that many values for A/B runs: measured SLOWER from 3 values -- 100 x 100 x 5 f64: 11 vs
+    // 21 Gqueries/s -- a thread per query turns every operand load into 64 scattered sectors, where the item-per-lane
+    // gather kernel reads each query's 40-byte segments whole.)
+    static const int small2d_lanes = ShortKnobs::env("NDI_SMALL2D_LANES", 2);
+    constexpr int VNs = Wide<T>::N;
+    const bool small2d = lanes <= 2 || (lanes <= (uint64_t)small2d_lanes && lanes % VNs != 0);
+    if (small2d && both <= LDS_STAGE_LIMIT && path != NDI_PATH_BUCKETED) {
       // short trailing axes: range pre-check, then both searches + evaluation fused in one launch
       P.kind = Plan2::SMALL;
       g_last_path.store(NDI_PATH_GATHER);
@@ -2117,7 +2125,24 @@ struct Interp2DImpl final : Interp2DBase {
       S.mode = mode;
       S.first_fail = &st->first_fail[0];
       S.prechecked = 1;
-      launch1<T>(s, PC_EVAL, dim3(g), dim3(BLOCK), both, eval_small2d_kernel<T>, S);
+      // large batches: bucket indices behind the pyramids (as the two-axis search stages them), and from two values per
+      // query the shared-divisor division (two reciprocals per query instead of three divisions per value: same bits)
+      size_t shm = both;
+      static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+      if (lut_env && nq >= 4096) {
+        px.ensure_bucket_index();
+        py.ensure_bucket_index();
+        if ((px.lut_bytes || py.lut_bytes) && both + px.lut_bytes + py.lut_bytes <= LDS_STAGE_LIMIT / 2) {
+          S.bx = px.bidx;
+          S.by = py.bidx;
+          shm = both + px.lut_bytes + py.lut_bytes;
+        }
+      }
+      S.sdiv = lanes >= 2 ? 1 : 0;
+      unsigned gs = g;
+      if (shm > both)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
+        gs = (unsigned)std::min<uint64_t>(g, (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / shm)));
+      launch1<T>(s, PC_EVAL, dim3(gs), dim3(BLOCK), shm, eval_small2d_kernel<T>, S);
       return;
     }
     Eval2Args<T> A{};

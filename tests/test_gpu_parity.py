@@ -1117,3 +1117,46 @@ def test_bilinear_tiles_shared_divisor_window(pkg, dt):
     both_nan = np.isnan(got["gather"]) & np.isnan(got["tiles"])
     assert np.all(same | both_nan)
     assert np.isfinite(ref).mean() > 0.5                            # the case is not degenerate
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("C", [1, 2, 3, 5, 6, 7, 8])
+def test_bilinear_small_channels_device_buffers(pkg, dt, C):
+    """Scalar grids and rows of a few values that are not 16-byte vectors (the reference's 100 x 100 and 100 x 100 x 5,
+    benches/bench_interp2d.rs) on device-resident buffers: one query per thread, both searches (bucket index from 4096
+    queries, pyramid below) and the evaluation in one launch, the three divisions of a value through the query's two
+    correctly rounded reciprocals -- the oracle's bits (bilinear.rs:64-99), incl. values far outside the divisor window,
+    extrapolation, and the first-error cut."""
+    import torch
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(500 + C)
+    for nx, ny, Q in ((100, 100, 100_000), (37, 300, 1000), (2, 2, 5000), (700, 45, 70_001)):
+        x = knots("rand", nx, rng, dt) if nx > 2 else np.array([0.0, 2.0], dtype=dt)
+        y = knots("jit", ny, rng, dt) if ny > 2 else np.array([-1.0, 0.5], dtype=dt)
+        g = rng.uniform(-1, 1, (nx, ny, C)).astype(dt)
+        g[0, 0] = 0.0; g[-1, -1] = np.finfo(dt).max / 4; g[nx // 2, ny // 2] = np.finfo(dt).tiny    # outside the window
+        if nx > 4:
+            g[3, :, 0] = g[4, :, 0]                                                                  # flat: zero numerators
+        for ext in (False, True):
+            m = 0.3 if ext else 0.0
+            sx, sy = float(x[-1] - x[0]), float(y[-1] - y[0])
+            qx = rng.uniform(x[0] - m * sx, x[-1] + m * sx, Q).astype(dt)
+            qy = rng.uniform(y[0] - m * sy, y[-1] + m * sy, Q).astype(dt)
+            if not ext:
+                qx = np.clip(qx, x[0], x[-1]); qy = np.clip(qy, y[0], y[-1])
+            qx[:3] = [x[0], x[-1], x[0]]; qy[:3] = [y[0], y[-1], y[-1]]
+            it = pkg.Interp2DBuilder.new(torch.as_tensor(g if C > 1 else g[..., 0], device=dev)).x(torch.as_tensor(x, device=dev)) \
+                .y(torch.as_tensor(y, device=dev)).strategy(pkg.Bilinear.new().extrapolate(ext)).build()
+            _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy, ext)
+            out = torch.full((Q, C), -4.0, dtype=tdt, device=dev)
+            it.strategy.interp_array_into(it, torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), out)
+            check_equal(out.cpu().numpy(), ref.reshape(Q, C), f"2-D small rows {nx}x{ny}x{C} Q={Q} ext={ext}")
+            if not ext:   # first error: rows before it written, later rows untouched
+                qx2 = qx.copy(); qx2[Q // 2] = x[-1] + 1
+                out2 = torch.full((Q, C), -4.0, dtype=tdt, device=dev)
+                with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+                    it.strategy.interp_array_into(it, torch.as_tensor(qx2, device=dev), torch.as_tensor(qy, device=dev), out2)
+                assert (ei.value.index, ei.value.axis) == (Q // 2, 0)
+                o2 = out2.cpu().numpy()
+                assert np.array_equal(o2[: Q // 2], ref.reshape(Q, C)[: Q // 2]) and np.all(o2[Q // 2:] == -4.0)

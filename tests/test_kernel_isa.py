@@ -73,6 +73,6 @@ def test_search_kernels_use_lds_and_cross_lane_ops(asm):
     text, _ = asm
     loc = [m for m in re.finditer(r"^(_ZN3ndi13locate_kernelId[^:]*):", text, flags=re.M)]
     assert loc
-    staged = _body(text, "_ZN3ndi13locate_kernelIdLb1EEEvNS_10LocateArgsIT_EE")
+    staged = _body(text, "_ZN3ndi13locate_kernelIdLb1ELi4EEEvNS_10LocateArgsIT_EE")
     assert "ds_bpermute_b32" in staged            # top pyramid level bisected across lanes
     assert re.search(r"\bds_read", staged) and "flat_load" not in staged     # explicit LDS pointers, no flat loads

@@ -355,3 +355,42 @@ def test_device_buffer_fuzz(pkg, seed):
             _, _, ref = oracle.interp1d_linear(x, y, q, ext)
         got = _device_eval(pkg, it, q, L, path, tdt, fill=-9.0).cpu().numpy()
         check_equal(got, ref.reshape(Q, L), f"fuzz seed={seed} dt={np.dtype(dt).name} cubic={cubic} per={per} ext={ext} n={n} L={L} Q={Q} path={path}")
+
+
+def test_auto_picks_the_measured_form(pkg, capfd):
+    """What AUTO takes for the shapes of profiles/r04_short_rows_*: the plan trace of the query-order kernel (or its
+    absence: grouped / one thread per query) for a large device-resident batch on 1024 knots."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1)
+    x = knots("rand", 1024, rng, np.float64)
+    expect = [   # (dtype, lanes, cubic, fragment of the trace or None = not the query-order kernel)
+        (np.float64, 8, True, "tables=lds{y,k}"), (np.float32, 8, True, "tables=lds{y,a,b}"),
+        (np.float32, 16, True, "tables=lds{y,k}"), (np.float64, 32, True, "tables=memory"),
+        (np.float64, 128, True, None),                      # 1 KiB rows, many queries per interval: grouped
+        (np.float64, 8, False, "tables=lds{y,a,b}"), (np.float32, 32, False, "tables=memory"),
+        (np.float64, 128, False, "tables=memory"),          # Linear: never grouped
+        (np.float64, 1, True, "tables=lds"),                # scalar data at 1e7 queries: the query-order kernel
+    ]
+    for dt, L, cubic, frag in expect:
+        tdt = torch.float64 if dt == np.float64 else torch.float32
+        Q = 10_000_000 if L == 1 else 600_000_000 // (L * np.dtype(dt).itemsize)
+        xs = np.unique(x.astype(dt))
+        yd = torch.rand((xs.size, L), dtype=tdt, device=dev)
+        strat = pkg.CubicSpline.new() if cubic else pkg.Linear.new()
+        it = pkg.Interp1DBuilder.new(yd).x(torch.as_tensor(xs, device=dev)).strategy(strat).build()
+        q = (torch.rand(Q, dtype=tdt, device=dev) * float(xs[-1] - xs[0]) * 0.999 + float(xs[0])).clamp(float(xs[0]), float(xs[-1]))
+        out = torch.empty((Q, L), dtype=tdt, device=dev)
+        capfd.readouterr()
+        os.environ["NDI_TRACE_PLAN"] = "1"
+        try:
+            with knobs():
+                it.interp_array_into(q, out)
+        finally:
+            del os.environ["NDI_TRACE_PLAN"]
+        err = capfd.readouterr().err
+        if frag is None:
+            assert "[ndi plan] fused" not in err, (np.dtype(dt).name, L, cubic, err)
+        else:
+            assert frag in err, (np.dtype(dt).name, L, cubic, err)
+        del out, q, it, yd

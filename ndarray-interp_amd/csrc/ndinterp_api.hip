@@ -2248,7 +2248,9 @@ struct Interp2DImpl final : Interp2DBase {
       // the IEEE divisions.  Same bits either way.
       allow_dynamic_lds(reinterpret_cast<const void*>(&eval_bilinear_kernel<T, VN, false, 2, TB, true>), (int)LDS_STAGE_LIMIT);
       allow_dynamic_lds(reinterpret_cast<const void*>(&eval_bilinear_kernel<T, VN, false, 2, TB, true, true>), (int)LDS_STAGE_LIMIT);
-      if (pair_packed)
+      static const int sdiv_env = [] { const char* e = std::getenv("NDI_BILINEAR_SDIV"); return e ? std::atoi(e) : -1; }();   // A/B
+      const bool sdiv = sdiv_env >= 0 ? sdiv_env != 0 : pair_packed;
+      if (sdiv)
         hipLaunchKernelGGL((eval_bilinear_kernel<T, VN, false, 2, TB, true, true>), dim3(gx), dim3(TB), (knot_bytes + 15) & ~(size_t)15, s, A, tile_q);
       else
         hipLaunchKernelGGL((eval_bilinear_kernel<T, VN, false, 2, TB, true>), dim3(gx), dim3(TB), (knot_bytes + 15) & ~(size_t)15, s, A, tile_q);

@@ -2060,6 +2060,177 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
   }
 }
 
+// 2-D GATHER order for rows of fewer than 256 vectors on axes that fit LDS twice over, QUERY ORDER with both searches
+// fused in -- the 2-D analogue of eval_fused_kernel, for the reference's own 2-D shapes (100 x 100 x 5,
+// benches/bench_interp2d.rs) and few-channel grids.  A wave takes 64 consecutive queries, one per lane: both searches
+// (bucket index or pyramid, staged in LDS), the cell's offset in the grid, (x - x1), (y - y1) and the two knot
+// spacings with their correctly rounded reciprocals (ONE IEEE division per direction and QUERY instead of three
+// divisions per value), parked in a wave-private LDS strip; then the wave walks the batch's 64 * LV output vectors in
+// row-major order, 64 per trip: four corner loads, three shared-divisor divisions (div_shared: the bits of the IEEE
+// divisions of bilinear.rs:88-97), one store -- a trip's stores are 1 KiB of consecutive output bytes.  No (xi, yi)
+// round trip through memory, no second launch.  The first failing query is known before the launch
+// (range_check_kernel): rows at / after it are never written (interp2d/mod.rs:297-306).
+template <class T>
+struct EvalFused2Args {
+  Pyramid<T> px, py;
+  BucketIndex<T> bx, by;   // lut == nullptr: pyramid search on that axis
+  const T* data;           // plain or pair-packed grid (pack_pairs_kernel)
+  const T* qx;
+  const T* qy;
+  T* out;
+  uint64_t nq, out_stride;
+  uint32_t lanes;
+  uint32_t lv;             // vectors per row
+  uint32_t lv_magic;       // ceil(2^32 / lv) for lv >= 2
+  uint32_t cell_vecs;      // vectors between z[xi][yi] and z[xi][yi+1]'s slot: lv (plain grid) or 2 lv (pair-packed)
+  uint32_t row_vecs;       // vectors between grid rows xi and xi + 1
+  int mode;
+  const unsigned long long* first_fail;   // [2]: x, y (range_check_kernel)
+};
+
+template <class T, int VEC, int UNR, int TB>
+__global__ __launch_bounds__(TB) void eval_fused2d_kernel(EvalFused2Args<T> A) {
+  using V = typename VecT<T, VEC>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t WAVES = TB / 64;
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nxa = A.px.n + A.px.n1, nya = A.py.n + A.py.n1;
+  // LDS: [x pyramid | y pyramid | x lut | y lut | per-wave strips: cell offset, fx, fy, dx, rx, dy, ry]
+  size_t off;
+  {
+    T* sx = reinterpret_cast<T*>(smem_raw);
+    T* sy = sx + nxa;
+    for (uint32_t i = tid; i < nxa; i += TB) sx[i] = A.px.lv0[i];
+    for (uint32_t i = tid; i < nya; i += TB) sy[i] = A.py.lv0[i];
+    off = ((size_t)(nxa + nya) * sizeof(T) + 15u) & ~(size_t)15u;
+  }
+  lds_u16 lutx = nullptr, luty = nullptr;
+  if (A.bx.lut || A.by.lut) {
+    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
+    const uint32_t wx = A.bx.lut ? (A.bx.m + 2u) / 2u : 0u, wy = A.by.lut ? (A.by.m + 2u) / 2u : 0u;
+    const uint32_t* srcx = reinterpret_cast<const uint32_t*>(A.bx.lut);
+    const uint32_t* srcy = reinterpret_cast<const uint32_t*>(A.by.lut);
+    for (uint32_t i = tid; i < wx; i += TB) sl[i] = srcx[i];
+    for (uint32_t i = tid; i < wy; i += TB) sl[wx + i] = srcy[i];
+    if (wx) lutx = (lds_u16)(smem_raw + off);
+    if (wy) luty = (lds_u16)(smem_raw + off + (size_t)wx * 4u);
+    off += (((size_t)(wx + wy) * 4u) + 15u) & ~(size_t)15u;
+  }
+  uint32_t* w_o = reinterpret_cast<uint32_t*>(smem_raw + off) + (tid >> 6) * 64u;
+  off += (size_t)WAVES * 64u * sizeof(uint32_t);
+  T* w_s = reinterpret_cast<T*>(smem_raw + off) + (tid >> 6) * 64u * 6u;   // [6][64] per wave: fx, fy, dx, rx, dy, ry
+  __syncthreads();
+  PyramidLds<T> PX, PY;
+  PX.lv0 = (lds_ptr<T>)(smem_raw);
+  PX.lv1 = PX.lv0 + A.px.n;
+  PX.n = A.px.n; PX.n1 = A.px.n1; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
+  PY.lv0 = PX.lv0 + nxa;
+  PY.lv1 = PY.lv0 + A.py.n;
+  PY.n = A.py.n; PY.n1 = A.py.n1; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
+  const T x0 = PX.lv0[0], xn = PX.lv0[PX.n - 1], y0 = PY.lv0[0], yn = PY.lv0[PY.n - 1];
+  const uint32_t lane = tid & 63u;
+  const uint32_t LV = A.lv;
+  const bool contig = A.out_stride == (uint64_t)A.lanes;
+  unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
+  if (limit > A.nq) limit = A.nq;
+  const V* const G = reinterpret_cast<const V*>(A.data);
+  const uint64_t wave_step = (uint64_t)gridDim.x * TB;
+  // queries of QB batches requested together, one round ahead (see eval_fused_kernel: one store drain per QB batches)
+  constexpr int QB = 4;
+  uint64_t round0 = ((uint64_t)blockIdx.x * WAVES + (tid >> 6)) * 64u;
+  T xq[QB], yq[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const uint64_t p = round0 + (uint64_t)j * wave_step + lane;
+    const uint64_t pc = p < A.nq ? p : A.nq - 1u;
+    xq[j] = A.qx[pc];
+    yq[j] = A.qy[pc];
+  }
+  for (; round0 < limit; round0 += (uint64_t)QB * wave_step) {
+  T xc[QB], yc[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const bool in = round0 + (uint64_t)j * wave_step + lane < limit;
+    xc[j] = in ? xq[j] : x0;
+    yc[j] = in ? yq[j] : y0;
+  }
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const uint64_t p = round0 + (uint64_t)(QB + j) * wave_step + lane;
+    const uint64_t pc = p < A.nq ? p : A.nq - 1u;
+    xq[j] = A.qx[pc];
+    yq[j] = A.qy[pc];
+  }
+#pragma unroll 1
+  for (int jb = 0; jb < QB; ++jb) {
+    const uint64_t base = round0 + (uint64_t)jb * wave_step;
+    if (base >= limit) break;
+    T x = xc[0], y = yc[0];
+#pragma unroll
+    for (int j = 1; j < QB; ++j)
+      if (jb == j) { x = xc[j]; y = yc[j]; }
+    const uint32_t xi = lutx ? locate_index_lut<T>(PX, lutx, A.bx.m, A.bx.scale, x0, xn, x)
+                             : locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);   // all 64 lanes take part
+    const uint32_t yi = luty ? locate_index_lut<T>(PY, luty, A.by.m, A.by.scale, y0, yn, y)
+                             : locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
+    {
+      const T x1 = PX.lv0[xi], x2 = PX.lv0[xi + 1], y1 = PY.lv0[yi], y2 = PY.lv0[yi + 1];
+      const SharedDivisor<T> dx = shared_divisor<T>(x2 - x1), dy = shared_divisor<T>(y2 - y1);
+      w_o[lane] = NDI_CHK(xi, PX.n - 1u, BC_CELL_X) * A.row_vecs + NDI_CHK(yi, PY.n - 1u, BC_CELL_Y) * A.cell_vecs;
+      w_s[0 * 64 + lane] = x - x1;              // linear.rs:35's (x - x1) of both directions
+      w_s[1 * 64 + lane] = y - y1;
+      w_s[2 * 64 + lane] = dx.d;
+      w_s[3 * 64 + lane] = dx.ok ? dx.r : T(0);
+      w_s[4 * 64 + lane] = dy.d;
+      w_s[5 * 64 + lane] = dy.ok ? dy.r : T(0);
+    }
+    __builtin_amdgcn_wave_barrier();        // LDS operations of one wave execute in order: no s_barrier needed
+    const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
+    const uint32_t items = nq_here * LV;
+    T* const o_base = A.out + base * A.out_stride;
+    for (uint32_t it0 = lane; it0 < items; it0 += 64u * UNR) {
+      bool live[UNR];
+      uint32_t ql[UNR], v[UNR], e[UNR];
+      T fx[UNR], fy[UNR];
+      SharedDivisor<T> dx[UNR], dy[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {        // phase 1: (query, vector) of the item and the query's scalars
+        const uint32_t it = it0 + (uint32_t)k * 64u;
+        live[k] = it < items;
+        const uint32_t itc = live[k] ? it : 0u;
+        ql[k] = (LV == 1u) ? itc : __umulhi(itc, A.lv_magic);
+        ql[k] = NDI_CHK(ql[k], 64u, BC_STRIP);
+        v[k] = itc - ql[k] * LV;
+        e[k] = w_o[ql[k]] + v[k];
+        fx[k] = w_s[0 * 64 + ql[k]];
+        fy[k] = w_s[1 * 64 + ql[k]];
+        dx[k].d = w_s[2 * 64 + ql[k]]; dx[k].r = w_s[3 * 64 + ql[k]]; dx[k].ok = dx[k].r > T(0);
+        dy[k].d = w_s[4 * 64 + ql[k]]; dy[k].r = w_s[5 * 64 + ql[k]]; dy[k].ok = dy[k].r > T(0);
+      }
+      V a11[UNR], a12[UNR], a21[UNR], a22[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {        // phase 2: the four corner vectors
+        a11[k] = G[e[k]];
+        a12[k] = G[e[k] + LV];
+        a21[k] = G[e[k] + A.row_vecs];
+        a22[k] = G[e[k] + A.row_vecs + LV];
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {        // phase 3: bilinear.rs:88-97 and the store
+        const V z1 = div_shared<T, V>(a21[k] - a11[k], dx[k]) * fx[k] + a11[k];
+        const V z2 = div_shared<T, V>(a22[k] - a12[k], dx[k]) * fx[k] + a12[k];
+        const V r = div_shared<T, V>(z2 - z1, dy[k]) * fy[k] + z1;
+        V* o = contig ? reinterpret_cast<V*>(o_base) + (it0 + (uint32_t)k * 64u)
+                      : reinterpret_cast<V*>(o_base + (uint64_t)ql[k] * A.out_stride) + v[k];
+        if (live[k]) store_stream<true>(o, r);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();        // the strip is rewritten by the next batch
+  }
+  }
+}
+
 // Measurement aid (ndi_interp2d_probe_ceiling): the memory access mix of eval_bilinear_kernel and nothing else --
 // per item one pre-generated uniformly random cell, the four corner vectors from the handle's own grid with the
 // kernel's lane mapping, a token amount of arithmetic, the output vector stored -- no searches, no knots, no query

@@ -1910,7 +1910,12 @@ struct Interp2DImpl final : Interp2DBase {
   // Two stages as in Interp1DImpl: prep() = both searches (+ the optional tile grouping) into a scratch set,
   // launch_eval() = the bilinear kernel reading that set.
   struct Plan2 {
-    enum Kind { SMALL, GATHER, TILED } kind = GATHER;
+    enum Kind { SMALL, GATHER, TILED, FUSED2 } kind = GATHER;
+    // FUSED2 (eval_fused2d_kernel)
+    bool f_vec = false, f_lut = false;
+    uint64_t f_lv = 0;
+    unsigned f_grid = 1, f_tb = 256;
+    size_t f_lds = 0;
     bool compact = false;   // TILED: self-contained 16-byte records (group_scatter2d_kernel<T, true>)
     uint32_t ts = 0, nty = 0, nb = 0;   // TILED: tile shift, tiles per grid row, number of tiles
     const T* qx = nullptr;
@@ -1938,7 +1943,10 @@ struct Interp2DImpl final : Interp2DBase {
     static const int small2d_lanes = ShortKnobs::env("NDI_SMALL2D_LANES", 2);
     constexpr int VNs = Wide<T>::N;
     const bool small2d = lanes <= 2 || (lanes <= (uint64_t)small2d_lanes && lanes % VNs != 0);
-    if (small2d && both <= LDS_STAGE_LIMIT && path != NDI_PATH_BUCKETED) {
+    static const long f2_minlanes = ShortKnobs::env("NDI_FUSED2D_MINLANES", 1);   // (3: scalar / 2-value grids always stay with one thread per query)
+    static const long f2_minq0 = ShortKnobs::env("NDI_FUSED2D_MINQ", 65536);
+    const bool small2d_yields = (long)lanes >= f2_minlanes && f2_minq0 >= 0 && (long)std::min<uint64_t>(nq, 1ull << 40) >= 8 * f2_minq0;
+    if (small2d && !small2d_yields && both <= LDS_STAGE_LIMIT && path != NDI_PATH_BUCKETED) {
       // short trailing axes: range pre-check, then both searches + evaluation fused in one launch
       P.kind = Plan2::SMALL;
       g_last_path.store(NDI_PATH_GATHER);
@@ -1950,6 +1958,60 @@ struct Interp2DImpl final : Interp2DBase {
       NDI_HIP(hipGetLastError());
       ps.done();
       return P;
+    }
+    // Rows of fewer than 256 vectors on axes that fit LDS twice over (the reference's 100 x 100 x 5; few-channel grids),
+    // batches from NDI_FUSED2D_MINQ queries: query order with both searches fused in (eval_fused2d_kernel) -- no (xi, yi)
+    // round trip, one reciprocal per direction and query.  Grids the tile order takes (below) are left to it.
+    {
+      static const long minq = ShortKnobs::env("NDI_FUSED2D_MINQ", 65536);
+      constexpr int VNf = Wide<T>::N;
+      const bool vec = (lanes % VNf == 0) && (out_stride % VNf == 0) && aligned16(out);
+      const uint64_t LVf = vec ? lanes / VNf : lanes;
+      const uint64_t cell_e = pair_packed ? 2 * lanes : lanes, row_c = pair_packed ? ny - 1 : ny;
+      const uint64_t grid_vecs = nx * row_c * cell_e / (vec ? VNf : 1);
+      static const int lut_env2 = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+      // workgroup size and search: the combination that keeps most waves on a CU beside the staged axes (the gathers
+      // are latency-bound: waves first); the bucket indices when they cost no waves, or at most half of them
+      static const int lut2_env = ShortKnobs::env("NDI_FUSED2D_LUT", -1);   // A/B: 0 never, 1 whenever they fit
+      size_t lut_b = 0;
+      if (lut_env2 && lut2_env != 0 && nq >= 4096 && both <= LDS_STAGE_LIMIT) {
+        px.ensure_bucket_index();
+        py.ensure_bucket_index();
+        lut_b = px.lut_bytes + py.lut_bytes;
+      }
+      auto plan = [&](bool with_lut, unsigned& tb_out, size_t& lds_out) -> size_t {
+        size_t best = 0;
+        for (unsigned tb : {256u, 512u, 1024u}) {
+          const size_t need = both + (with_lut ? lut_b : 0) + (size_t)(tb / 64) * 64 * (sizeof(uint32_t) + 6 * sizeof(T));
+          if (need > LDS_STAGE_LIMIT) continue;
+          const size_t waves = std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
+          if (waves > best) { best = waves; tb_out = tb; lds_out = need; }
+        }
+        return best;
+      };
+      unsigned tb0 = 256, tb1 = 256;
+      size_t lds0 = 0, lds1 = 0;
+      const size_t w0 = plan(false, tb0, lds0);
+      const size_t w1 = lut_b ? plan(true, tb1, lds1) : 0;
+      const bool lut = w1 != 0 && (lut2_env > 0 || 2 * w1 >= w0);
+      const unsigned TBf = lut ? tb1 : tb0;
+      const size_t lds = lut ? lds1 : lds0;
+      const bool tile_candidate = path == NDI_PATH_BUCKETED || (path == NDI_PATH_AUTO && auto_tiles(nq) && lanes * sizeof(T) >= 64);
+      if (minq >= 0 && (long)std::min<uint64_t>(nq, 1ull << 40) >= minq && (long)lanes >= f2_minlanes && LVf < 256 && 64 * LVf * LVf < (1ull << 32) &&
+          grid_vecs < (1ull << 32) && (lut ? w1 : w0) != 0 && !tile_candidate) {
+        P.kind = Plan2::FUSED2;
+        P.f_vec = vec; P.f_lv = LVf; P.f_lut = lut; P.f_lds = lds; P.f_tb = TBf;
+        const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 32 / (TBf / 64)));
+        P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + TBf - 1) / TBf, (uint64_t)cu_count() * wg_per_cu * 4));
+        g_last_path.store(NDI_PATH_GATHER);
+        const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+        ProfScope ps(s, PC_LOCATE);
+        hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
+                           px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode, &st->first_fail[0]);
+        NDI_HIP(hipGetLastError());
+        ps.done();
+        return P;
+      }
     }
     // BUCKETED for 2-D = tile grouping: the queries are ordered by the tile of 2^ts x 2^ts cells they fall in and
     // eval_bilinear_tiles_kernel evaluates tile by tile out of LDS, so every grid value is read from memory once
@@ -2143,6 +2205,42 @@ struct Interp2DImpl final : Interp2DBase {
       if (shm > both)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
         gs = (unsigned)std::min<uint64_t>(g, (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / shm)));
       launch1<T>(s, PC_EVAL, dim3(gs), dim3(BLOCK), shm, eval_small2d_kernel<T>, S);
+      return;
+    }
+    if (P.kind == Plan2::FUSED2) {
+      EvalFused2Args<T> F{};
+      F.px = px.view; F.py = py.view;
+      F.bx = P.f_lut ? px.bidx : BucketIndex<T>{nullptr, 0, T(0)};
+      F.by = P.f_lut ? py.bidx : BucketIndex<T>{nullptr, 0, T(0)};
+      F.data = data.as<T>();
+      F.qx = P.qx; F.qy = P.qy;
+      F.out = P.out;
+      F.nq = nq;
+      F.out_stride = P.out_stride;
+      F.lanes = (uint32_t)lanes;
+      F.lv = (uint32_t)P.f_lv;
+      F.lv_magic = F.lv >= 2 ? (uint32_t)(((1ull << 32) + F.lv - 1) / F.lv) : 0u;
+      const uint64_t vec = P.f_vec ? Wide<T>::N : 1;
+      F.cell_vecs = (uint32_t)((pair_packed ? 2 * lanes : lanes) / vec);
+      F.row_vecs = (uint32_t)((pair_packed ? ny - 1 : ny) * (pair_packed ? 2 * lanes : lanes) / vec);
+      F.mode = mode;
+      F.first_fail = &st->first_fail[0];
+      if (std::getenv("NDI_TRACE_PLAN"))
+        std::fprintf(stderr, "[ndi plan] fused2d vec=%d lv=%u lut=%d tb=%u grid=%u lds=%zu\n", (int)P.f_vec, F.lv, (int)P.f_lut,
+                     P.f_tb, P.f_grid, P.f_lds);
+      constexpr int VNf = Wide<T>::N;
+#define NDI_F2(VEC, TB)                                                                      \
+  do {                                                                                       \
+    auto kern = eval_fused2d_kernel<T, VEC, 2, TB>;                                          \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)LDS_STAGE_LIMIT);            \
+    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(TB), P.f_lds, kern, F);                      \
+  } while (0)
+      if (P.f_vec) {
+        if (P.f_tb == 1024) NDI_F2(VNf, 1024); else if (P.f_tb == 512) NDI_F2(VNf, 512); else NDI_F2(VNf, 256);
+      } else {
+        if (P.f_tb == 1024) NDI_F2(1, 1024); else if (P.f_tb == 512) NDI_F2(1, 512); else NDI_F2(1, 256);
+      }
+#undef NDI_F2
       return;
     }
     Eval2Args<T> A{};

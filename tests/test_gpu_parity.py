@@ -1121,7 +1121,7 @@ def test_bilinear_tiles_shared_divisor_window(pkg, dt):
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("C", [1, 2, 3, 5, 6, 7, 8])
-def test_bilinear_small_channels_device_buffers(pkg, dt, C):
+def test_bilinear_small_channels_device_buffers(pkg, dt, C, capfd):
     """Scalar grids and rows of a few values that are not 16-byte vectors (the reference's 100 x 100 and 100 x 100 x 5,
     benches/bench_interp2d.rs) on device-resident buffers: one query per thread, both searches (bucket index from 4096
     queries, pyramid below) and the evaluation in one launch, the three divisions of a value through the query's two
@@ -1131,7 +1131,7 @@ def test_bilinear_small_channels_device_buffers(pkg, dt, C):
     tdt = torch.float64 if dt == np.float64 else torch.float32
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(500 + C)
-    for nx, ny, Q in ((100, 100, 100_000), (37, 300, 1000), (2, 2, 5000), (700, 45, 70_001)):
+    for nx, ny, Q in ((100, 100, 100_000), (37, 300, 1000), (2, 2, 5000), (700, 45, 70_001), (90, 110, 600_000)):
         x = knots("rand", nx, rng, dt) if nx > 2 else np.array([0.0, 2.0], dtype=dt)
         y = knots("jit", ny, rng, dt) if ny > 2 else np.array([-1.0, 0.5], dtype=dt)
         g = rng.uniform(-1, 1, (nx, ny, C)).astype(dt)
@@ -1150,7 +1150,15 @@ def test_bilinear_small_channels_device_buffers(pkg, dt, C):
                 .y(torch.as_tensor(y, device=dev)).strategy(pkg.Bilinear.new().extrapolate(ext)).build()
             _, _, _, ref = oracle.interp2d_bilinear(x, y, g, qx, qy, ext)
             out = torch.full((Q, C), -4.0, dtype=tdt, device=dev)
-            it.strategy.interp_array_into(it, torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), out)
+            capfd.readouterr()
+            os.environ["NDI_TRACE_PLAN"] = "1"
+            try:
+                it.strategy.interp_array_into(it, torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), out)
+            finally:
+                del os.environ["NDI_TRACE_PLAN"]
+            took_query_order = "[ndi plan] fused2d" in capfd.readouterr().err
+            # the query-order kernel from 65 536 queries (1-2 values per point: from 524 288), else the two-kernel / one-thread forms
+            assert took_query_order == (Q >= (524_288 if C <= 2 else 65_536)), (nx, ny, C, Q)
             check_equal(out.cpu().numpy(), ref.reshape(Q, C), f"2-D small rows {nx}x{ny}x{C} Q={Q} ext={ext}")
             if not ext:   # first error: rows before it written, later rows untouched
                 qx2 = qx.copy(); qx2[Q // 2] = x[-1] + 1

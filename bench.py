@@ -304,11 +304,32 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
     import ctypes
     cap = pkg._capi
 
+    def traced_kernel():
+        """Which gather-order kernel the library takes for this batch: one call with NDI_TRACE_PLAN=1, the library's
+        stderr line captured at file-descriptor level."""
+        import tempfile
+        sys.stderr.flush()
+        saved = os.dup(2)
+        with tempfile.TemporaryFile(mode="w+b") as tf:
+            os.dup2(tf.fileno(), 2)
+            os.environ["NDI_TRACE_PLAN"] = "1"
+            try:
+                step()
+                interp.strategy.finish()
+            finally:
+                del os.environ["NDI_TRACE_PLAN"]
+                os.dup2(saved, 2)
+                os.close(saved)
+            tf.seek(0)
+            txt = tf.read().decode(errors="replace")
+        return "eval_fused2d_kernel" if "[ndi plan] fused2d" in txt else "eval_bilinear_kernel"
+
     def measure(path):
         interp.strategy.path = path
         for _ in range(warmup):
             step()
         interp.strategy.finish()
+        gather_kernel = traced_kernel()
         # (a) per-stage kernel times: the library's HIP events (two event records per stage on the launch stream)
         pkg.profile_enable(True); pkg.profile_read(reset=True)
         for _ in range(steps):
@@ -349,7 +370,7 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
         interp.strategy.finish()
         gpu_ms = kms + prof["locate_ms"] / max(1, prof["locate_launches"]) + prof["group_ms"] / steps
         r = {"path": "tile-grouped" if tiled else "gather",
-             "kernel": "eval_bilinear_tiles_kernel" if tiled else "eval_bilinear_kernel", "kernel_ms": round(kms, 4),
+             "kernel": "eval_bilinear_tiles_kernel" if tiled else gather_kernel, "kernel_ms": round(kms, 4),
              "locate_ms": round(prof["locate_ms"] / max(1, prof["locate_launches"]), 4),
              "group_ms": round(prof["group_ms"] / steps, 4),
              "ms_per_step": round(el / steps * 1e3, 4), "Mpoints_s": round(nq * C * steps / el / 1e6, 1),

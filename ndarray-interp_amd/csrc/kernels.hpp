@@ -23,7 +23,10 @@
 //                          block-local counting sort of the queries by interval (LDS histograms and cursors)
 //   eval_bucketed_kernel   BUCKETED formulation: grouped order, operand rows held in registers across a
 //                          group, output streamed; XCD-aware chunk order
-//   eval_bilinear_kernel   2-D gather order (bilinear.rs:83-97), plain or pair-packed grid (pack_pairs_kernel)
+//   eval_fused2d_kernel    2-D gather order, QUERY ORDER with both searches fused in (axes staged in LDS), one reciprocal
+//                          per direction and query in a wave-private LDS strip, row-major coalesced stores
+//   eval_bilinear_kernel   2-D gather order, two-kernel form (bilinear.rs:83-97), plain or pair-packed grid
+//                          (pack_pairs_kernel): axes too long for LDS, small batches
 //   eval_bilinear_tiles_kernel
 //                          2-D tile-grouped order (locate2_kernel's tile histogram + group_scatter2d_kernel): every
 //                          tile of grid points staged once in LDS (double-buffered through registers) together with

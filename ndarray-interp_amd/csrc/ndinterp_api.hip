@@ -1039,13 +1039,31 @@ struct Interp1DImpl final : Interp1DBase {
   // Query-order fused search + evaluation (short rows): decides the variant and its launch shape, and enqueues the
   // range pre-pass the kernel relies on.  Returns false when the shape is not eligible.
   bool plan_fused(hipStream_t s, Scratch& sc, Plan1& P, const ShortKnobs& K) {
-    if (pyr.lds_bytes > LDS_STAGE_LIMIT / 2) return false;
+    static const int long_axes = ShortKnobs::env("NDI_FUSED_LONG_AXES", 1);   // A/B: 0 = axes up to half the LDS only
+    if (pyr.lds_bytes > (long_axes ? LDS_STAGE_LIMIT - 8 * 1024 : LDS_STAGE_LIMIT / 2)) return false;
     const uint64_t LV = P.LV;
     if (LV == 0 || 64ull * LV * LV >= (1ull << 32) || (uint64_t)n * LV >= (1ull << 32)) return false;   // 32-bit item / vector indices
     static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
     if (lut_env && P.nq >= 4096) pyr.ensure_bucket_index();
-    P.f_lut = lut_env && P.nq >= 4096 && pyr.lut_bytes != 0 &&
-              fused_lds_bytes(true, 256, false) <= LDS_STAGE_LIMIT / 2;
+    // the bucket index beside the knots when it costs no more than half the waves a CU could hold without it
+    auto waves_at = [&](bool with_lut, unsigned tb) -> size_t {
+      const size_t need = fused_lds_bytes(with_lut, tb, 0);
+      return need > LDS_STAGE_LIMIT ? 0 : std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
+    };
+    auto best_tb = [&](bool with_lut, unsigned& tb_out) -> size_t {
+      size_t best = 0;
+      for (unsigned tb : {256u, 512u, 1024u}) {
+        const size_t w = waves_at(with_lut, tb);
+        if (w > best) { best = w; tb_out = tb; }
+      }
+      return best;
+    };
+    unsigned tb_plain = 256, tb_lut = 256;
+    const size_t w_plain = best_tb(false, tb_plain);
+    const size_t w_lut = (lut_env && P.nq >= 4096 && pyr.lut_bytes != 0) ? best_tb(true, tb_lut) : 0;
+    if (w_plain == 0 && w_lut == 0) return false;
+    P.f_lut = w_lut != 0 && 2 * w_lut >= w_plain;
+    const unsigned tb_auto = P.f_lut ? tb_lut : tb_plain;
     P.f_unr = (K.unr == 1 || K.unr == 4) ? K.unr : 2;
     // Tables in LDS when they fit beside everything else, and when the batch gives every workgroup several times the
     // table size to write (the staging pass is per workgroup).  Workgroup size: the one that keeps most waves on a
@@ -1053,7 +1071,7 @@ struct Interp1DImpl final : Interp1DBase {
     // {y, k} (the spline's derivatives, kept by small builds) is two thirds of {y, a, b}: it fits where the latter
     // does not, and leaves room for more waves where both do.  NDI_FUSED_LDS = 1 / 2 pins the form.
     P.f_tlds = 0;
-    P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : 256u;
+    P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : tb_auto;
     if (K.lds != 0) {
       size_t best_waves = 0;
       const bool yk_ok = strategy == NDI_CUBIC_SPLINE && ck.p;
@@ -1080,7 +1098,7 @@ struct Interp1DImpl final : Interp1DBase {
       if (P.f_tlds && K.lds < 0 && (P.nq * lanes * sizeof(T) < 8 * (size_t)cu_count() * tab ||
                                     (strategy != NDI_CUBIC_SPLINE && lanes * sizeof(T) >= (sizeof(T) == 4 ? 64 : 128)))) {
         P.f_tlds = 0;
-        P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : 256u;
+        P.f_tb = (K.tb == 512 || K.tb == 1024) ? (unsigned)K.tb : tb_auto;
       }
     }
     P.f_lds = fused_lds_bytes(P.f_lut, P.f_tb, P.f_tlds);

@@ -394,3 +394,38 @@ def test_auto_picks_the_measured_form(pkg, capfd):
         else:
             assert frag in err, (np.dtype(dt).name, L, cubic, err)
         del out, q, it, yd
+
+
+@pytest.mark.parametrize("dt,n,L", [(np.float64, 12000, 8), (np.float64, 16384, 5), (np.float32, 30000, 16), (np.float32, 9000, 3)])
+def test_query_order_kernel_on_long_axes(pkg, dt, n, L, capfd):
+    """Axes of more than half the LDS (up to ~18 000 f64 / 36 000 f32 knots) still take the query-order kernel -- one
+    large workgroup per CU around the staged knots instead of the two-kernel flat form -- with the oracle's bits."""
+    import torch
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + L)
+    x = knots("rand", n, rng, dt)
+    y = rng.uniform(-1, 1, (n, L)).astype(dt)
+    Q = 120_001
+    q = rng.uniform(x[0], x[-1], Q).astype(dt)
+    q[:3] = [x[0], x[-1], x[n // 3]]
+    os.environ["NDI_SPLINE_BLOCKED"] = "0"
+    try:
+        cub = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)).strategy(pkg.CubicSpline.new()).build()
+    finally:
+        del os.environ["NDI_SPLINE_BLOCKED"]
+    lin = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)).build()
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref_c = oracle.interp1d_cubic(x, y, a, b, q)
+    _, _, ref_l = oracle.interp1d_linear(x, y, q)
+    for it, ref, name in ((cub, ref_c, "cubic"), (lin, ref_l, "linear")):
+        capfd.readouterr()
+        os.environ["NDI_TRACE_PLAN"] = "1"
+        try:
+            with knobs():
+                got = _device_eval(pkg, it, q, L, pkg.PATH_AUTO, tdt).cpu().numpy()
+        finally:
+            del os.environ["NDI_TRACE_PLAN"]
+        err = capfd.readouterr().err
+        assert "[ndi plan] fused tables=memory" in err, (name, n, L, err)
+        check_equal(got, ref.reshape(Q, L), f"long axis {name} n={n} L={L}")

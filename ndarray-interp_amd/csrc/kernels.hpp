@@ -944,6 +944,7 @@ struct EvalFusedArgs {
   const T* ca;
   const T* cb;
   const T* ck;           // the derivatives k, [n][lanes] (TLDS == 2 only)
+  BucketIndex32<T> bx32; // TLDS == 3: bucket index of the axis in global memory (nullptr: pyramid search from memory)
   const T* q;
   T* out;
   uint64_t nq, out_stride;
@@ -967,8 +968,13 @@ struct TabPtr<V, true> { using type = const __attribute__((address_space(3))) V*
 template <class T, int STRAT, int VEC, int UNR, int TB, int TLDS>
 __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
   static_assert(TLDS != 2 || STRAT == ST_CUBIC, "the {y, k} form is the spline's");
+  // TLDS == 3: axes too long for LDS -- the knots stay in global memory (L2) and are searched through the u32 bucket
+  // index (lut32_count_le: two adjacent index reads + the bucket's 1-2 knots); tables from memory as with TLDS == 0.
+  // Still one launch and no idx[] / t[] round trip (12 B written + 12-20 B re-read per query by the two-kernel form).
+  constexpr bool GK = TLDS == 3;
+  constexpr bool TAB_LDS = TLDS == 1 || TLDS == 2;
   using V = typename VecT<T, VEC>::type;
-  using tab_ptr = typename TabPtr<V, TLDS != 0>::type;
+  using tab_ptr = typename TabPtr<V, TAB_LDS>::type;
   constexpr bool STRIP2 = STRAT == ST_LINEAR || TLDS == 2;   // a second per-query scalar: (x - x1) / the interval's dx
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr uint32_t WAVES = TB / 64;
@@ -977,14 +983,14 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
   const uint32_t n = A.pyr.n, n1 = A.pyr.n1;
   // LDS: [pyramid | lut | per-wave strips (interval, c0, c1) | tables]
   size_t off = 0;
-  {
+  if constexpr (!GK) {
     T* s0 = reinterpret_cast<T*>(smem_raw);
     const uint32_t total = n + n1;   // the levels are one allocation
     for (uint32_t i = tid; i < total; i += TB) s0[i] = A.pyr.lv0[i];
     off = ((size_t)total * sizeof(T) + 15u) & ~(size_t)15u;
   }
   lds_u16 lut = nullptr;
-  if (A.bx.lut) {
+  if (!GK && A.bx.lut) {
     uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
     const uint32_t words = (A.bx.m + 2u) / 2u;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(A.bx.lut);
@@ -999,7 +1005,7 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
   T* w_c1 = reinterpret_cast<T*>(smem_raw + off) + (tid >> 6) * 64u;
   if (STRIP2) off += (size_t)WAVES * 64u * sizeof(T);
   const uint32_t LV = A.lv;
-  const uint32_t RS = TLDS ? LV : A.rec_stride;
+  const uint32_t RS = TAB_LDS ? LV : A.rec_stride;
   tab_ptr t_y, t_a, t_b;
   if constexpr (TLDS == 2) {
     V* sy = reinterpret_cast<V*>(smem_raw + off);
@@ -1036,7 +1042,7 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
   P.lv0 = (lds_ptr<T>)(smem_raw);
   P.lv1 = P.lv0 + n;
   P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
-  const T k0 = P.lv0[0], kn = P.lv0[n - 1];
+  const T k0 = GK ? A.pyr.lv0[0] : (T)P.lv0[0], kn = GK ? A.pyr.lv0[n - 1] : (T)P.lv0[n - 1];
   const uint32_t lane = tid & 63u;
   const bool contig = A.out_stride == (uint64_t)A.lanes;
   unsigned long long limit = *A.first_fail;
@@ -1076,15 +1082,28 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
     T xs = x;
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;   // cubic_spline.rs:805-809
     // (queries at / after the first failing one never get here; an inactive lane searches k0)
-#ifdef NDI_TUNING
     uint32_t i;
-    if (A.debug & 1) i = (uint32_t)((base + lane) * 2654435761ull >> 7) % (n - 1u);
-    else i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs) : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);
-#else
-    const uint32_t i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs)
-                           : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);   // all 64 lanes take part
+    T xl, xr;
+    if constexpr (GK) {
+      if (A.bx32.lut) {
+        const uint32_t ub = lut32_count_le<T>(A.pyr.lv0, n, A.bx32.lut, A.bx32.m, A.bx32.scale, k0, kn, xs);
+        i = (ub == 0) ? 0u : ub - 1u;
+        if (i > n - 2u) i = n - 2u;
+      } else {
+        i = locate_index<T, const T*>(A.pyr, k0, kn, xs, lane);   // all 64 lanes take part
+      }
+      xl = A.pyr.lv0[i];
+      xr = A.pyr.lv0[i + 1];
+    } else {
+#ifdef NDI_TUNING
+      if (A.debug & 1) i = (uint32_t)((base + lane) * 2654435761ull >> 7) % (n - 1u);
+      else
 #endif
-    const T xl = P.lv0[i], xr = P.lv0[i + 1];
+      i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs)
+              : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);   // all 64 lanes take part
+      xl = P.lv0[i];
+      xr = P.lv0[i + 1];
+    }
     w_i[lane] = NDI_CHK(i, n - 1u, BC_INTERVAL) * RS;   // offset of the interval's operands (n * RS < 2^32: host)
     if (STRAT == ST_CUBIC) {
       w_c0[lane] = (xs - xl) / (xr - xl);   // t, cubic_spline.rs:818

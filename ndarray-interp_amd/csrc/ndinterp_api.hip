@@ -1040,10 +1040,35 @@ struct Interp1DImpl final : Interp1DBase {
   // range pre-pass the kernel relies on.  Returns false when the shape is not eligible.
   bool plan_fused(hipStream_t s, Scratch& sc, Plan1& P, const ShortKnobs& K) {
     static const int long_axes = ShortKnobs::env("NDI_FUSED_LONG_AXES", 1);   // A/B: 0 = axes up to half the LDS only
-    if (pyr.lds_bytes > (long_axes ? LDS_STAGE_LIMIT - 8 * 1024 : LDS_STAGE_LIMIT / 2)) return false;
+    static const int global_axes = ShortKnobs::env("NDI_FUSED_GLOBAL_AXES", 1);   // A/B: 0 = two-kernel form for axes beyond LDS
     const uint64_t LV = P.LV;
-    if (LV == 0 || 64ull * LV * LV >= (1ull << 32) || (uint64_t)n * LV >= (1ull << 32)) return false;   // 32-bit item / vector indices
+    if (LV == 0 || 64ull * LV * LV >= (1ull << 32) || (uint64_t)n * LV >= (1ull << 32) * 1ull) return false;   // 32-bit item / vector indices
     static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+    if (pyr.lds_bytes > (long_axes ? LDS_STAGE_LIMIT - 8 * 1024 : LDS_STAGE_LIMIT / 2)) {
+      // Axes too long for LDS: the same kernel with the knots left in global memory and searched through the u32 bucket
+      // index (TLDS == 3) -- one launch, no idx[] / t[] round trip.  Batches below 4096 queries keep the two-kernel form.
+      if (!global_axes || !long_axes || !lut_env || P.nq < 4096) return false;
+      pyr.ensure_bucket_index32();
+      P.f_lut = false;
+      P.f_unr = 2;
+      P.f_tlds = 3;
+      P.f_tb = 256;
+      const bool strip2 = strategy != NDI_CUBIC_SPLINE;
+      P.f_lds = (size_t)(256 / 64) * 64 * (sizeof(uint32_t) + (strip2 ? 2 : 1) * sizeof(T));
+      P.f_pack = (K.pack > 0 || (K.pack < 0 && lanes * sizeof(T) < 128)) && ensure_packed();
+      P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + 255) / 256, (uint64_t)cu_count() * 8 * 4));
+      P.kind = Plan1::FUSED;
+      g_last_path.store(NDI_PATH_GATHER);
+      StatusBlock* st = sc.status.as<StatusBlock>();
+      const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
+      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + BLOCK - 1) / BLOCK, 4096));
+      ProfScope ps(s, PC_LOCATE);
+      hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, P.q, (const T*)nullptr, P.nq, k0, kn, k0, kn,
+                         mode, &st->first_fail[0]);
+      NDI_HIP(hipGetLastError());
+      ps.done();
+      return true;
+    }
     if (lut_env && P.nq >= 4096) pyr.ensure_bucket_index();
     // the bucket index beside the knots when it costs no more than half the waves a CU could hold without it
     auto waves_at = [&](bool with_lut, unsigned tb) -> size_t {
@@ -1370,6 +1395,7 @@ struct Interp1DImpl final : Interp1DBase {
     F.ca = ca.as<T>();
     F.cb = cb.as<T>();
     F.ck = ck.as<T>();
+    F.bx32 = P.f_tlds == 3 ? pyr.bidx32 : BucketIndex32<T>{nullptr, 0, T(0)};
     F.rec_stride = (uint32_t)P.LV;
     if (P.f_pack) {   // {y[i], y[i+1], a[i], b[i]} per interval
       F.data = packed.as<T>();
@@ -1394,7 +1420,8 @@ struct Interp1DImpl final : Interp1DBase {
     const dim3 grid(P.f_grid), block(P.f_tb);
     if (std::getenv("NDI_TRACE_PLAN"))   // which variant a batch took (tests assert on it; read per call)
       std::fprintf(stderr, "[ndi plan] fused tables=%s lut=%d pack=%d unr=%d tb=%u grid=%u lds=%zu\n",
-                   P.f_tlds == 2 ? "lds{y,k}" : (P.f_tlds == 1 ? "lds{y,a,b}" : "memory"), (int)P.f_lut, (int)P.f_pack,
+                   P.f_tlds == 2 ? "lds{y,k}" : (P.f_tlds == 1 ? "lds{y,a,b}" : (P.f_tlds == 3 ? "memory,knots=global" : "memory")),
+                   (int)P.f_lut, (int)P.f_pack,
                    P.f_unr, P.f_tb, P.f_grid, P.f_lds);
 #define NDI_FU(ST, VEC, UNR, TB, TL)                                                                   \
   do {                                                                                                 \
@@ -1419,7 +1446,10 @@ struct Interp1DImpl final : Interp1DBase {
     if (strategy == NDI_CUBIC_SPLINE) NDI_FU_UNR(ST_CUBIC, VEC, TL);                    \
     else NDI_FU_UNR(ST_LINEAR, VEC, TL);                                                \
   } while (0)
-    if (P.vec_ok) {
+    if (P.f_tlds == 3) {   // knots in global memory: one launch shape
+      if (strategy == NDI_CUBIC_SPLINE) { if (P.vec_ok) NDI_FU(ST_CUBIC, VN, 2, 256, 3); else NDI_FU(ST_CUBIC, 1, 2, 256, 3); }
+      else { if (P.vec_ok) NDI_FU(ST_LINEAR, VN, 2, 256, 3); else NDI_FU(ST_LINEAR, 1, 2, 256, 3); }
+    } else if (P.vec_ok) {
       if (P.f_tlds == 2) NDI_FU_UNR(ST_CUBIC, VN, 2);
       else if (P.f_tlds) NDI_FU_ST(VN, 1);
       else NDI_FU_ST(VN, 0);

@@ -429,3 +429,48 @@ def test_query_order_kernel_on_long_axes(pkg, dt, n, L, capfd):
         err = capfd.readouterr().err
         assert "[ndi plan] fused tables=memory" in err, (name, n, L, err)
         check_equal(got, ref.reshape(Q, L), f"long axis {name} n={n} L={L}")
+
+
+@pytest.mark.parametrize("dt,n,L,kind", [(np.float64, 30_000, 1, "rand"), (np.float64, 100_000, 5, "jit"), (np.float32, 70_000, 8, "log"),
+                                         (np.float64, 50_000, 2, "lin"), (np.float32, 200_000, 3, "rand")])
+def test_query_order_kernel_with_knots_in_global_memory(pkg, dt, n, L, kind, capfd):
+    """Axes too long for LDS: the query-order kernel leaves the knots in global memory and searches them through the
+    u32 bucket index (evenly spaced axes: the reference's O(1) guess) -- one launch instead of locate + flat, the
+    oracle's bits, first-error cut included."""
+    import torch
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + L)
+    x = knots(kind, n, rng, dt) if kind != "log" else np.unique(np.logspace(-2, 0, n).astype(dt))
+    n = x.size
+    y = rng.uniform(-1, 1, (n, L)).astype(dt)
+    Q = 90_001
+    q = rng.uniform(x[0], x[-1], Q).astype(dt)
+    q[:4] = [x[0], x[-1], x[n // 3], np.nextafter(x[-1], x[0])]
+    os.environ["NDI_SPLINE_BLOCKED"] = "0"
+    try:
+        cub = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)).strategy(pkg.CubicSpline.new()).build()
+    finally:
+        del os.environ["NDI_SPLINE_BLOCKED"]
+    lin = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)).build()
+    st, a, b = oracle.cubic_build(x, y)
+    _, _, ref_c = oracle.interp1d_cubic(x, y, a, b, q)
+    _, _, ref_l = oracle.interp1d_linear(x, y, q)
+    for it, ref, name in ((cub, ref_c, "cubic"), (lin, ref_l, "linear")):
+        capfd.readouterr()
+        os.environ["NDI_TRACE_PLAN"] = "1"
+        try:
+            with knobs():
+                got = _device_eval(pkg, it, q, L, pkg.PATH_AUTO, tdt).cpu().numpy()
+        finally:
+            del os.environ["NDI_TRACE_PLAN"]
+        assert "knots=global" in capfd.readouterr().err, (name, n, L)
+        check_equal(got, ref.reshape(Q, L), f"global knots {name} n={n} L={L}")
+    # first error: rows before it written, later rows untouched
+    q2 = q.copy(); q2[40_000] = x[-1] + 1
+    out = torch.full((Q, L), -2.0, dtype=tdt, device=dev)
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        lin.interp_array_into(torch.as_tensor(q2, device=dev), out)
+    assert ei.value.index == 40_000
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:40_000], ref_l.reshape(Q, L)[:40_000]) and np.all(o[40_000:] == -2.0)

@@ -1190,7 +1190,8 @@ struct Interp1DImpl final : Interp1DBase {
     // rows shorter than one workgroup pass (or unaligned): grouped from a few hundred bytes per row upwards when the
     // batch has enough queries per interval, else query order with the search fused in
     const bool short_rows = !rows_ok || (P.vec_ok && P.LV < (uint64_t)K.maxlv);
-    const bool group_ok = nq < 0xffffffffull && P.vec_ok && P.LV < (uint64_t)BLOCK && lds_sort_fits(pyr, n - 1);
+    // (axes whose interval histogram does not fit LDS are grouped with global atomics, as long rows are)
+    const bool group_ok = nq < 0xffffffffull && P.vec_ok && P.LV < (uint64_t)BLOCK;
     bool bucketed = false, grouped_short = false;
     if (path == NDI_PATH_BUCKETED) {
       bucketed = rows_ok && nq < 0xffffffffull;
@@ -1200,7 +1201,12 @@ struct Interp1DImpl final : Interp1DBase {
       // (Linear reads two operand rows per item instead of four: its query-order form already runs at 5-6 TB/s on rows
       //  of 128 B - 2 KiB and beats the grouped form everywhere: profiles/r04_short_rows_linear_sweep.txt)
       grouped_short = short_rows && group_ok && nq >= 5 * (n - 1) &&
-                      (K.mode == 3 || (K.mode == 0 && strategy == NDI_CUBIC_SPLINE && lanes * sizeof(T) >= (uint64_t)K.rowb));
+                      (K.mode == 3 || (K.mode == 0 && strategy == NDI_CUBIC_SPLINE &&
+                                       (lanes * sizeof(T) >= (uint64_t)K.rowb ||
+                                        // tables that outgrow L2 (its 4 MiB per XCD): the query-order form re-reads them
+                                        // from memory per query, the grouped form once per interval -- from 512-byte rows
+                                        // (8192 knots x 128 f32 lanes, 12.6 MB: 3.94 vs 2.21 TB/s; tools/group_vs_fused_probe.py)
+                                        (lanes * sizeof(T) >= 512 && (size_t)(3 * n - 2) * lanes * sizeof(T) >= ((size_t)8 << 20)))));
     }
     if (short_rows && !grouped_short && !bucketed && K.mode != 1 && K.mode != 3 && plan_fused(s, sc, P, K)) return P;
     g_last_path.store(bucketed || grouped_short ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);

@@ -1201,7 +1201,12 @@ struct Interp1DImpl final : Interp1DBase {
       // (Linear reads two operand rows per item instead of four: its query-order form already runs at 5-6 TB/s on rows
       //  of 128 B - 2 KiB and beats the grouped form everywhere: profiles/r04_short_rows_linear_sweep.txt)
       grouped_short = short_rows && group_ok && nq >= 5 * (n - 1) &&
-                      (K.mode == 3 || (K.mode == 0 && strategy == NDI_CUBIC_SPLINE &&
+                      (K.mode == 3 ||
+                       // Linear: only when its one table outgrows L2 and the rows are 1 KiB or more (16 384 knots x 512 f32
+                       // lanes, 33.6 MB: 3.54 vs 2.55 TB/s)
+                       (K.mode == 0 && strategy != NDI_CUBIC_SPLINE && lanes * sizeof(T) >= 1024 &&
+                        (size_t)n * lanes * sizeof(T) >= ((size_t)8 << 20)) ||
+                       (K.mode == 0 && strategy == NDI_CUBIC_SPLINE &&
                                        (lanes * sizeof(T) >= (uint64_t)K.rowb ||
                                         // tables that outgrow L2 (its 4 MiB per XCD): the query-order form re-reads them
                                         // from memory per query, the grouped form once per interval -- from 512-byte rows

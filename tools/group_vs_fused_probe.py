@@ -7,10 +7,11 @@ import __graft_entry__ as g
 pkg = g.load_package()
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
-shapes = [(np.float32, 8192, 128), (np.float64, 8192, 32), (np.float64, 16384, 32), (np.float64, 16384, 128), (np.float64, 16384, 8),
+shapes = [(np.float32, 8192, 512), (np.float32, 16384, 512), (np.float64, 8192, 128), (np.float64, 16384, 256), (np.float32, 8192, 256),
+          (np.float32, 8192, 128), (np.float64, 8192, 32), (np.float64, 16384, 32), (np.float64, 16384, 128), (np.float64, 16384, 8),
           (np.float64, 100_000, 8), (np.float64, 100_000, 32), (np.float64, 100_000, 128), (np.float32, 100_000, 32), (np.float64, 4096, 32),
           (np.float64, 4096, 64), (np.float64, 2048, 64)]
-for strategy in ("cubic", "linear"):
+for strategy in (sys.argv[1:] or ["cubic", "linear"]):
     for dt, n, L in shapes:
         tdt = torch.float64 if dt == np.float64 else torch.float32
         el = np.dtype(dt).itemsize

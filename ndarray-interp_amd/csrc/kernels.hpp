@@ -59,6 +59,8 @@ struct StatusBlock {
   unsigned long long first_fail[2];  // lowest failing flat query index per axis (x, y)
   unsigned long long n_valid;        // bucketed path: number of grouped queries
   unsigned long long periodic_mismatch;  // build: lanes with y[0] != y[n-1]
+  unsigned int ticket;               // group_offsets_scan_kernel: workgroups that have published their bin totals
+  unsigned int reserved;
 };
 
 // Opt-in checked build (`make debug` -> libndinterp_hip_dbg.so, -DNDI_BOUNDS): every device-side index that
@@ -102,6 +104,8 @@ __global__ __launch_bounds__(64) void reset_status_kernel(StatusBlock* s) {
   s->first_fail[1] = NO_FAIL;
   s->n_valid = 0;
   s->periodic_mismatch = 0;
+  s->ticket = 0;
+  s->reserved = 0;
 }
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -617,6 +621,81 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
     uint32_t* dst = A.hist + (uint64_t)blockIdx.x * A.nb;
     for (uint32_t i = tid; i < A.nb; i += blockDim.x) dst[i] = s_hist[i];
   }
+}
+
+// Correctly rounded division of many numerators by ONE divisor (the per-query knot spacing shared by all channels
+// of a row): r = RN(1 / d) is formed once with the IEEE division, then every quotient costs one multiplication and
+// four FMAs -- all available as packed 2 x f32 instructions -- instead of the ~10-instruction IEEE sequence with its
+// quarter-rate reciprocal:
+//     q0 = RN(n r);  e0 = n - d q0 (exact, FMA);  q1 = RN(q0 + e0 r);  e1 = n - d q1 (exact);  q = RN(q1 + e1 r).
+// q0 is within 2^-23 |n / d| of the quotient, so q1 is a faithful rounding of it, and for a faithful q1 and a
+// correctly rounded reciprocal the last step yields RN(n / d) exactly (Markstein's theorem; Muller et al., Handbook
+// of Floating-Point Arithmetic, "division with an FMA") -- provided no intermediate under- or overflows.  The guard
+// keeps divisor and numerators inside an exponent window in which every product and residual is a normal number;
+// it is ONE test per vector: the smallest magnitude of the components >= N_LO (an exact zero therefore takes the
+// IEEE path: flat data lose the speed-up, never the result) and the sum of the magnitudes <= N_HI (a NaN or an
+// infinity makes the sum fail).  Outside the window the lane does the IEEE division.  The explicit FMAs compute
+// exact residuals; they are not contractions of the reference's expression, whose operation order (linear.rs:33-35)
+// is unchanged: m = RN(n / d), then RN(RN(m (x - x1)) + y1).  Pinned against the IEEE path of the gather kernel on
+// all 6.4e8 outputs of C3 (test_full_size_c3_bilinear) and by test_bilinear_tile_grouped_lds (values far outside
+// the window included).
+template <class T>
+struct DivWindow;
+template <>
+struct DivWindow<float> {
+  static constexpr float N_LO = 0x1p-60f, N_HI = 0x1p60f, D_LO = 0x1p-40f, D_HI = 0x1p40f;
+};
+template <>
+struct DivWindow<double> {
+  static constexpr double N_LO = 0x1p-500, N_HI = 0x1p500, D_LO = 0x1p-400, D_HI = 0x1p400;
+};
+template <class T>
+struct SharedDivisor {
+  T d, r;
+  bool ok;
+};
+template <class T>
+__device__ __forceinline__ SharedDivisor<T> shared_divisor(T d) {
+  SharedDivisor<T> s;
+  s.d = d;
+  s.r = T(1) / d;
+  s.ok = (d >= DivWindow<T>::D_LO) && (d <= DivWindow<T>::D_HI);
+  return s;
+}
+__device__ __forceinline__ bool nums_in_window(flt4 n) {
+  const float lo = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
+  const float sum = (fabsf(n.x) + fabsf(n.y)) + (fabsf(n.z) + fabsf(n.w));
+  return (lo >= DivWindow<float>::N_LO) & (sum <= DivWindow<float>::N_HI);
+}
+__device__ __forceinline__ bool nums_in_window(float n) {
+  const float a = fabsf(n);
+  return (a >= DivWindow<float>::N_LO) & (a <= DivWindow<float>::N_HI);
+}
+__device__ __forceinline__ bool nums_in_window(double n) {
+  const double a = fabs(n);
+  return (a >= DivWindow<double>::N_LO) & (a <= DivWindow<double>::N_HI);
+}
+__device__ __forceinline__ bool nums_in_window(dbl2 n) {
+  const double lo = fmin(fabs(n.x), fabs(n.y));
+  const double sum = fabs(n.x) + fabs(n.y);
+  return (lo >= DivWindow<double>::N_LO) & (sum <= DivWindow<double>::N_HI);
+}
+template <class T, class V>
+__device__ __forceinline__ V div_shared(V n, const SharedDivisor<T>& s) {
+  const V d = V(s.d), r = V(s.r);
+  const V q0 = n * r;
+  const V e0 = __builtin_elementwise_fma(-q0, d, n);
+  const V q1 = __builtin_elementwise_fma(e0, r, q0);
+  const V e1 = __builtin_elementwise_fma(-q1, d, n);
+  V q = __builtin_elementwise_fma(e1, r, q1);
+  if (__builtin_expect(!(s.ok & nums_in_window(n)), 0)) q = n / s.d;   // outside the window: the IEEE division
+  return q;
+}
+// Linear::calc_frac (linear.rs:29-36) with the divisor's reciprocal shared across the row
+template <class T, class V>
+__device__ __forceinline__ V frac_shared(T x1, V y1, const SharedDivisor<T>& dx, V y2, T x) {
+  const V m = div_shared<T, V>(y2 - y1, dx);
+  return m * (x - x1) + y1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1194,6 +1273,218 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
   }
 }
 
+// QUERY PER LANE with the whole table set resident in LDS -- the formulation for the reference's own bench shapes at
+// large Q (scalar data and (100, 5) on 100 knots: benches/bench_interp1d.rs:12-47, 82-122).  Counters of the query-order
+// kernel on those shapes (profiles/r05_small_shapes_counters.txt): 126 VALU wave instructions per 64 scalar queries, 43 %
+// of the LDS cycles bank conflicts, nothing saturated -- the per-query strip round trip, one item per lane and trip,
+// 8-byte loads and stores and an IEEE division per query are overhead when a row is one or a few values.  Here a lane owns
+// its query from the search to the result:
+//  * staging (once per workgroup): the knots (+ bucket index), one record {x_l, dx, RN(1 / dx)} per interval and one
+//    record per (interval, lane of the trailing axes): {y_l, y_r, a, b} (cubic) or {y_l, m} (linear) with
+//    m = (y_r - y_l) / (x_r - x_l) -- Linear::calc_frac's division (linear.rs:33) has no query in it, so it is done
+//    once per record with the IEEE division: the same operands, the same bits;
+//  * t = (x - x_l) / dx (cubic_spline.rs:818) by the correctly rounded shared-divisor division (div_shared: the bits of
+//    the IEEE division; the reciprocal comes from the interval's record);
+//  * scalar data (L == 1): QPL consecutive queries per lane, one 16-byte query load and one 16-byte store per lane;
+//  * 2 <= L: the wave's 64 rows are written to a wave-private LDS strip and leave as ONE sequential stream of
+//    16-byte vectors (64 * L * sizeof(T) consecutive bytes per batch), whatever L is (5 is not a multiple of anything).
+// Same operations in the same order as Linear / CubicSplineStrategy::interp_into; rows at / after the batch's first
+// failing query (range_check_kernel) are never written.
+template <class T>
+struct XRec { T xl, dx, r, pad; };   // r = RN(1 / dx), 0 when dx is outside the shared-divisor window
+
+template <class T>
+struct EvalLanesArgs {
+  Pyramid<T> pyr;
+  BucketIndex<T> bx;     // lut == nullptr: pyramid search
+  const T* data;         // [n][lanes]
+  const T* ca;           // [n-1][lanes] (cubic)
+  const T* cb;
+  const T* q;
+  T* out;
+  uint64_t nq, out_stride;
+  uint32_t lanes;
+  int mode;              // ExtrapMode
+  const unsigned long long* first_fail;
+};
+
+template <class T, int STRAT, int QPL, int TB>
+__global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int TR = STRAT == ST_CUBIC ? 4 : 2;      // values per table record
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  using QV = typename VecT<T, QPL>::type;
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t n = A.pyr.n, n1 = A.pyr.n1, L = A.lanes;
+  // LDS: [pyramid | lut | interval records | table records | per-wave strips (L > 1)]
+  size_t off;
+  {
+    T* s0 = reinterpret_cast<T*>(smem_raw);
+    const uint32_t total = n + n1;
+    for (uint32_t i = tid; i < total; i += TB) s0[i] = A.pyr.lv0[i];
+    off = ((size_t)total * sizeof(T) + 15u) & ~(size_t)15u;
+  }
+  lds_u16 lut = nullptr;
+  if (A.bx.lut) {
+    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
+    const uint32_t words = (A.bx.m + 2u) / 2u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.bx.lut);
+    for (uint32_t i = tid; i < words; i += TB) sl[i] = src[i];
+    lut = (lds_u16)(smem_raw + off);
+    off += ((size_t)words * 4u + 15u) & ~(size_t)15u;
+  }
+  XRec<T>* s_x = reinterpret_cast<XRec<T>*>(smem_raw + off);
+  off += (size_t)(n - 1u) * sizeof(XRec<T>);
+  T* s_t = reinterpret_cast<T*>(smem_raw + off);
+  off += (((size_t)(n - 1u) * L * TR * sizeof(T)) + 15u) & ~(size_t)15u;
+  T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;   // (touched only when L > 1)
+  for (uint32_t i = tid; i + 1u < n; i += TB) {
+    const T xl = A.pyr.lv0[i], xr = A.pyr.lv0[i + 1];
+    const SharedDivisor<T> sd = shared_divisor<T>(xr - xl);
+    XRec<T> r;
+    r.xl = xl; r.dx = sd.d; r.r = sd.ok ? sd.r : T(0); r.pad = T(0);
+    s_x[i] = r;
+  }
+  for (uint32_t e = tid; e < (n - 1u) * L; e += TB) {
+    const uint32_t i = e / L;
+    const T yl = A.data[e], yr = A.data[e + L];
+    if (STRAT == ST_CUBIC) {
+      s_t[(size_t)e * TR + 0] = yl;
+      s_t[(size_t)e * TR + 1] = yr;
+      s_t[(size_t)e * TR + 2] = A.ca[e];
+      s_t[(size_t)e * TR + 3] = A.cb[e];
+    } else {
+      const T dx = A.pyr.lv0[i + 1] - A.pyr.lv0[i];
+      s_t[(size_t)e * TR + 0] = yl;
+      s_t[(size_t)e * TR + 1] = (yr - yl) / dx;          // linear.rs:33, once per record
+    }
+  }
+  __syncthreads();
+  PyramidLds<T> P;
+  P.lv0 = (lds_ptr<T>)(smem_raw);
+  P.lv1 = P.lv0 + n;
+  P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
+  const T k0 = P.lv0[0], kn = P.lv0[n - 1];
+  unsigned long long limit = *A.first_fail;
+  if (limit > A.nq) limit = A.nq;
+  // interval + per-query scalars of one query (all 64 lanes call it: the pyramid search is wave-cooperative)
+  auto locate = [&](T x, uint32_t& i, T& s0, T& s1) {
+    const bool inr = (k0 <= x) && (x <= kn);
+    T xs = x;
+    if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;   // cubic_spline.rs:805-809
+    i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs) : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);
+    i = NDI_CHK(i, n - 1u, BC_INTERVAL);
+    const XRec<T> xr = s_x[i];
+    if (STRAT == ST_CUBIC) {
+      SharedDivisor<T> sd;
+      sd.d = xr.dx; sd.r = xr.r; sd.ok = xr.r > T(0);
+      s0 = div_shared<T, T>(xs - xr.xl, sd);              // t, cubic_spline.rs:818
+      s1 = T(0);
+    } else {
+      s0 = x - xr.xl;                                     // linear.rs:35's (x - x1)
+      s1 = T(0);
+    }
+  };
+  auto point = [&](uint32_t rec, T s0) -> T {
+    const T* r = s_t + (size_t)rec * TR;
+    if (STRAT == ST_CUBIC) {                              // cubic_spline.rs:825-827
+      const T yl = r[0], yr = r[1], a = r[2], b = r[3];
+      const T c0 = T(1) - s0;
+      return c0 * yl + s0 * yr + (s0 * c0) * (a * c0 + b * s0);
+    } else {                                              // linear.rs:33-35 with the record's m
+      return r[1] * s0 + r[0];
+    }
+  };
+  if (L == 1u) {
+    // ---- scalar data: QPL consecutive queries per lane, vector load / store; the (< QPL) queries behind the last full
+    // vector below `limit` go one per lane at the end
+    const uint64_t nvec = limit / QPL;
+    const uint64_t step = (uint64_t)gridDim.x * TB;
+    const QV* qv = reinterpret_cast<const QV*>(A.q);
+    QV* ov = reinterpret_cast<QV*>(A.out);
+    const uint64_t vlast = nvec ? nvec - 1u : 0u;
+    uint64_t v0 = (uint64_t)blockIdx.x * TB + (tid & ~63u);
+    QV nxt = nvec ? qv[(v0 + lane < nvec) ? v0 + lane : vlast] : QV(k0);   // one vector ahead, clamped (unconditional)
+    for (; v0 < nvec; v0 += step) {
+      const uint64_t vi = v0 + lane;
+      const bool active = vi < nvec;
+      const QV cur = nxt;
+      {
+        const uint64_t vn = vi + step;
+        nxt = qv[vn < nvec ? vn : vlast];
+      }
+      QV res;
+#pragma unroll
+      for (int u = 0; u < QPL; ++u) {
+        T x;
+        if constexpr (QPL == 1) x = cur; else x = cur[u];
+        if (!active) x = k0;
+        uint32_t i;
+        T s0, s1;
+        locate(x, i, s0, s1);
+        const T r = point(i, s0);
+        if constexpr (QPL == 1) res = r; else res[u] = r;
+      }
+      if constexpr (QPL == 1) {
+        if (active) store_stream<true>(A.out + vi * A.out_stride, res);   // (rows of one value may still be strided)
+      } else {
+        if (active) store_stream<true>(ov + vi, res);
+      }
+    }
+    const uint64_t done = nvec * QPL;
+    if (blockIdx.x == 0 && tid < 64u && done < limit) {   // (QPL > 1 only; wave-uniform)
+      const uint64_t qi = done + lane;
+      const bool active = qi < limit;
+      const T x = active ? A.q[qi] : k0;
+      uint32_t i;
+      T s0, s1;
+      locate(x, i, s0, s1);
+      const T r = point(i, s0);
+      if (active) A.out[qi * A.out_stride] = r;
+    }
+    return;
+  }
+  // ---- 2 <= L: one query per lane, the wave's rows through a strip, out as one sequential vector stream
+  const bool contig = A.out_stride == (uint64_t)L;
+  const uint64_t wstep = (uint64_t)gridDim.x * TB;
+  uint64_t base = ((uint64_t)blockIdx.x * (TB / 64) + (tid >> 6)) * 64u;
+  T xn = A.q[(base + lane < A.nq) ? base + lane : A.nq - 1u];
+  for (; base < limit; base += wstep) {
+    const bool active = base + lane < limit;
+    const T x = active ? xn : k0;
+    {
+      const uint64_t pn = base + wstep + lane;
+      xn = A.q[pn < A.nq ? pn : A.nq - 1u];               // the next batch, in flight during this one
+    }
+    uint32_t i;
+    T s0, s1;
+    locate(x, i, s0, s1);
+    const uint32_t rec0 = i * L;
+    for (uint32_t l = 0; l < L; ++l) s_strip[lane * L + l] = point(rec0 + l, s0);
+    __builtin_amdgcn_wave_barrier();                      // LDS operations of one wave execute in order
+    const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
+    const uint32_t total = nq_here * L;
+    if (contig) {
+      T* const o = A.out + base * L;                      // 64 * L * sizeof(T) bytes per batch: 16-byte aligned with `out`
+      for (uint32_t e0 = lane * VN; e0 < total; e0 += 64u * VN) {
+        if (e0 + VN <= total) {
+          store_stream<true>(reinterpret_cast<V*>(o + e0), *reinterpret_cast<const V*>(s_strip + e0));
+        } else {
+          for (uint32_t e = e0; e < total; ++e) o[e] = s_strip[e];
+        }
+      }
+    } else {
+      for (uint32_t it = lane; it < total; it += 64u) {
+        const uint32_t ql = it / L, l = it - ql * L;
+        A.out[(base + ql) * A.out_stride + l] = s_strip[it];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                      // the strip is rewritten by the next batch
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BUCKETED: counting sort of the valid queries by interval, then a streaming evaluation
 // ---------------------------------------------------------------------------------------------
@@ -1276,6 +1567,100 @@ __global__ __launch_bounds__(BLOCK) void group_offsets_kernel(uint32_t* hist, ui
     run += h;
   }
   totals[bin] = run;
+}
+
+// group_offsets_kernel, the exclusive scan of the bin totals and (2-D tile order) the chunk -> first-tile table in ONE
+// launch instead of three: every workgroup turns its 256 histogram columns into per-slice start offsets and publishes
+// their totals; the workgroup that draws the last ticket (an agent-scope atomic in the status block, release fence
+// before it, acquire fence after it) scans all nb totals into cursor[] (= bin_start[]) with coalesced 16-byte pieces --
+// thread-local prefix of 4, wave scan by cross-lane shifts, four wave totals through LDS -- and, while it has every
+// bin's [start, end) in registers, records for every chunk of `chunk` grouped positions the tile that holds the chunk's
+// first position (what tile_chunk_bins_kernel found by bisection).  The separate scan kernel took 26 us for 16 384 bins
+// (one uncoalesced serial pass per thread) and two more launch gaps; this is ~6 us in all (profiles/r05_tuning.md).
+// totals / cursor must be allocated with nb rounded up to a multiple of 4 entries.
+__global__ __launch_bounds__(BLOCK) void group_offsets_scan_kernel(uint32_t* hist, uint32_t nblocks, uint32_t nb,
+                                                                   uint32_t* totals, uint32_t* cursor,
+                                                                   StatusBlock* status, uint64_t n_pos, uint32_t chunk,
+                                                                   uint32_t* chunk_bin) {
+  __shared__ uint32_t s_wave[BLOCK / 64];
+  __shared__ uint32_t s_last;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t bin = blockIdx.x * BLOCK + tid;
+  if (bin < nb) {
+    uint32_t run = 0;
+    uint32_t b = 0;
+    for (; b + 8 <= nblocks; b += 8) {
+      uint32_t h[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) h[u] = hist[(uint64_t)(b + u) * nb + bin];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        hist[(uint64_t)(b + u) * nb + bin] = run;
+        run += h[u];
+      }
+    }
+    for (; b < nblocks; ++b) {
+      const uint32_t h = hist[(uint64_t)b * nb + bin];
+      hist[(uint64_t)b * nb + bin] = run;
+      run += h;
+    }
+    totals[bin] = run;
+  }
+  __threadfence();                 // the totals of this workgroup are visible device-wide before its ticket is
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(&status->ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;             // (workgroup-uniform)
+  __threadfence();                 // every other workgroup's totals are visible to this one
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  uint32_t carry = 0;
+  constexpr int NT = 4;            // tiles of BLOCK * 4 bins whose loads are issued together
+  for (uint32_t base = 0; base < nb; base += (uint32_t)BLOCK * 4u * NT) {
+    uint4 v[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const uint32_t i0 = base + ((uint32_t)j * BLOCK + tid) * 4u;
+      v[j] = i0 < nb ? reinterpret_cast<const uint4*>(totals)[i0 >> 2] : make_uint4(0u, 0u, 0u, 0u);
+      if (i0 + 1u >= nb) v[j].y = 0u;     // (the padding entries of the allocation hold nothing)
+      if (i0 + 2u >= nb) v[j].z = 0u;
+      if (i0 + 3u >= nb) v[j].w = 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const uint32_t i0 = base + ((uint32_t)j * BLOCK + tid) * 4u;
+      const uint32_t local = v[j].x + v[j].y + v[j].z + v[j].w;
+      uint32_t incl = local;
+#pragma unroll
+      for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      __syncthreads();              // (s_wave of the previous tile has been read)
+      if (lane == 63u) s_wave[wave] = incl;
+      __syncthreads();
+      uint32_t wave_off = 0, tile_total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)BLOCK / 64u; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) wave_off += t;
+        tile_total += t;
+      }
+      const uint32_t e0 = carry + wave_off + incl - local;
+      const uint32_t e1 = e0 + v[j].x, e2 = e1 + v[j].y, e3 = e2 + v[j].z, e4 = e3 + v[j].w;
+      if (i0 < nb) reinterpret_cast<uint4*>(cursor)[i0 >> 2] = make_uint4(e0, e1, e2, e3);
+      if (chunk_bin) {              // chunks whose first position p0 = c * chunk lies in [start, end) of a non-empty bin
+        const uint32_t st[5] = {e0, e1, e2, e3, e4};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (st[k + 1] == st[k]) continue;
+          for (uint64_t c = ((uint64_t)st[k] + chunk - 1u) / chunk; c * chunk < (uint64_t)st[k + 1]; ++c)
+            chunk_bin[c] = i0 + (uint32_t)k;
+        }
+      }
+      carry += tile_total;
+    }
+  }
+  if (tid == 0) status->n_valid = carry;
 }
 
 template <class T>
@@ -1491,6 +1876,7 @@ struct Eval2Args {
   // ceil(2^32 / (cols * LV)) for a full tile row (2^ts + 1 grid points) and for the last tile column's shorter rows:
   // item -> (grid row, vector) of the tile staging by one v_mul_hi instead of an emulated division
   uint32_t rvm_full, rvm_edge;
+  uint32_t ch_split;           // eval_bilinear_tiles_kernel: 0 / 1 = every workgroup handles whole rows, 2 = one half each
 };
 
 template <class T, bool LDS>
@@ -1576,81 +1962,6 @@ __global__ __launch_bounds__(BLOCK) void pack_pairs_kernel(const E* in, E* out, 
       dst[e] = src[((pair >> 1) + (pair & 1u)) * units + c];                // z[xi][yi + h][c]
     }
   }
-}
-
-// Correctly rounded division of many numerators by ONE divisor (the per-query knot spacing shared by all channels
-// of a row): r = RN(1 / d) is formed once with the IEEE division, then every quotient costs one multiplication and
-// four FMAs -- all available as packed 2 x f32 instructions -- instead of the ~10-instruction IEEE sequence with its
-// quarter-rate reciprocal:
-//     q0 = RN(n r);  e0 = n - d q0 (exact, FMA);  q1 = RN(q0 + e0 r);  e1 = n - d q1 (exact);  q = RN(q1 + e1 r).
-// q0 is within 2^-23 |n / d| of the quotient, so q1 is a faithful rounding of it, and for a faithful q1 and a
-// correctly rounded reciprocal the last step yields RN(n / d) exactly (Markstein's theorem; Muller et al., Handbook
-// of Floating-Point Arithmetic, "division with an FMA") -- provided no intermediate under- or overflows.  The guard
-// keeps divisor and numerators inside an exponent window in which every product and residual is a normal number;
-// it is ONE test per vector: the smallest magnitude of the components >= N_LO (an exact zero therefore takes the
-// IEEE path: flat data lose the speed-up, never the result) and the sum of the magnitudes <= N_HI (a NaN or an
-// infinity makes the sum fail).  Outside the window the lane does the IEEE division.  The explicit FMAs compute
-// exact residuals; they are not contractions of the reference's expression, whose operation order (linear.rs:33-35)
-// is unchanged: m = RN(n / d), then RN(RN(m (x - x1)) + y1).  Pinned against the IEEE path of the gather kernel on
-// all 6.4e8 outputs of C3 (test_full_size_c3_bilinear) and by test_bilinear_tile_grouped_lds (values far outside
-// the window included).
-template <class T>
-struct DivWindow;
-template <>
-struct DivWindow<float> {
-  static constexpr float N_LO = 0x1p-60f, N_HI = 0x1p60f, D_LO = 0x1p-40f, D_HI = 0x1p40f;
-};
-template <>
-struct DivWindow<double> {
-  static constexpr double N_LO = 0x1p-500, N_HI = 0x1p500, D_LO = 0x1p-400, D_HI = 0x1p400;
-};
-template <class T>
-struct SharedDivisor {
-  T d, r;
-  bool ok;
-};
-template <class T>
-__device__ __forceinline__ SharedDivisor<T> shared_divisor(T d) {
-  SharedDivisor<T> s;
-  s.d = d;
-  s.r = T(1) / d;
-  s.ok = (d >= DivWindow<T>::D_LO) && (d <= DivWindow<T>::D_HI);
-  return s;
-}
-__device__ __forceinline__ bool nums_in_window(flt4 n) {
-  const float lo = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
-  const float sum = (fabsf(n.x) + fabsf(n.y)) + (fabsf(n.z) + fabsf(n.w));
-  return (lo >= DivWindow<float>::N_LO) & (sum <= DivWindow<float>::N_HI);
-}
-__device__ __forceinline__ bool nums_in_window(float n) {
-  const float a = fabsf(n);
-  return (a >= DivWindow<float>::N_LO) & (a <= DivWindow<float>::N_HI);
-}
-__device__ __forceinline__ bool nums_in_window(double n) {
-  const double a = fabs(n);
-  return (a >= DivWindow<double>::N_LO) & (a <= DivWindow<double>::N_HI);
-}
-__device__ __forceinline__ bool nums_in_window(dbl2 n) {
-  const double lo = fmin(fabs(n.x), fabs(n.y));
-  const double sum = fabs(n.x) + fabs(n.y);
-  return (lo >= DivWindow<double>::N_LO) & (sum <= DivWindow<double>::N_HI);
-}
-template <class T, class V>
-__device__ __forceinline__ V div_shared(V n, const SharedDivisor<T>& s) {
-  const V d = V(s.d), r = V(s.r);
-  const V q0 = n * r;
-  const V e0 = __builtin_elementwise_fma(-q0, d, n);
-  const V q1 = __builtin_elementwise_fma(e0, r, q0);
-  const V e1 = __builtin_elementwise_fma(-q1, d, n);
-  V q = __builtin_elementwise_fma(e1, r, q1);
-  if (__builtin_expect(!(s.ok & nums_in_window(n)), 0)) q = n / s.d;   // outside the window: the IEEE division
-  return q;
-}
-// Linear::calc_frac (linear.rs:29-36) with the divisor's reciprocal shared across the row
-template <class T, class V>
-__device__ __forceinline__ V frac_shared(T x1, V y1, const SharedDivisor<T>& dx, V y2, T x) {
-  const V m = div_shared<T, V>(y2 - y1, dx);
-  return m * (x - x1) + y1;
 }
 
 // APPROX exists only for the tuning harness (tools/tune_eval.hip: how much of the kernel is division cost);
@@ -1769,7 +2080,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_kernel(Eval2Args<T> A, uint3
 // query) instead of three -- the same bits, because the slope of a grid cell does not depend on the query.  At C3
 // (2.4 queries per cell) the tile kernel is bound by the arithmetic of those divisions.
 template <class T, int VEC, int TB, int RB = TB, int MAXI = 6, bool COMPACT = false, bool SLOPE = false, int NREC = 1>
-__global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A) {
+__global__ __launch_bounds__(TB, 4) void eval_bilinear_tiles_kernel(Eval2Args<T> A) {
   using V = typename VecT<T, VEC>::type;
   static_assert(RB <= TB, "the first RB threads of the workgroup load the records");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1778,7 +2089,13 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
   __shared__ uint4 s_rec[RB];
   __shared__ T s_rq[COMPACT ? 2 : 2 * RB];   // {qx, qy} of non-compact records (f64, or an axis with more than 65536 knots)
   const uint32_t S = 1u << A.ts, S1 = S + 1u;
-  const uint32_t LV = (uint32_t)(A.lanes / VEC);
+  // Channel split (A.ch_split = 2): the workgroup stages and evaluates only one half of the trailing axis -- LV is the
+  // number of vectors per row IT handles, LVF the row's full length, `ch0` its first vector.  Two such workgroups of
+  // 512 threads share a CU, each with its own half-tile (values + slopes: 72 KiB at C3), and overlap each other's
+  // staging / slope / hand-over phases, which a single 1024-thread workgroup serialises behind its barriers.
+  const uint32_t LVF = (uint32_t)(A.lanes / VEC);
+  const uint32_t nsplit = A.ch_split ? A.ch_split : 1u;
+  const uint32_t LV = LVF / nsplit;
   V* s_tile = reinterpret_cast<V*>(smem_raw);                              // [S1][S1][LV]
   V* s_mx = s_tile + (size_t)S1 * S1 * LV;                                 // SLOPE: [S][S1][LV]
   T* s_kx = reinterpret_cast<T*>(smem_raw + ((size_t)S1 * S1 + (SLOPE ? (size_t)S * S1 : 0)) * LV * sizeof(V));   // [S1]
@@ -1795,8 +2112,13 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
   const uint64_t nchunks = (n_pos + A.chunk - 1) / A.chunk;
   const uint64_t per = (nchunks + 7) / 8;
   const bool xcd = (gridDim.x & 7u) == 0u;
-  const uint64_t c_first = xcd ? (uint64_t)(blockIdx.x >> 3) : (uint64_t)blockIdx.x;
-  const uint64_t c_step = xcd ? (uint64_t)(gridDim.x >> 3) : (uint64_t)gridDim.x;
+  // (split: the workgroups of one chunk's halves are neighbours on the same XCD -- the second reader of the chunk's
+  //  records finds them in that XCD's L2; the host makes the grid a multiple of 8 * ch_split)
+  const uint32_t wg_local = xcd ? (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t ch0 = (wg_local % nsplit) * LV;
+  const uint32_t lvs = 31u - (uint32_t)__builtin_clz(LV);   // LV is a power of two (it divides TB)
+  const uint64_t c_first = (uint64_t)(wg_local / nsplit);
+  const uint64_t c_step = (uint64_t)((xcd ? (gridDim.x >> 3) : gridDim.x) / nsplit);
   const uint64_t c_span = xcd ? per : nchunks;
   const uint64_t c_base = xcd ? (uint64_t)(blockIdx.x & 7u) * per : 0;
   for (uint64_t cl = c_first; cl < c_span; cl += c_step) {
@@ -1868,7 +2190,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
         // workgroup-uniform tile origin + one 32 x 32 -> 64-bit multiply-add per load (a grid row is < 2^32 elements:
         // checked by the host)
         const V* src = reinterpret_cast<const V*>(tile0 + (uint64_t)r * row_elems);
-        pre[k] = src[j];
+        pre[k] = src[(j >> lvs) * LVF + ch0 + (j & (LV - 1u))];   // (grid point, vector) of this workgroup's channel range
         pre_off[k] = mine ? r * S1 * LV + j : 0xffffffffu;
       }
       // threads 0 .. rows-1 carry the x knots (and their right neighbours, for the spacing), 128 .. 128+cols-1 the y
@@ -2009,7 +2331,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
             const V z1 = m1 * ddx + b1;   // m * (x - x1) + b with the staged slopes (bilinear.rs:88-97, linear.rs:33-35)
             const V z2 = m2 * ddx + b2;
             const V m = div_shared<T, V>(z2 - z1, dy);
-            V* o = reinterpret_cast<V*>(A.out + (uint64_t)r.x * (uint32_t)A.out_stride) + v;   // (row stride < 2^32: host)
+            V* o = reinterpret_cast<V*>(A.out + (uint64_t)r.x * (uint32_t)A.out_stride) + ch0 + v;   // (row stride < 2^32: host)
 #ifdef NDI_TUNING
             if (A.debug & 4) {
               const V w = m * yd + z1;
@@ -2043,7 +2365,7 @@ __global__ __launch_bounds__(TB) void eval_bilinear_tiles_kernel(Eval2Args<T> A)
             const uint32_t zo = (lx * S1 + ly) * LV + v;
             const V* z11 = s_tile + zo;
             const T y1 = s_ky[ly], y2 = s_ky[ly + 1u];
-            V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride);
+            V* o = reinterpret_cast<V*>(A.out + qi * A.out_stride) + ch0;
             SharedDivisor<T> dy;
             dy.d = y2 - y1; dy.r = s_dyr[2u * ly + 1u]; dy.ok = dy.r > T(0);
             const V a11 = z11[0], a12 = z11[LV], a21 = z11[(size_t)S1 * LV], a22 = z11[(size_t)S1 * LV + LV];
@@ -2250,6 +2572,217 @@ __global__ __launch_bounds__(TB) void eval_fused2d_kernel(EvalFused2Args<T> A) {
     }
     __builtin_amdgcn_wave_barrier();        // the strip is rewritten by the next batch
   }
+  }
+}
+
+// 2-D QUERY PER LANE with the whole GRID resident in LDS -- the reference's own 2-D bench shape (a 100 x 100 scalar grid,
+// benches/bench_interp2d.rs:12-18: 80 KB in f64) and any other grid that fits beside its axes.  The counters of the
+// query-order kernel on that shape (profiles/r05_small_shapes_counters.txt) show the L1 address path as the bound: every
+// one of the four corner loads of a wave touches up to 64 different cache lines (374 L1 accesses per 64 queries: 0.48 of
+// the 0.90 ms).  With the grid in LDS no corner read leaves the CU.  A lane owns its query: both searches, the two knot
+// spacings with their staged reciprocals (one record {k_l, dk, RN(1 / dk)} per knot interval and axis), the four corners of
+// every value from LDS, bilinear.rs:88-97 with the correctly rounded shared-divisor divisions (div_shared: the bits of the
+// IEEE divisions); scalar grids take QPL consecutive queries per lane (16-byte query loads and stores), rows of several
+// values leave through a wave-private strip as one sequential stream of 16-byte vectors.
+template <class T>
+struct EvalLanes2Args {
+  Pyramid<T> px, py;
+  BucketIndex<T> bx, by;   // lut == nullptr: pyramid search on that axis
+  const T* data;           // plain grid [nx][ny][lanes]
+  const T* qx;
+  const T* qy;
+  T* out;
+  uint64_t nq, out_stride;
+  uint32_t lanes;
+  int mode;
+  const unsigned long long* first_fail;   // [2]: x, y (range_check_kernel)
+};
+
+template <class T, int QPL, int TB>
+__global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  using QV = typename VecT<T, QPL>::type;
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t nx = A.px.n, ny = A.py.n, L = A.lanes;
+  const uint32_t nxa = nx + A.px.n1, nya = ny + A.py.n1;
+  // LDS: [x pyramid | y pyramid | x lut | y lut | x interval records | y interval records | grid | per-wave strips]
+  size_t off;
+  {
+    T* sx = reinterpret_cast<T*>(smem_raw);
+    T* sy = sx + nxa;
+    for (uint32_t i = tid; i < nxa; i += TB) sx[i] = A.px.lv0[i];
+    for (uint32_t i = tid; i < nya; i += TB) sy[i] = A.py.lv0[i];
+    off = ((size_t)(nxa + nya) * sizeof(T) + 15u) & ~(size_t)15u;
+  }
+  lds_u16 lutx = nullptr, luty = nullptr;
+  if (A.bx.lut || A.by.lut) {
+    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
+    const uint32_t wx = A.bx.lut ? (A.bx.m + 2u) / 2u : 0u, wy = A.by.lut ? (A.by.m + 2u) / 2u : 0u;
+    const uint32_t* srcx = reinterpret_cast<const uint32_t*>(A.bx.lut);
+    const uint32_t* srcy = reinterpret_cast<const uint32_t*>(A.by.lut);
+    for (uint32_t i = tid; i < wx; i += TB) sl[i] = srcx[i];
+    for (uint32_t i = tid; i < wy; i += TB) sl[wx + i] = srcy[i];
+    if (wx) lutx = (lds_u16)(smem_raw + off);
+    if (wy) luty = (lds_u16)(smem_raw + off + (size_t)wx * 4u);
+    off += (((size_t)(wx + wy) * 4u) + 15u) & ~(size_t)15u;
+  }
+  XRec<T>* s_xx = reinterpret_cast<XRec<T>*>(smem_raw + off);
+  off += (size_t)(nx - 1u) * sizeof(XRec<T>);
+  XRec<T>* s_xy = reinterpret_cast<XRec<T>*>(smem_raw + off);
+  off += (size_t)(ny - 1u) * sizeof(XRec<T>);
+  T* s_g = reinterpret_cast<T*>(smem_raw + off);
+  const uint32_t gelems = nx * ny * L;
+  off += ((size_t)gelems * sizeof(T) + 15u) & ~(size_t)15u;
+  T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;   // (touched only when L > 1)
+  for (uint32_t i = tid; i + 1u < nx; i += TB) {
+    const T kl = A.px.lv0[i], kr = A.px.lv0[i + 1];
+    const SharedDivisor<T> sd = shared_divisor<T>(kr - kl);
+    XRec<T> r;
+    r.xl = kl; r.dx = sd.d; r.r = sd.ok ? sd.r : T(0); r.pad = T(0);
+    s_xx[i] = r;
+  }
+  for (uint32_t i = tid; i + 1u < ny; i += TB) {
+    const T kl = A.py.lv0[i], kr = A.py.lv0[i + 1];
+    const SharedDivisor<T> sd = shared_divisor<T>(kr - kl);
+    XRec<T> r;
+    r.xl = kl; r.dx = sd.d; r.r = sd.ok ? sd.r : T(0); r.pad = T(0);
+    s_xy[i] = r;
+  }
+  if ((gelems % VN) == 0u && (reinterpret_cast<uintptr_t>(A.data) & 15u) == 0u) {
+    const V* src = reinterpret_cast<const V*>(A.data);
+    V* dst = reinterpret_cast<V*>(s_g);
+    for (uint32_t i = tid; i < gelems / VN; i += TB) dst[i] = src[i];
+  } else {
+    for (uint32_t i = tid; i < gelems; i += TB) s_g[i] = A.data[i];
+  }
+  __syncthreads();
+  PyramidLds<T> PX, PY;
+  PX.lv0 = (lds_ptr<T>)(smem_raw);
+  PX.lv1 = PX.lv0 + nx;
+  PX.n = nx; PX.n1 = A.px.n1; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
+  PY.lv0 = PX.lv0 + nxa;
+  PY.lv1 = PY.lv0 + ny;
+  PY.n = ny; PY.n1 = A.py.n1; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
+  const T x0 = PX.lv0[0], xn = PX.lv0[nx - 1], y0 = PY.lv0[0], yn = PY.lv0[ny - 1];
+  unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
+  if (limit > A.nq) limit = A.nq;
+  const uint32_t rowe = ny * L;   // elements between grid rows
+  // the query's cell and its per-direction scalars (all 64 lanes call it: the pyramid search is wave-cooperative)
+  struct Cell { uint32_t o; T fx, fy; SharedDivisor<T> dx, dy; };
+  auto locate = [&](T x, T y) -> Cell {
+    const uint32_t xi = lutx ? locate_index_lut<T>(PX, lutx, A.bx.m, A.bx.scale, x0, xn, x)
+                             : locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
+    const uint32_t yi = luty ? locate_index_lut<T>(PY, luty, A.by.m, A.by.scale, y0, yn, y)
+                             : locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
+    const XRec<T> rx = s_xx[NDI_CHK(xi, nx - 1u, BC_CELL_X)], ry = s_xy[NDI_CHK(yi, ny - 1u, BC_CELL_Y)];
+    Cell c;
+    c.o = (xi * ny + yi) * L;
+    c.fx = x - rx.xl;                 // linear.rs:35's (x - x1) of both directions
+    c.fy = y - ry.xl;
+    c.dx.d = rx.dx; c.dx.r = rx.r; c.dx.ok = rx.r > T(0);
+    c.dy.d = ry.dx; c.dy.r = ry.r; c.dy.ok = ry.r > T(0);
+    return c;
+  };
+  auto point = [&](const Cell& c, uint32_t l) -> T {   // bilinear.rs:88-97
+    const T* g = s_g + c.o + l;
+    const T a11 = g[0], a12 = g[L], a21 = g[rowe], a22 = g[rowe + L];
+    const T z1 = div_shared<T, T>(a21 - a11, c.dx) * c.fx + a11;
+    const T z2 = div_shared<T, T>(a22 - a12, c.dx) * c.fx + a12;
+    return div_shared<T, T>(z2 - z1, c.dy) * c.fy + z1;
+  };
+  if (L == 1u) {
+    const uint64_t nvec = limit / QPL;
+    const uint64_t step = (uint64_t)gridDim.x * TB;
+    const QV* qxv = reinterpret_cast<const QV*>(A.qx);
+    const QV* qyv = reinterpret_cast<const QV*>(A.qy);
+    QV* ov = reinterpret_cast<QV*>(A.out);
+    const uint64_t vlast = nvec ? nvec - 1u : 0u;
+    uint64_t v0 = (uint64_t)blockIdx.x * TB + (tid & ~63u);
+    QV nx_ = QV(x0), ny_ = QV(y0);
+    if (nvec) {
+      const uint64_t vc = (v0 + lane < nvec) ? v0 + lane : vlast;
+      nx_ = qxv[vc];
+      ny_ = qyv[vc];
+    }
+    for (; v0 < nvec; v0 += step) {
+      const uint64_t vi = v0 + lane;
+      const bool active = vi < nvec;
+      const QV cx = nx_, cy = ny_;
+      {
+        const uint64_t vn = vi + step;
+        const uint64_t vc = vn < nvec ? vn : vlast;
+        nx_ = qxv[vc];
+        ny_ = qyv[vc];
+      }
+      QV res;
+#pragma unroll
+      for (int u = 0; u < QPL; ++u) {
+        T x, y;
+        if constexpr (QPL == 1) { x = cx; y = cy; } else { x = cx[u]; y = cy[u]; }
+        if (!active) { x = x0; y = y0; }
+        const Cell c = locate(x, y);
+        const T r = point(c, 0u);
+        if constexpr (QPL == 1) res = r; else res[u] = r;
+      }
+      if constexpr (QPL == 1) {
+        if (active) store_stream<true>(A.out + vi * A.out_stride, res);
+      } else {
+        if (active) store_stream<true>(ov + vi, res);
+      }
+    }
+    const uint64_t done = nvec * QPL;
+    if (blockIdx.x == 0 && tid < 64u && done < limit) {
+      const uint64_t qi = done + lane;
+      const bool active = qi < limit;
+      const T x = active ? A.qx[qi] : x0, y = active ? A.qy[qi] : y0;
+      const Cell c = locate(x, y);
+      const T r = point(c, 0u);
+      if (active) A.out[qi * A.out_stride] = r;
+    }
+    return;
+  }
+  const bool contig = A.out_stride == (uint64_t)L;
+  const uint64_t wstep = (uint64_t)gridDim.x * TB;
+  uint64_t base = ((uint64_t)blockIdx.x * (TB / 64) + (tid >> 6)) * 64u;
+  T xq, yq;
+  {
+    const uint64_t pc = (base + lane < A.nq) ? base + lane : A.nq - 1u;
+    xq = A.qx[pc];
+    yq = A.qy[pc];
+  }
+  for (; base < limit; base += wstep) {
+    const bool active = base + lane < limit;
+    const T x = active ? xq : x0, y = active ? yq : y0;
+    {
+      const uint64_t pn = base + wstep + lane;
+      const uint64_t pc = pn < A.nq ? pn : A.nq - 1u;
+      xq = A.qx[pc];
+      yq = A.qy[pc];
+    }
+    const Cell c = locate(x, y);
+    for (uint32_t l = 0; l < L; ++l) s_strip[lane * L + l] = point(c, l);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
+    const uint32_t total = nq_here * L;
+    if (contig) {
+      T* const o = A.out + base * L;
+      for (uint32_t e0 = lane * VN; e0 < total; e0 += 64u * VN) {
+        if (e0 + VN <= total) {
+          store_stream<true>(reinterpret_cast<V*>(o + e0), *reinterpret_cast<const V*>(s_strip + e0));
+        } else {
+          for (uint32_t e = e0; e < total; ++e) o[e] = s_strip[e];
+        }
+      }
+    } else {
+      for (uint32_t it = lane; it < total; it += 64u) {
+        const uint32_t ql = it / L, l = it - ql * L;
+        A.out[(base + ql) * A.out_stride + l] = s_strip[it];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

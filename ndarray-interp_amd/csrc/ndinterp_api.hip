@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <set>
+#include <stdexcept>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -95,6 +96,13 @@ static void copy_across_devices(void* dst, int dst_dev, const void* src, int src
       NDI_HIP(hipMemcpy((char*)dst + off, pin, nb, hipMemcpyHostToDevice));
     }
   }
+}
+
+// Test hook (tests/test_gpu_short_rows.py): NDI_TEST_FAIL_LAZY_ALLOC=1 makes the lazily built optional copies (bucket
+// indices, interval-packed tables) fail as an out-of-memory hipMalloc would -- the fallbacks must serve the batch.
+static void maybe_fail_lazy_alloc(int line) {
+  const char* e = std::getenv("NDI_TEST_FAIL_LAZY_ALLOC");
+  if (e && e[0] == '1') throw HipFailure{hipErrorOutOfMemory, "injected lazy-allocation failure", line};
 }
 
 // Workspaces are keyed by (stream, calling thread): work enqueued on one stream is ordered, so a
@@ -280,9 +288,21 @@ struct DevicePyramid {
   // and latency-bound small batches never pay for it.
   bool guess_is_exact = false;
   mutable std::once_flag lut_once;
+  // A build that fails (out of device memory, a copy refused during stream capture) leaves the axis without the
+  // index: the pyramid search serves every batch as before -- nothing is thrown out of call_once, no later call
+  // retries, no evaluation fails because an optional accelerator could not be built.
   void ensure_bucket_index() const {   // lazily built cache: logically const
     std::call_once(lut_once, [this] {
-      const_cast<DevicePyramid*>(this)->build_bucket_index(host_knots.data(), host_knots.size(), guess_is_exact);
+      DevicePyramid* self = const_cast<DevicePyramid*>(this);
+      try {
+        maybe_fail_lazy_alloc(__LINE__);
+        self->build_bucket_index(host_knots.data(), host_knots.size(), guess_is_exact);
+      } catch (const HipFailure&) {
+        (void)hipGetLastError();
+        self->bidx = BucketIndex<T>{nullptr, 0, T(0)};
+        self->lut_bytes = 0;
+        self->lut_buf.release();
+      }
     });
   }
 
@@ -306,9 +326,16 @@ struct DevicePyramid {
       for (uint64_t i = 0; i < n; ++i) lut[bucket_of<T>(knots[i], k0, scale, m) + 1]++;   // counts, shifted by one
       for (uint32_t b = 0; b < m; ++b) lut[b + 1] += lut[b];                              // lut[b] = knots in buckets < b
       lut[m + 1] = (uint32_t)n;
-      self->lut32_buf.reserve(lut.size() * sizeof(uint32_t));
-      NDI_HIP(hipMemcpy(self->lut32_buf.p, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      self->bidx32 = BucketIndex32<T>{self->lut32_buf.template as<uint32_t>(), m, scale};
+      try {   // (failure: no index, the pyramid search from memory serves the axis -- see ensure_bucket_index)
+        maybe_fail_lazy_alloc(__LINE__);
+        self->lut32_buf.reserve(lut.size() * sizeof(uint32_t));
+        NDI_HIP(hipMemcpy(self->lut32_buf.p, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        self->bidx32 = BucketIndex32<T>{self->lut32_buf.template as<uint32_t>(), m, scale};
+      } catch (const HipFailure&) {
+        (void)hipGetLastError();
+        self->bidx32 = BucketIndex32<T>{nullptr, 0, T(0)};
+        self->lut32_buf.release();
+      }
     });
   }
 
@@ -513,6 +540,15 @@ static void reset_status(void* status, hipStream_t s) {
 constexpr uint32_t BUCKETED_RUN = 1;         // consecutive 128-query chunks per workgroup of eval_bucketed_kernel
                                              // (1 / 4 / 8 / 16 / 32 measured equal within 1 %: tools/sweep_target.py)
 constexpr uint32_t GROUP_MAX_BLOCKS = 256;   // query slices of the block-local counting sort
+// NDI_GROUP_BLOCKS (A/B, read once): fewer, longer slices -- longer runs per (slice, bin) in the record scatter
+static uint32_t group_blocks() {
+  static const uint32_t v = [] {
+    const char* e = std::getenv("NDI_GROUP_BLOCKS");
+    const int k = e ? std::atoi(e) : 0;
+    return (uint32_t)(k >= 8 && k <= (int)GROUP_MAX_BLOCKS ? k : (int)GROUP_MAX_BLOCKS);
+  }();
+  return v;
+}
 constexpr uint32_t GROUP_MAX_BINS = 16384;   // histogram must fit LDS next to the pyramid
 
 template <class T>
@@ -733,24 +769,66 @@ struct Interp1DImpl final : Interp1DBase {
   // interval-packed copy of the tables for rows shorter than a cache line (pack_intervals_kernel), built on first
   // use by a batch that takes the query-order kernel; a replica builds its own
   DevBuf packed;
-  std::once_flag packed_once;
-  bool packed_ok = false;
   static constexpr size_t PACKED_LIMIT = 1ull << 30;
-  bool ensure_packed() {
-    std::call_once(packed_once, [this] {
+  // 0 = not tried, 1 = ready and known complete, 2 = unavailable (too large / allocation failed: the unpacked tables serve
+  // every batch), 3 = built by a kernel enqueued on packed_stream, completion signalled by packed_ev
+  std::atomic<int> packed_state{0};
+  std::mutex packed_mu;
+  hipEvent_t packed_ev = nullptr;
+  hipStream_t packed_stream = nullptr;
+  ~Interp1DImpl() override {
+    if (packed_ev) (void)hipEventDestroy(packed_ev);
+  }
+  // The copy is made by a kernel on the CALLER's stream (no NULL-stream launch, no device-wide synchronisation on the
+  // evaluation path: the ring's side stream keeps running); calls on other streams are ordered behind it with an event
+  // until it is known complete.  Never while the stream is being captured, and never fatal: a failed allocation leaves
+  // the handle on the unpacked tables.
+  bool ensure_packed(hipStream_t s) {
+    int st = packed_state.load(std::memory_order_acquire);
+    if (st == 1) return true;
+    if (st == 2) return false;
+    std::lock_guard<std::mutex> g(packed_mu);
+    st = packed_state.load(std::memory_order_acquire);
+    if (st == 1) return true;
+    if (st == 2) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+    if (cs != hipStreamCaptureStatusNone) return false;   // this batch reads the unpacked tables
+    if (st == 0) {
       const int parts = strategy == NDI_CUBIC_SPLINE ? 4 : 2;
       const size_t bytes = (size_t)(n - 1) * parts * lanes * sizeof(T);
-      if (bytes == 0 || bytes > PACKED_LIMIT) return;
-      packed.reserve(bytes);
-      const uint64_t total = (n - 1) * (uint64_t)parts * lanes;
-      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((total + BLOCK - 1) / BLOCK, 65536));
-      hipLaunchKernelGGL(pack_intervals_kernel<T>, dim3(g), dim3(BLOCK), 0, (hipStream_t) nullptr, (const T*)data.as<T>(),
-                         (const T*)ca.as<T>(), (const T*)cb.as<T>(), packed.as<T>(), n, lanes, parts);
-      NDI_HIP(hipGetLastError());
-      NDI_HIP(hipDeviceSynchronize());   // once per handle; later launches may be on any stream
-      packed_ok = true;
-    });
-    return packed_ok;
+      if (bytes == 0 || bytes > PACKED_LIMIT) {
+        packed_state.store(2, std::memory_order_release);
+        return false;
+      }
+      try {
+        maybe_fail_lazy_alloc(__LINE__);
+        packed.reserve(bytes);
+        if (!packed_ev) NDI_HIP(hipEventCreateWithFlags(&packed_ev, hipEventDisableTiming));
+        const uint64_t total = (n - 1) * (uint64_t)parts * lanes;
+        const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((total + BLOCK - 1) / BLOCK, 65536));
+        hipLaunchKernelGGL(pack_intervals_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, (const T*)data.as<T>(),
+                           (const T*)ca.as<T>(), (const T*)cb.as<T>(), packed.as<T>(), n, lanes, parts);
+        NDI_HIP(hipGetLastError());
+        NDI_HIP(hipEventRecord(packed_ev, s));
+      } catch (const HipFailure&) {
+        (void)hipGetLastError();
+        packed.release();
+        packed_state.store(2, std::memory_order_release);
+        return false;
+      }
+      packed_stream = s;
+      packed_state.store(3, std::memory_order_release);
+      return true;
+    }
+    // st == 3
+    if (hipEventQuery(packed_ev) == hipSuccess) {
+      packed_state.store(1, std::memory_order_release);
+      return true;
+    }
+    (void)hipGetLastError();
+    if (s != packed_stream) NDI_HIP(hipStreamWaitEvent(s, packed_ev, 0));
+    return true;
   }
 
   uint64_t signature() const override {
@@ -1007,7 +1085,7 @@ struct Interp1DImpl final : Interp1DBase {
   // A batch is evaluated in two stages that may run on different streams: prep() = search (+ grouping) into a
   // scratch set, launch_eval() = the evaluation kernel reading that set.  Plan1 carries what prep() decided.
   struct Plan1 {
-    enum Kind { SMALL, BUCKETED, ROWS, FLAT, FUSED, BUCKETED_SHORT } kind = ROWS;
+    enum Kind { SMALL, BUCKETED, ROWS, FLAT, FUSED, BUCKETED_SHORT, LANES } kind = ROWS;
     const T* q = nullptr;
     uint64_t nq = 0;
     T* out = nullptr;
@@ -1021,7 +1099,108 @@ struct Interp1DImpl final : Interp1DBase {
     int f_unr = 2;
     size_t f_lds = 0;
     int s_cq = 64;   // BUCKETED_SHORT
+    int l_qpl = 1;   // LANES, scalar data: queries per lane (1, or one 16-byte vector)
   };
+
+  // LDS footprint of eval_lanes_kernel: [pyramid | lut | interval records | table records | per-wave strips]
+  size_t lanes_lds_bytes(bool with_lut, unsigned tb) const {
+    const size_t tr = strategy == NDI_CUBIC_SPLINE ? 4 : 2;
+    size_t b = (pyr.lds_bytes + 15) & ~(size_t)15;
+    if (with_lut) b += pyr.lut_bytes;
+    b += (size_t)(n - 1) * 4 * sizeof(T);
+    b += ((size_t)(n - 1) * lanes * tr * sizeof(T) + 15) & ~(size_t)15;
+    if (lanes > 1) b += (size_t)(tb / 64) * 64 * lanes * sizeof(T);
+    return b;
+  }
+
+  // Query per lane with the whole table set in LDS (eval_lanes_kernel): rows of up to 64 bytes (NDI_LANES_MAXB) whose
+  // records fit LDS beside the knots, batches that give every workgroup several times its staging bytes to write.
+  // NDI_LANES_KERNEL=0 leaves these shapes to the query-order kernel (A/B); =1 takes it whenever it fits.
+  bool plan_lanes(hipStream_t s, Scratch& sc, Plan1& P, int path) {
+    static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
+    static const int on_once = ShortKnobs::env("NDI_LANES_KERNEL", -1), maxb_once = ShortKnobs::env("NDI_LANES_MAXB", 64);
+    const int on = tune_live ? ShortKnobs::env("NDI_LANES_KERNEL", -1) : on_once;
+    const int maxb = tune_live ? ShortKnobs::env("NDI_LANES_MAXB", 64) : maxb_once;
+    if (on == 0 || path == NDI_PATH_BUCKETED || n < 2) return false;
+    if (on < 0 && short_knobs().mode != 0) return false;   // a pinned short-row variant (NDI_SHORT_MODE) is what runs
+    if (lanes * sizeof(T) > (size_t)maxb || pyr.lds_bytes > LDS_STAGE_LIMIT / 2) return false;
+    static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+    if (lut_env && P.nq >= 4096) pyr.ensure_bucket_index();
+    const size_t tab = lanes_lds_bytes(false, 64) - (lanes > 1 ? (size_t)64 * lanes * sizeof(T) : 0);
+    if (on < 0 && (P.nq < 65536 || (double)P.nq * (double)lanes * sizeof(T) < 4.0 * (double)cu_count() * (double)tab)) return false;
+    size_t best = 0;
+    for (int with_lut = (lut_env && P.nq >= 4096 && pyr.lut_bytes) ? 1 : 0; with_lut >= 0; --with_lut) {
+      for (unsigned tb : {1024u, 512u, 256u}) {      // among equals the largest workgroup: fewest staging passes
+        const size_t need = lanes_lds_bytes(with_lut != 0, tb);
+        if (need > FUSED_LDS_LIMIT) continue;
+        const size_t waves = std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
+        if (waves > best) {
+          best = waves;
+          P.f_lut = with_lut != 0;
+          P.f_tb = tb;
+          P.f_lds = need;
+        }
+      }
+      if (best) break;   // the bucket index whenever it fits at all: the tables are small by construction
+    }
+    if (!best) return false;
+    constexpr int VN = Wide<T>::N;
+    P.l_qpl = (lanes == 1 && P.out_stride == 1 && aligned16(P.q) && aligned16(P.out)) ? VN : 1;
+    const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
+    const uint64_t per_wg = (uint64_t)P.f_tb * (lanes == 1 ? (uint64_t)P.l_qpl : 1);
+    P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + per_wg - 1) / per_wg, (uint64_t)cu_count() * wg_per_cu));
+    P.kind = Plan1::LANES;
+    g_last_path.store(NDI_PATH_GATHER);
+    StatusBlock* st = sc.status.as<StatusBlock>();
+    const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
+    const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + BLOCK - 1) / BLOCK, 4096));
+    ProfScope ps(s, PC_LOCATE);
+    hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, P.q, (const T*)nullptr, P.nq, k0, kn, k0, kn,
+                       mode, &st->first_fail[0]);
+    NDI_HIP(hipGetLastError());
+    ps.done();
+    return true;
+  }
+
+  void launch_lanes(hipStream_t s, Scratch& sc, const Plan1& P) {
+    EvalLanesArgs<T> F{};
+    F.pyr = pyr.view;
+    F.bx = P.f_lut ? pyr.bidx : BucketIndex<T>{nullptr, 0, T(0)};
+    F.data = data.as<T>();
+    F.ca = ca.as<T>();
+    F.cb = cb.as<T>();
+    F.q = P.q;
+    F.out = P.out;
+    F.nq = P.nq;
+    F.out_stride = P.out_stride;
+    F.lanes = (uint32_t)lanes;
+    F.mode = mode;
+    F.first_fail = &sc.status.as<StatusBlock>()->first_fail[0];
+    if (std::getenv("NDI_TRACE_PLAN"))
+      std::fprintf(stderr, "[ndi plan] lanes L=%llu qpl=%d lut=%d tb=%u grid=%u lds=%zu\n", (unsigned long long)lanes,
+                   P.l_qpl, (int)P.f_lut, P.f_tb, P.f_grid, P.f_lds);
+    constexpr int VN = Wide<T>::N;
+    const dim3 grid(P.f_grid), block(P.f_tb);
+#define NDI_LA(ST, QPL, TB)                                                               \
+  do {                                                                                    \
+    auto kern = eval_lanes_kernel<T, ST, QPL, TB>;                                        \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);         \
+    launch1<T>(s, PC_EVAL, grid, block, P.f_lds, kern, F);                                \
+  } while (0)
+#define NDI_LA_TB(ST, QPL)                                          \
+  do {                                                              \
+    if (P.f_tb == 1024) NDI_LA(ST, QPL, 1024);                      \
+    else if (P.f_tb == 512) NDI_LA(ST, QPL, 512);                   \
+    else NDI_LA(ST, QPL, 256);                                      \
+  } while (0)
+    if (strategy == NDI_CUBIC_SPLINE) {
+      if (P.l_qpl == VN) NDI_LA_TB(ST_CUBIC, VN); else NDI_LA_TB(ST_CUBIC, 1);
+    } else {
+      if (P.l_qpl == VN) NDI_LA_TB(ST_LINEAR, VN); else NDI_LA_TB(ST_LINEAR, 1);
+    }
+#undef NDI_LA_TB
+#undef NDI_LA
+  }
 
   // LDS footprint of eval_fused_kernel: [pyramid | lut | per-wave strips | tables]
   size_t fused_lds_bytes(bool with_lut, unsigned tb, int tables) const {
@@ -1055,7 +1234,7 @@ struct Interp1DImpl final : Interp1DBase {
       P.f_tb = 256;
       const bool strip2 = strategy != NDI_CUBIC_SPLINE;
       P.f_lds = (size_t)(256 / 64) * 64 * (sizeof(uint32_t) + (strip2 ? 2 : 1) * sizeof(T));
-      P.f_pack = (K.pack > 0 || (K.pack < 0 && lanes * sizeof(T) < 128)) && ensure_packed();
+      P.f_pack = (K.pack > 0 || (K.pack < 0 && lanes * sizeof(T) < 128)) && ensure_packed(s);
       P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + 255) / 256, (uint64_t)cu_count() * 8 * 4));
       P.kind = Plan1::FUSED;
       g_last_path.store(NDI_PATH_GATHER);
@@ -1128,7 +1307,7 @@ struct Interp1DImpl final : Interp1DBase {
     }
     P.f_lds = fused_lds_bytes(P.f_lut, P.f_tb, P.f_tlds);
     // rows shorter than a cache line read from L2: one contiguous record per interval instead of three row pieces
-    P.f_pack = !P.f_tlds && (K.pack > 0 || (K.pack < 0 && lanes * sizeof(T) < 128)) && ensure_packed();
+    P.f_pack = !P.f_tlds && (K.pack > 0 || (K.pack < 0 && lanes * sizeof(T) < 128)) && ensure_packed(s);
     const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(P.f_lds, 1), 32 / (P.f_tb / 64)));
     const uint64_t want = (uint64_t)cu_count() * (K.wgs > 0 ? (size_t)K.wgs : wg_per_cu * (P.f_tlds ? 1 : 4));
     P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + P.f_tb - 1) / P.f_tb, want));
@@ -1158,6 +1337,7 @@ struct Interp1DImpl final : Interp1DBase {
     // (scalar data at 1e8 queries: 98 -> 157 Gqueries/s f64, 2 lanes 45 -> 141).  Measured crossover
     // (profiles/r04_scalar_crossover.jsonl): ~8e6 output elements on <= 1024 knots, proportionally earlier on longer
     // axes (8192 knots: ~1e6), whose table gathers miss L1.  NDI_SMALL_MAXQ overrides the 8e6.
+    if (plan_lanes(s, sc, P, path)) return P;
     static const long small_maxq = ShortKnobs::env("NDI_SMALL_MAXQ", 8000000);
     const bool small_first = lanes <= 2 && pyr.lds_bytes <= LDS_STAGE_LIMIT;
     const double small_work = (double)nq * (double)lanes * (double)std::max<uint64_t>(n, 1024) / 1024.0;
@@ -1223,8 +1403,8 @@ struct Interp1DImpl final : Interp1DBase {
       P.kind = bucketed ? Plan1::BUCKETED : Plan1::BUCKETED_SHORT;
       P.s_cq = K.cq;
       const uint32_t nb = (uint32_t)(n - 1);
-      sc.counts.reserve((size_t)nb * sizeof(uint32_t));
-      sc.cursor.reserve((size_t)nb * sizeof(uint32_t));
+      sc.counts.reserve(((size_t)nb + 4) * sizeof(uint32_t));   // (+4: the fused scan reads / writes 16-byte pieces)
+      sc.cursor.reserve(((size_t)nb + 4) * sizeof(uint32_t));
       sc.perm.reserve(nq * sizeof(uint4));
       const T* sval = strategy == NDI_CUBIC_SPLINE ? (const T*)sc.t.as<T>() : q;   // t (cubic) / raw x (linear)
       if (lds_sort_fits(pyr, nb)) {
@@ -1235,10 +1415,9 @@ struct Interp1DImpl final : Interp1DBase {
         run_locate<T>(s, pyr, q, nq, sc.idx.as<uint32_t>(), nullptr, t_out,
                       &st->first_fail[0], mode, sc.hist.as<uint32_t>(), nb, &slice, &blocks, beside_eval);
         ProfScope ps(s, PC_GROUP);
-        hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
-                           sc.hist.as<uint32_t>(), blocks, nb, sc.counts.as<uint32_t>());
-        hipLaunchKernelGGL(bucket_scan_kernel<256>, dim3(1), dim3(256), 0, s, sc.counts.as<uint32_t>(), nb,
-                           sc.cursor.as<uint32_t>(), st);
+        hipLaunchKernelGGL(group_offsets_scan_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
+                           sc.hist.as<uint32_t>(), blocks, nb, sc.counts.as<uint32_t>(), sc.cursor.as<uint32_t>(), st,
+                           nq, 0u, (uint32_t*)nullptr);
         allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter_kernel<T>), (int)(GROUP_MAX_BINS * 4));
         hipLaunchKernelGGL(group_scatter_kernel<T>, dim3(blocks), dim3(BLOCK), (size_t)nb * 4, s,
                            (const uint32_t*)sc.idx.as<uint32_t>(), sval, nq, slice,
@@ -1295,6 +1474,10 @@ struct Interp1DImpl final : Interp1DBase {
     }
     if (P.kind == Plan1::FUSED) {
       launch_fused(s, sc, P);
+      return;
+    }
+    if (P.kind == Plan1::LANES) {
+      launch_lanes(s, sc, P);
       return;
     }
     Eval1Args<T> A{};
@@ -1969,7 +2152,8 @@ struct Interp2DImpl final : Interp2DBase {
   // Two stages as in Interp1DImpl: prep() = both searches (+ the optional tile grouping) into a scratch set,
   // launch_eval() = the bilinear kernel reading that set.
   struct Plan2 {
-    enum Kind { SMALL, GATHER, TILED, FUSED2 } kind = GATHER;
+    enum Kind { SMALL, GATHER, TILED, FUSED2, LANES2 } kind = GATHER;
+    int l_qpl = 1;          // LANES2, scalar grids: queries per lane (1, or one 16-byte vector)
     // FUSED2 (eval_fused2d_kernel)
     bool f_vec = false, f_lut = false;
     uint64_t f_lv = 0;
@@ -1999,6 +2183,50 @@ struct Interp2DImpl final : Interp2DBase {
     // unaligned rows of up to that many values for A/B runs: measured SLOWER from 3 values -- 100 x 100 x 5 f64: 11 vs
     // 21 Gqueries/s -- a thread per query turns every operand load into 64 scattered sectors, where the item-per-lane
     // gather kernel reads each query's 40-byte segments whole.)
+    // Grids that fit LDS beside their axes (the reference's 100 x 100 scalar grid: 80 KB in f64), rows of up to 64 bytes,
+    // large batches: query per lane with every corner read served by LDS (eval_lanes2d_kernel).  NDI_LANES2D_KERNEL=0: A/B.
+    {
+      static const bool tune_live2 = std::getenv("NDI_TUNE_LIVE") != nullptr;
+      static const int on_once = ShortKnobs::env("NDI_LANES2D_KERNEL", -1);
+      const int on = tune_live2 ? ShortKnobs::env("NDI_LANES2D_KERNEL", -1) : on_once;
+      const size_t grid_b = (size_t)nx * ny * lanes * sizeof(T);
+      if (on != 0 && path != NDI_PATH_BUCKETED && !pair_packed && both <= LDS_STAGE_LIMIT / 2 && lanes * sizeof(T) <= 64 &&
+          grid_b <= FUSED_LDS_LIMIT && (uint64_t)nx * ny * lanes < (1ull << 31) &&
+          (on > 0 || (nq >= 65536 && (double)nq * (double)lanes * sizeof(T) >= 4.0 * (double)cu_count() * (double)grid_b))) {
+        static const int lut_env0 = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+        size_t lut_b = 0;
+        if (lut_env0 && nq >= 4096) {
+          px.ensure_bucket_index();
+          py.ensure_bucket_index();
+          lut_b = px.lut_bytes + py.lut_bytes;
+        }
+        const size_t fixed = both + (size_t)(nx - 1 + ny - 1) * 4 * sizeof(T) + ((grid_b + 15) & ~(size_t)15);
+        size_t best = 0;
+        for (int with_lut = lut_b ? 1 : 0; with_lut >= 0 && !best; --with_lut)
+          for (unsigned tb : {1024u, 512u, 256u}) {
+            const size_t need = fixed + (with_lut ? lut_b : 0) + (lanes > 1 ? (size_t)(tb / 64) * 64 * lanes * sizeof(T) : 0);
+            if (need > FUSED_LDS_LIMIT) continue;
+            const size_t waves = std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
+            if (waves > best) { best = waves; P.f_lut = with_lut != 0; P.f_tb = tb; P.f_lds = need; }
+          }
+        if (best) {
+          constexpr int VNl = Wide<T>::N;
+          P.kind = Plan2::LANES2;
+          P.l_qpl = (lanes == 1 && out_stride == 1 && aligned16(qx) && aligned16(qy) && aligned16(out)) ? VNl : 1;
+          const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
+          const uint64_t per_wg = (uint64_t)P.f_tb * (lanes == 1 ? (uint64_t)P.l_qpl : 1);
+          P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + per_wg - 1) / per_wg, (uint64_t)cu_count() * wg_per_cu));
+          g_last_path.store(NDI_PATH_GATHER);
+          const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+          ProfScope ps(s, PC_LOCATE);
+          hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
+                             px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode, &st->first_fail[0]);
+          NDI_HIP(hipGetLastError());
+          ps.done();
+          return P;
+        }
+      }
+    }
     static const int small2d_lanes = ShortKnobs::env("NDI_SMALL2D_LANES", 2);
     constexpr int VNs = Wide<T>::N;
     const bool small2d = lanes <= 2 || (lanes <= (uint64_t)small2d_lanes && lanes % VNs != 0);
@@ -2150,7 +2378,7 @@ struct Interp2DImpl final : Interp2DBase {
         shmem = ((both_l + 15) & ~(size_t)15) + (size_t)nb * 4;
       }
       const unsigned threads = beside_eval ? 256u : threads_for_lds(shmem);
-      blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, tiled ? GROUP_MAX_BLOCKS : 2048));
+      blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, tiled ? group_blocks() : 2048));
       if (LA.bx.lut || LA.by.lut || tiled)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
         blocks = std::min<uint64_t>(blocks, (uint64_t)cu_count() * std::max<size_t>(1, (160 * 1024) / shmem));
       slice = (nq + blocks - 1) / blocks;
@@ -2173,19 +2401,19 @@ struct Interp2DImpl final : Interp2DBase {
       const unsigned gthreads = beside_eval ? 256u : (slice >= 4096 ? 1024u : (unsigned)BLOCK);
       sc.perm.reserve(nq * sizeof(uint4));            // grouped records
       if (!P.compact) sc.recq.reserve(nq * 2 * sizeof(T));
-      sc.counts.reserve((size_t)nb * sizeof(uint32_t));
-      sc.cursor.reserve((size_t)nb * sizeof(uint32_t));
+      sc.counts.reserve(((size_t)nb + 4) * sizeof(uint32_t));   // (+4: the fused scan reads / writes 16-byte pieces)
+      sc.cursor.reserve(((size_t)nb + 4) * sizeof(uint32_t));
       allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T, true>), (int)(GROUP_MAX_BINS * 4));
       allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T, false>), (int)(GROUP_MAX_BINS * 4));
       ProfScope ps(s, PC_GROUP);
-      hipLaunchKernelGGL(group_offsets_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
-                         sc.hist.as<uint32_t>(), (uint32_t)blocks, nb, sc.counts.as<uint32_t>());
-      if (beside_eval || nb <= 4096)   // (a 4-wave workgroup finds room beside a running evaluation kernel)
-        hipLaunchKernelGGL(bucket_scan_kernel<256>, dim3(1), dim3(256), 0, s, sc.counts.as<uint32_t>(), nb,
-                           sc.cursor.as<uint32_t>(), st);
-      else
-        hipLaunchKernelGGL(bucket_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, sc.counts.as<uint32_t>(), nb,
-                           sc.cursor.as<uint32_t>(), st);
+      {   // slice offsets, the scan of the tile totals and the tile each evaluation chunk starts in: one launch
+        const uint32_t chunk = tile_chunk();
+        const uint64_t nchunks = (nq + chunk - 1) / chunk;
+        sc.chunkbin.reserve(nchunks * sizeof(uint32_t));
+        hipLaunchKernelGGL(group_offsets_scan_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
+                           sc.hist.as<uint32_t>(), (uint32_t)blocks, nb, sc.counts.as<uint32_t>(),
+                           sc.cursor.as<uint32_t>(), st, nq, chunk, sc.chunkbin.as<uint32_t>());
+      }
       if (P.compact)
         hipLaunchKernelGGL((group_scatter2d_kernel<T, true>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
                            (const uint32_t*)sc.idx.as<uint32_t>(),
@@ -2197,13 +2425,6 @@ struct Interp2DImpl final : Interp2DBase {
                            (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
                            slice, (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(),
                            nb, sx, sy, nty, sc.perm.as<uint4>(), sc.recq.as<T>());
-      {   // the tile each evaluation chunk starts in
-        const uint32_t chunk = tile_chunk();
-        const uint64_t nchunks = (nq + chunk - 1) / chunk;
-        sc.chunkbin.reserve(nchunks * sizeof(uint32_t));
-        hipLaunchKernelGGL(tile_chunk_bins_kernel, dim3((unsigned)((nchunks + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
-                           (const uint32_t*)sc.cursor.as<uint32_t>(), nb, nq, chunk, sc.chunkbin.as<uint32_t>());
-      }
       NDI_HIP(hipGetLastError());
       ps.done();
     }
@@ -2264,6 +2485,37 @@ struct Interp2DImpl final : Interp2DBase {
       if (shm > both)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
         gs = (unsigned)std::min<uint64_t>(g, (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / shm)));
       launch1<T>(s, PC_EVAL, dim3(gs), dim3(BLOCK), shm, eval_small2d_kernel<T>, S);
+      return;
+    }
+    if (P.kind == Plan2::LANES2) {
+      EvalLanes2Args<T> F{};
+      F.px = px.view; F.py = py.view;
+      F.bx = P.f_lut ? px.bidx : BucketIndex<T>{nullptr, 0, T(0)};
+      F.by = P.f_lut ? py.bidx : BucketIndex<T>{nullptr, 0, T(0)};
+      F.data = data.as<T>();
+      F.qx = P.qx; F.qy = P.qy;
+      F.out = P.out;
+      F.nq = nq;
+      F.out_stride = P.out_stride;
+      F.lanes = (uint32_t)lanes;
+      F.mode = mode;
+      F.first_fail = &st->first_fail[0];
+      if (std::getenv("NDI_TRACE_PLAN"))
+        std::fprintf(stderr, "[ndi plan] lanes2d L=%llu qpl=%d lut=%d tb=%u grid=%u lds=%zu\n", (unsigned long long)lanes,
+                     P.l_qpl, (int)P.f_lut, P.f_tb, P.f_grid, P.f_lds);
+      constexpr int VNl = Wide<T>::N;
+#define NDI_L2(QPL, TB)                                                                   \
+  do {                                                                                    \
+    auto kern = eval_lanes2d_kernel<T, QPL, TB>;                                          \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);         \
+    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(TB), P.f_lds, kern, F);                   \
+  } while (0)
+      if (P.l_qpl == VNl) {
+        if (P.f_tb == 1024) NDI_L2(VNl, 1024); else if (P.f_tb == 512) NDI_L2(VNl, 512); else NDI_L2(VNl, 256);
+      } else {
+        if (P.f_tb == 1024) NDI_L2(1, 1024); else if (P.f_tb == 512) NDI_L2(1, 512); else NDI_L2(1, 256);
+      }
+#undef NDI_L2
       return;
     }
     if (P.kind == Plan2::FUSED2) {
@@ -2329,8 +2581,21 @@ struct Interp2DImpl final : Interp2DBase {
       A.nb = P.nb; A.ts = P.ts; A.nty = P.nty;
       A.chunk = tile_chunk();
       A.chunk_bin = sc.chunkbin.as<uint32_t>();
+      const size_t s1 = ((size_t)1 << P.ts) + 1;
+      // Channel split: two 512-thread workgroups per CU, each staging one half of the trailing axis of its tile (values +
+      // x slopes), when two such half-tiles fit the CU's LDS beside 256 records each and a half-row still fills whole
+      // 16-byte vectors.  NDI_TILE_SPLIT=0 keeps one 1024-thread workgroup per CU (A/B).
+      static const int split_env = [] { const char* e = std::getenv("NDI_TILE_SPLIT"); return e ? std::atoi(e) : -1; }();
+      static const int slope_env0 = [] { const char* e = std::getenv("NDI_TILE_SLOPES"); return e ? std::atoi(e) : 1; }();
+      const uint64_t lv_full = lanes / Wide<T>::N;
+      const size_t shm_half = (s1 * s1 + (s1 - 1) * s1) * (lanes / 2) * sizeof(T) + 5 * s1 * sizeof(T) + 16;
+      const size_t static512s = 256 * 16 + (P.compact ? 2 : 2 * 256) * sizeof(T) + 320;
+      const bool split2 = split_env != 0 && slope_env0 != 0 && lv_full >= 2 && lv_full % 2 == 0 &&
+                          s1 * s1 * (lv_full / 2) <= 5 * 512 && 512 % (lv_full / 2) == 0 &&
+                          2 * (shm_half + static512s) <= 160 * 1024;
+      A.ch_split = split2 ? 2u : 1u;
       {   // item -> (grid row, vector) of the tile staging: ceil(2^32 / vectors per tile row), full and last-column tiles
-        const uint64_t lvv = lanes / Wide<T>::N;
+        const uint64_t lvv = lv_full / A.ch_split;
         const uint64_t full = (((uint64_t)1 << P.ts) + 1) * lvv;
         const uint64_t edge = (ny - ((uint64_t)(P.nty - 1) << P.ts)) * lvv;
         A.rvm_full = (uint32_t)((((uint64_t)1 << 32) + full - 1) / full);
@@ -2340,11 +2605,11 @@ struct Interp2DImpl final : Interp2DBase {
 #ifdef NDI_TUNING
       A.debug = ShortKnobs::env("NDI_FUSED_DEBUG", 0);
 #endif
-      const size_t s1 = ((size_t)1 << P.ts) + 1;
       const size_t shm = s1 * s1 * lanes * sizeof(T) + 5 * s1 * sizeof(T) + 16;
       const uint64_t nchunks = (nq + A.chunk - 1) / A.chunk;
       const uint64_t resident = (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (shm + 64)));
-      const unsigned gx = (unsigned)((std::max<uint64_t>(1, std::min<uint64_t>(nchunks, resident * 4)) + 7) / 8 * 8);
+      const unsigned gmul = 8u * A.ch_split;   // XCD-aware chunk order; the halves of a chunk are neighbours on one XCD
+      const unsigned gx = (unsigned)((std::max<uint64_t>(1, std::min<uint64_t>(nchunks * A.ch_split, resident * 4 * A.ch_split)) + gmul - 1) / gmul * gmul);
       // One 1024-thread workgroup per CU.  NDI_TILE_WG=512 (A/B only): two 512-thread workgroups per CU when two tiles
       // (+ 256 records each) fit the 160 KiB and the tile fits the 10 x 512-vector register double buffer -- measured
       // slower at C3 (1.54 vs 1.17 ms: twice the tile staging per CU, half the rows per trip).
@@ -2367,6 +2632,22 @@ struct Interp2DImpl final : Interp2DBase {
     allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024 - RB * (16 + 2 * sizeof(T)) - 512)); \
     launch1<T>(s, PC_EVAL, dim3(gx), dim3(TTB), (SL) ? shm_slope : shm, kern, A);                             \
   } while (0)
+      if (std::getenv("NDI_TRACE_PLAN"))
+        std::fprintf(stderr, "[ndi plan] tiles ts=%u split=%u compact=%d grid=%u\n", P.ts, A.ch_split, (int)P.compact, gx);
+      if (split2) {
+        if constexpr (std::is_same<T, float>::value) {
+          if (P.compact) {
+            auto kern = eval_bilinear_tiles_kernel<T, VNt, 512, 256, 5, true, true>;
+            allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(80 * 1024 - 256 * (16 + 2 * sizeof(T)) - 512));
+            launch1<T>(s, PC_EVAL, dim3(gx), dim3(512), shm_half, kern, A);
+            return;
+          }
+        }
+        auto kern = eval_bilinear_tiles_kernel<T, VNt, 512, 256, 5, false, true>;
+        allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(80 * 1024 - 256 * (16 + 2 * sizeof(T)) - 512));
+        launch1<T>(s, PC_EVAL, dim3(gx), dim3(512), shm_half, kern, A);
+        return;
+      }
       if constexpr (std::is_same<T, float>::value) {
         if (P.compact) {
           if (slopes_rb1024) NDI_TILES(1024, 1024, 6, true, true);
@@ -2859,8 +3140,11 @@ static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
   h->py.upload(y.data(), d.ny);
   const size_t bytes = (size_t)d.nx * d.ny * d.lanes * sizeof(T);
   const hipMemcpyKind kind = d.memspace == NDI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  // Short trailing axes (<= 64 B per grid point): keep the pair-packed layout instead of the plain one.
-  h->pair_packed = d.lanes * sizeof(T) <= 64 && d.ny >= 2;
+  // Short trailing axes (<= 64 B per grid point): keep the pair-packed layout instead of the plain one -- unless the
+  // whole grid fits a CU's LDS (the reference's 100 x 100 bench grids): those stay plain, the layout eval_lanes2d_kernel
+  // stages, and never leave L2 for the other kernels.  NDI_PAIR_PACK=1 packs every eligible grid (tests), 0 none.
+  static const int pack_env = [] { const char* e = std::getenv("NDI_PAIR_PACK"); return e ? std::atoi(e) : -1; }();
+  h->pair_packed = d.lanes * sizeof(T) <= 64 && d.ny >= 2 && (pack_env > 0 || (pack_env < 0 && bytes > FUSED_LDS_LIMIT));
   if (h->pair_packed) {
     const size_t packed = (size_t)d.nx * (d.ny - 1) * 2 * d.lanes * sizeof(T);
     h->data.reserve(packed);
@@ -3061,13 +3345,24 @@ class ShardWorkers {
       if (w->th.joinable()) w->th.join();
     }
   }
+  // A worker enters the pool only once its thread runs: if std::thread throws (the case run_shards drops shards for),
+  // the thread-less Worker is taken out again, so a later call never start()s a job nobody will run.
+  // NDI_TEST_FAIL_WORKER_START=k (tests only, read per call): the k-th and later workers of a pool fail to start.
   void ensure(size_t n) {
     while (w_.size() < n) {
       w_.emplace_back(new Worker());
       Worker* w = w_.back().get();
-      w->th = std::thread(loop, w);
+      try {
+        if (const char* e = std::getenv("NDI_TEST_FAIL_WORKER_START"))
+          if (*e && w_.size() >= (size_t)std::max(1, std::atoi(e))) throw std::runtime_error("injected: worker thread start");
+        w->th = std::thread(loop, w);
+      } catch (...) {
+        w_.pop_back();
+        throw;
+      }
     }
   }
+  size_t size() const { return w_.size(); }
   void start(size_t i, std::function<void()> f) {
     Worker* w = w_[i].get();
     {

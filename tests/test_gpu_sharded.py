@@ -5,6 +5,7 @@ benches/bench_interp1d.rs:49-79.  Two (three) handles on device 0 exercise the t
 and the cross-shard first-error minimum on a 1-GPU box; with >= 2 devices the same tests also place one handle per
 device."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -491,3 +492,40 @@ def test_one_process_drives_every_device_sharded(pkg):
     with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
         pkg.sharding.interp_array_sharded(reps, q)
     assert ei.value.index == Q - 5
+
+
+def test_worker_start_failure_leaves_the_pool_consistent(pkg, monkeypatch):
+    """A shard whose host thread cannot be started is dropped from the call (DeviceError, the barrier stays consistent)
+    and -- ADVICE r4 -- leaves no thread-less worker behind: the same calling thread fails the same way a second time
+    instead of hanging on a job nobody runs, and succeeds once threads can be started again.  The pool is per calling
+    thread, so the whole scenario runs on a fresh one."""
+    rng = np.random.default_rng(79)
+    x = knots("rand", 64, rng, np.float64); y = rng.uniform(0, 1, (64, 256))
+    st, a, b = oracle.cubic_build(x, y)
+    reps = _replicas(pkg, x, y, _devices(pkg, 3))
+    q = rng.uniform(x[0], x[-1], 6001)
+    ref = oracle.interp1d_cubic(x, y, a, b, q)[2]
+    result = {}
+
+    def scenario():
+        try:
+            os.environ["NDI_TEST_FAIL_WORKER_START"] = "2"     # worker 1 starts, worker 2 (shard 2) cannot
+            for attempt in range(2):
+                out = np.full_like(ref, -1.0)
+                try:
+                    pkg.sharding.interp_array_sharded(reps, q, out=out)
+                    result[attempt] = "no error"
+                except pkg.DeviceError as e:
+                    result[attempt] = str(e)
+            del os.environ["NDI_TEST_FAIL_WORKER_START"]
+            out = np.full_like(ref, -1.0)
+            pkg.sharding.interp_array_sharded(reps, q, out=out)
+            result["after"] = bool(np.array_equal(out, ref))
+        finally:
+            os.environ.pop("NDI_TEST_FAIL_WORKER_START", None)
+    t = threading.Thread(target=scenario)
+    t.start()
+    t.join(timeout=120)
+    assert not t.is_alive(), "a sharded call hung on a worker without a thread"
+    assert "could not start the shard's host thread" in result[0] and "could not start" in result[1], result
+    assert result["after"] is True

@@ -40,7 +40,9 @@ print("variants-ok")
 """
 
 VARIANTS = [
-    {},                                   # what ships (the control of this harness)
+    {},                                   # what ships (the control of this harness): two half-row workgroups per CU
+    {"NDI_TILE_SPLIT": "0"},              # one 1024-thread workgroup per CU staging whole rows (round 4's launch)
+    {"NDI_TILE_SPLIT": "0", "NDI_GROUP_BLOCKS": "32"},
     {"NDI_TILE_SLOPES": "0"},
     {"NDI_TILE_WG": "512", "NDI_TILE_SLOPES": "0"},
     {"NDI_TILE_TS": "2"},

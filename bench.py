@@ -10,8 +10,9 @@ the library's device-output ring (ndi_interp1d_eval_ring): 4 chunks of 2.5e6 *di
 grouped and evaluated into one of 2 ring slots of 81.9 GB (one allocation, slots interleaved row by row); nothing is
 copied to the host.  Tables, queries and
 the ring are resident in HBM when the timed region starts.  N>1: every rank runs the same per-GPU batch on its
-own device (weak scaling; `--queries 12500000` is C4's per-GPU share), tables replicated, no collective on the
-data path.
+own device (weak scaling), tables replicated, no collective on the data path; with N > 1 the per-GPU batch defaults to
+C4's share (BASELINE configs[3]: 1.25e7 queries per GPU, 5 chunks) and every rank also runs C5's per-GPU share
+(configs[4]) after the timed region -- the line carries both with per-rank clocks.
 
     python bench.py                                  # N=1, Target
     python bench.py --gpus 8 --steps 20 --warmup 5   # spawns 8 ranks itself (RCCL barrier / max-reduce only)
@@ -283,7 +284,7 @@ def extra_workload(args, pkg, torch, dev, rank, world):
                       "stages_ms_per_step": {k: round(prof[k + "_ms"] / args.steps, 4) for k in ("locate", "group", "eval")}}))
 
 
-def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
+def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False, rank=0):
     """One secondary 2-D leg: random-knot axes, uniform in-range queries, device-resident output; HIP-event kernel
     time from the library's profile, wall-clock end to end (search [+ grouping] + evaluation).  Measured with the
     formulation AUTO picks and, when that is the tile-grouped order, with the gather order as well (the gather
@@ -295,8 +296,9 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
     interp = pkg.Interp2DBuilder.new(g).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
     del g
     torch.cuda.empty_cache()
-    qx = torch.as_tensor(np.random.default_rng(123).uniform(x[0], x[-1], nq).astype(np.float32), device=dev)
-    qy = torch.as_tensor(np.random.default_rng(96).uniform(y[0], y[-1], nq).astype(np.float32), device=dev)
+    sx, sy = (123, 96) if rank == 0 else ([123, rank], [96, rank])   # (every rank its own block of the scattered queries)
+    qx = torch.as_tensor(np.random.default_rng(sx).uniform(x[0], x[-1], nq).astype(np.float32), device=dev)
+    qy = torch.as_tensor(np.random.default_rng(sy).uniform(y[0], y[-1], nq).astype(np.float32), device=dev)
     out = torch.empty((nq, C), dtype=torch.float32, device=dev)
     step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
     alg = nq * C * 20 + nq * 8                                   # 5 x 4 B per point + the query pair
@@ -392,10 +394,12 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False):
     res.update(measure(pkg.PATH_AUTO))
     if res["path"] != "gather":
         res["gather_order"] = measure(pkg.PATH_GATHER)
-    if probe:      # the same access mix without searches / knots / arithmetic: the memory system's ceiling on this box
-        pms = interp.strategy.probe_ceiling(out, reps=7)
-        res["access_mix_ceiling_ms"] = round(pms, 4)
-        res["frac_of_measured_ceiling"] = round(pms / res["kernel_ms"], 4)
+    if probe:      # context only (round 5): a stripped-down kernel with the same four-corner access mix -- random cells, no
+        # searches, token arithmetic.  It is NOT an upper bound (its lane mapping and in-flight depth are not tuned, and the
+        # product kernel has beaten it): no ratio is derived from it.  The guide's figure for this kind of access
+        # (MI355X_MICROARCH.md, random rows fetched once from a table far beyond the Infinity Cache) is 5.5-5.8 TB/s.
+        res["access_mix_probe_ms"] = round(interp.strategy.probe_ceiling(out, reps=7), 4)
+        res["access_mix_probe_note"] = "context, not a ceiling; guide: random rows fetched once 5.5-5.8 TB/s"
     interp.strategy.release()
     del interp, qx, qy, out
     torch.cuda.empty_cache()
@@ -474,6 +478,118 @@ def short_rows_leg(pkg, torch, dev, out_bytes=4e9, steps=5):
     return res
 
 
+def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
+    """BASELINE configs[1]'s shape (4096 knots x 4096 lanes, 1e6 queries, one resident output buffer) for the two long-row
+    kernels the headline does not time: 1-D Linear f64 (linear.rs:73-98; SURVEY 8(d): 24 B per point) and CubicSpline
+    f32.  AUTO takes the bucketed formulation (Q >= 5 (n - 1)): compulsory bytes = output + tables + records once;
+    the SURVEY 8(d) gather-model ratio is printed next to it, never as `frac`.  PMC traffic: the stored figure of the
+    same launch from profiles/traffic.json (tools/profile_r05.sh), labelled."""
+    res = {}
+    n = lanes = 4096
+    nq = 1_000_000
+    for key, dt, tdt, strat_name in (("c2_linear", np.float64, torch.float64, "linear"), ("c2_f32", np.float32, torch.float32, "cubic")):
+        x, yv, q = synth_c2(n, lanes, nq, 0)
+        x = np.unique(x.astype(dt)); yv = yv[:x.size].astype(dt)
+        q = np.clip(q.astype(dt), x[0], x[-1])
+        el = np.dtype(dt).itemsize
+        b = pkg.Interp1DBuilder.new(torch.as_tensor(yv, device=dev)).x(torch.as_tensor(x, device=dev))
+        interp = (b.strategy(pkg.CubicSpline.new()) if strat_name == "cubic" else b).build()
+        qd = torch.as_tensor(q, device=dev)
+        out = torch.empty((nq, lanes), dtype=tdt, device=dev)
+        step = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
+        step(); interp.strategy.finish()
+        pkg.profile_enable(True); pkg.profile_read(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps
+        interp.strategy.finish()
+        prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
+        kms = prof["eval_ms"] / max(1, prof["eval_launches"])
+        ntab = x.size + (2 * (x.size - 1) if strat_name == "cubic" else 0)
+        comp = nq * lanes * el + ntab * lanes * el + nq * 16
+        model = nq * lanes * (5 if strat_name == "cubic" else 3) * el + nq * el
+        bucketed = prof["last_path"] == "bucketed"
+        stored = (traffic_store or {}).get(f"{key}_bytes_per_launch")
+        res[key] = {"workload": f"1D {'CubicSpline' if strat_name == 'cubic' else 'Linear'}, {x.size} knots x {lanes} lanes "
+                                f"{np.dtype(dt).name}, {nq} queries, one resident output buffer ({nq * lanes * el / 1e9:.1f} GB)",
+                    "path": prof["last_path"], "kernel": "eval_bucketed_kernel" if bucketed else "eval_rows_kernel",
+                    "kernel_ms": round(kms, 4), "ms_per_step": round(wall * 1e3, 4),
+                    "Mpoints_s": round(nq * lanes / wall / 1e6, 1),
+                    "compulsory_bytes_per_launch": int(comp), "frac": round(comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "bytes_basis": "compulsory bytes per launch (output + tables + query records, once)",
+                    "survey_8d_model_bytes": int(model),
+                    "gather_model_ratio": round(model / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "traffic": stored, "traffic_source": "stored (profiles/traffic.json, rocprofv3 --pmc of this launch)" if stored else None,
+                    "traffic_frac": round(stored / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if stored else None,
+                    "stages_ms_per_step": {k: round(prof[k + "_ms"] / steps, 4) for k in ("locate", "group", "eval")}}
+        interp.strategy.release()
+        del interp, qd, out
+        torch.cuda.empty_cache()
+    return res
+
+
+def reference_shapes_2d_leg(pkg, torch, dev, steps=5):
+    """The reference's 2-D bench shapes (benches/bench_interp2d.rs:12-18, 87-92: a 100 x 100 scalar grid and a
+    100 x 100 x 5 grid) scaled to 5e7 / 2e7 queries on device buffers, f64 and f32: wall time of a whole
+    interp_array_into call, Gqueries/s, and the query-in / row-out stream as a fraction of the HBM peak."""
+    rng = np.random.default_rng(0)
+    rows = []
+    for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        el = np.dtype(dt).itemsize
+        for nx, ny, C, Q in ((100, 100, 1, 50_000_000), (100, 100, 5, 20_000_000)):
+            x = np.cumsum(rng.uniform(0.5, 1.5, nx)).astype(dt); y = np.cumsum(rng.uniform(0.5, 1.5, ny)).astype(dt)
+            grid = torch.rand((nx, ny, C), dtype=tdt, device=dev)
+            it = pkg.Interp2DBuilder.new(grid).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
+            qx = torch.rand(Q, dtype=tdt, device=dev) * float(x[-1] - x[0]) * 0.999 + float(x[0])
+            qy = torch.rand(Q, dtype=tdt, device=dev) * float(y[-1] - y[0]) * 0.999 + float(y[0])
+            out = torch.empty((Q, C), dtype=tdt, device=dev)
+            call = lambda: it.strategy.interp_array_into(it, qx, qy, out, async_launch=True)
+            call(); it.strategy.finish()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                call()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / steps
+            it.strategy.finish()
+            io = Q * (C + 2) * el
+            rows.append({"dtype": np.dtype(dt).name, "grid": [nx, ny, C], "queries": Q, "ms": round(wall * 1e3, 4),
+                         "Gqueries_s": round(Q / wall / 1e9, 1), "io_TBps": round(io / wall / 1e12, 3),
+                         "io_frac_of_peak": round(io / wall / 1e9 / HBM_PEAK_GBS, 4)})
+            it.strategy.release()
+            del it, qx, qy, out, grid
+        torch.cuda.empty_cache()
+    return rows
+
+
+def host_path_leg(pkg, torch, dev, nq=100_000, reps=3):
+    """The literal drop-in: host ndarrays in, host ndarray out (what a caller of the unpatched reference hands over), on
+    BASELINE configs[1]'s tables -- 4096 knots x 4096 f64 lanes -- with 1e5 queries (3.3 GB of output per call; the
+    full 1e6 queries would be 32.8 GB of pageable host memory per call).  The library streams the rows through a
+    device staging buffer; the rate is the PCIe link's, not the kernel's -- reported here so that a reader of the
+    bench line sees it, never part of `value`."""
+    n = lanes = 4096
+    x, yv, q = synth_c2(n, lanes, nq, 0)
+    interp = pkg.Interp1DBuilder.new(torch.as_tensor(yv, device=dev)).x(torch.as_tensor(x, device=dev)) \
+        .strategy(pkg.CubicSpline.new()).build()
+    out = np.empty((nq, lanes))
+    out[:] = 0.0                                     # touch the pages once, outside the timing
+    interp.interp_array_into(q, out)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        interp.interp_array_into(q, out)
+    wall = (time.perf_counter() - t0) / reps
+    interp.strategy.release()
+    return {"workload": f"1D CubicSpline, {n} knots x {lanes} lanes f64, {nq} queries, host arrays in, host array out "
+                        f"({nq * lanes * 8 / 1e9:.2f} GB of output per call, pageable memory)",
+            "ms_per_call": round(wall * 1e3, 2), "output_GBps": round(nq * lanes * 8 / wall / 1e9, 1),
+            "Mpoints_s": round(nq * lanes / wall / 1e6, 1),
+            "bound": "PCIe (device -> host copy of every row); the HBM-resident rate is the headline's"}
+
+
 def in_process_sharded_leg(args, pkg, torch, x, y, steps=3, budget_s=90.0):
     """When this ONE process sees several devices (the N = 1 run on a multi-GPU node): the Target batch per device
     through ndi_interp1d_eval_ring_sharded -- replicas by device-to-device copy, one library call per step, one host
@@ -545,9 +661,16 @@ def secondary_legs(pkg, torch, dev):
     import ctypes
     sys.path.insert(0, ROOT)
     import oracle
+    try:
+        traffic_store = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        traffic_store = None
     sec = {"c3": bilinear_leg(pkg, torch, dev, 2048, 64, 10_000_000),
            "c5_share": bilinear_leg(pkg, torch, dev, 8192, 16, 12_500_000, probe=True),
            "short_rows": short_rows_leg(pkg, torch, dev)}
+    sec.update(long_rows_leg(pkg, torch, dev, traffic_store))
+    sec["reference_shapes_2d"] = reference_shapes_2d_leg(pkg, torch, dev)
+    sec["host_path"] = host_path_leg(pkg, torch, dev)
     n, nq = 1024, 10_000
     rng = np.random.default_rng(42)
     yv = rng.uniform(0, 1, n); q = np.random.default_rng(123).uniform(0, n - 1, nq)
@@ -644,6 +767,19 @@ def check_rows_against_oracle(x, y, q_rows, got_rows):
     return {"rows": int(got_rows.shape[0]), "bit_exact": bool(np.array_equal(ref, got_rows)), "max_abs_err": err}
 
 
+def workload_name(n, lanes, nq, world):
+    """N = 1: the north-star Target (BASELINE configs[1]'s tables, 1e7 queries).  N > 1: BASELINE configs[3] -- C4, 1e8
+    queries sharded over 8 GPUs -- as its per-GPU share of 1.25e7 queries on every rank (weak scaling: at N = 8 the job is
+    C4 itself).  Other sizes (rehearsals, sweeps) say so."""
+    if (n, lanes) == (4096, 4096) and world > 1 and nq == 12_500_000:
+        return f"C4 (BASELINE configs[3]) per-GPU share x {world}" + (" = C4" if world == 8 else "")
+    if (n, lanes) == (4096, 4096) and nq == 10_000_000:
+        return "Target"
+    if world > 1:
+        return "C4-shaped rehearsal (sizes overridden)"
+    return "Target-shaped (sizes overridden)"
+
+
 def run_target(args, pkg, torch, dist, dev, rank, world):
     n, lanes, nq, chunk = args.knots, args.lanes, args.queries, args.chunk
     x, y, _ = synth_c2(n, lanes, 1, rank)
@@ -715,6 +851,28 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
     elapsed = float(t.item())
     points_per_step = nq * lanes
     value = world * points_per_step * args.steps / elapsed / 1e6
+
+    # N > 1 (or --c5-leg): BASELINE configs[4]'s per-GPU share on EVERY rank at the same time, after the timed region --
+    # 8192 x 8192 x 16 f32 grid replicated per device, this rank's 1.25e7 of the 1e8 scattered queries, no collective on
+    # the data path; per-rank clocks gathered like the headline's
+    c5 = None
+    if world > 1 or args.c5_leg:
+        fence()
+        mine = bilinear_leg(pkg, torch, dev, args.c5_leg_grid, 16, args.c5_leg_queries, steps=10, warmup=2, rank=rank)
+        fence()
+        per = [mine]
+        if use_dist:
+            per = [None] * world
+            dist.all_gather_object(per, mine)
+        if rank == 0:
+            slow = max(p["ms_per_step"] for p in per)
+            c5 = {"workload": f"C5 (BASELINE configs[4]) per-GPU share: 2D Bilinear, {args.c5_leg_grid}x{args.c5_leg_grid} grid x 16 "
+                              f"channels f32 replicated per device, {args.c5_leg_queries} scattered queries per GPU "
+                              f"({world} x {args.c5_leg_queries} in all), every rank at the same time",
+                  "per_rank_ms": [p["ms_per_step"] for p in per], "per_rank_kernel_ms": [p["kernel_ms"] for p in per],
+                  "kernel": per[0]["kernel"], "path": per[0]["path"],
+                  "ms_per_step": slow, "Mpoints_s": round(world * args.c5_leg_queries * 16 / (slow * 1e-3) / 1e6, 1),
+                  "frac_rank0": per[0].get("frac"), "scaling": "weak", "timed_through": per[0]["timed_through"]}
     if rank != 0:
         return
 
@@ -745,7 +903,8 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         "ms_per_step_median": round(float(np.median(step_s)) * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"Target: 1D CubicSpline NotAKnot, {n} knots x {lanes} lanes f64, {nq} queries per GPU "
+        "config": {"workload": workload_name(n, lanes, nq, world) +
+                               f": 1D CubicSpline NotAKnot, {n} knots x {lanes} lanes f64, {nq} queries per GPU "
                                f"in {nchunks} distinct chunks of {chunk} through a {args.ring_slots}-slot device-output "
                                "ring (sorted-unique uniform knots, unsorted uniform in-range queries; output "
                                f"{nq * lanes * 8 / 1e9:.1f} GB per step, never copied to the host)",
@@ -777,6 +936,8 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
     }
     if ranks is not None:
         line["ranks"] = ranks
+    if c5 is not None:
+        line["c5_share"] = c5
 
     # sanity: sampled rows of every chunk against the CPU oracle (one extra pass, rows gathered on the device)
     if not args.no_check:
@@ -810,6 +971,12 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
             "algorithmic_ratio_to_peak": round(alg_bytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "read_only_frac_of_peak": round(pts * 32 / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "Mpoints_s": round(pts / (gms * 1e-3) / 1e6, 1)}
+        # SURVEY 8(d)'s formula applies to the GATHER kernel (4 operand rows in + 1 row out per query): both bases sit in
+        # `roofline` -- `frac` (compulsory bytes, the shipped bucketed kernel) and these two (the gather kernel)
+        line["roofline"]["survey_8d_frac"] = line["gather_formulation"]["algorithmic_ratio_to_peak"]
+        line["roofline"]["survey_8d_read_frac"] = line["gather_formulation"]["read_only_frac_of_peak"]
+        line["roofline"]["survey_8d_kernel"] = "eval_rows_kernel (ndi_path GATHER, the north star's literal formulation): " \
+            "40 B per point / its own launch time / peak; > 1 means part of the 384 MiB table set is served on-die"
         interp.strategy.path = paths[args.path]
 
     # placement sensitivity of the output stream: the same chunk evaluated into every slot of the
@@ -923,6 +1090,9 @@ def main():
     ap.add_argument("--workload", choices=["target", "c2", "c3", "c5", "c2-linear", "c2-f32", "c1"], default="target",
                     help="target = headline (north-star Target; BASELINE configs[1] tables, 1e7 queries through the "
                          "ring); the others are secondary measurements for DESIGN.md")
+    ap.add_argument("--c5-leg", action="store_true", help="N = 1: run the per-rank C5-share leg of the N > 1 line as well")
+    ap.add_argument("--c5-leg-grid", type=int, default=8192, help="rehearsals: grid points per axis of the per-rank C5 leg")
+    ap.add_argument("--c5-leg-queries", type=int, default=12_500_000, help="rehearsals: queries per rank of the C5 leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this GPU")
     ap.add_argument("--force-dist", action="store_true",
@@ -933,8 +1103,8 @@ def main():
                     help="no GPU work: only the launch / rendezvous / barrier / max-over-ranks skeleton (gloo), used by "
                          "the CPU tests to cover the N>1 self-launch")
     args = ap.parse_args()
-    if args.queries is None:
-        args.queries = 10_000_000 if args.workload == "target" else 1_000_000
+    if args.queries is None:   # N = 1: the Target; N > 1: C4's per-GPU share (BASELINE configs[3]: 1e8 queries over 8 GPUs)
+        args.queries = (12_500_000 if args.gpus > 1 else 10_000_000) if args.workload == "target" else 1_000_000
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))          # nothing in this process has touched the GPU
@@ -962,7 +1132,8 @@ def main():
                                  {"rank": rank, "ordinal": local_rank, "uuid": f"rehearsal-{rank}", "name": "none"}, "cpu")
         if rank == 0:
             print(json.dumps({"rehearsal": True, "n_gpus": world, "max_over_ranks": float(t.item()),
-                              "local_rank": local_rank, "ranks": ranks}), flush=True)
+                              "local_rank": local_rank, "ranks": ranks, "queries_per_gpu": args.queries,
+                              "workload": workload_name(args.knots, args.lanes, args.queries, world)}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define NDI_VERSION_MAJOR 0
-#define NDI_VERSION_MINOR 3
+#define NDI_VERSION_MINOR 4
 
 /* BuilderError / InterpolateError (src/lib.rs:127-146) + ABI-only codes. */
 typedef enum ndi_status {
@@ -88,6 +88,22 @@ typedef enum ndi_monotonic {
  *           the grouping pass, else GATHER. */
 typedef enum ndi_path { NDI_PATH_AUTO = 0, NDI_PATH_GATHER = 1, NDI_PATH_BUCKETED = 2 } ndi_path;
 
+/* CubicSpline::build (cubic_spline.rs:310-368, 409-721) -- numerical contract of the coefficient tables.
+ * The serial per-lane kernels evaluate thomas (:678-721) in the reference's operation order without contraction: the
+ * a / b tables are BIT-IDENTICAL to the reference's.  For narrow trailing axes on many knots (n >= 2048 and
+ * lanes <= 256: scalar data on 1e5-1e6 knots, 8 lanes on 4096) that would be one or two wavefronts doing 2n dependent
+ * steps, so by default such builds take blocked sweeps: both first-order recurrences are cut into blocks and
+ * re-associated (back substitution as r'/mid' + (-up/mid') k).  Every coefficient then agrees with the reference's to
+ * within 1e-12 (f64) / 1e-5 (f32) of the larger of: the magnitudes of the table entries within 32 rows of it, and the
+ * interval's |dy| -- errors do not travel (the recurrences' multipliers are <= 1/2 in magnitude) -- and evaluated
+ * rows meet the crate's own assertion form at 1e-10 / 1e-5 (tests/test_gpu_spline_blocked.py, incl. geometric and
+ * clustered knots).  NDI_BUILD_REFERENCE_ORDER keeps the serial kernels for the handle: bit-identical tables at the
+ * serial kernels' speed. */
+typedef enum ndi_build_flags {
+  NDI_BUILD_DEFAULT = 0,
+  NDI_BUILD_REFERENCE_ORDER = 1 /* never re-associate the Thomas sweeps: tables bit-identical to the reference's */
+} ndi_build_flags;
+
 /* Replaces Interp1DBuilder::{new,x,strategy,build} (src/interp1d/mod.rs:399-476)
  * + Interp1DStrategyBuilder::build (src/interp1d/strategies/mod.rs:12-40):
  * Linear::build (linear.rs:54-63) / CubicSpline::build (cubic_spline.rs:754-771). */
@@ -105,6 +121,7 @@ typedef struct ndi_interp1d_desc {
   int32_t validate;    /* != 0: run Interp1DBuilder::build's checks (:449-471) here */
   /* CubicSpline boundary (BoundaryCondition, cubic_spline.rs:153-168) */
   int32_t periodic;    /* BoundaryCondition::Periodic */
+  int32_t build_flags; /* ndi_build_flags (0 = default); occupies what was alignment padding in v0.3: same layout */
   ndi_boundary left;   /* applied to every lane unless lane_* are given */
   ndi_boundary right;
   /* BoundaryCondition::Individual (per trailing element, cubic_spline.rs:332-347):

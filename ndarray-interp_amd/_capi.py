@@ -23,6 +23,7 @@ F32, F64 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 LINEAR, CUBIC_SPLINE = 0, 1
 BC_NOT_A_KNOT, BC_NATURAL, BC_CLAMPED, BC_FIRST_DERIV, BC_SECOND_DERIV = range(5)
+BUILD_DEFAULT, BUILD_REFERENCE_ORDER = 0, 1
 PATH_AUTO, PATH_GATHER, PATH_BUCKETED = 0, 1, 2
 PATH_NAMES = {0: "auto", 1: "gather", 2: "bucketed"}
 
@@ -36,7 +37,7 @@ class Interp1DDesc(C.Structure):
         ("dtype", C.c_int32), ("strategy", C.c_int32), ("extrapolate", C.c_int32), ("device", C.c_int32),
         ("n", C.c_uint64), ("lanes", C.c_uint64), ("x_len", C.c_uint64),
         ("x", C.c_void_p), ("data", C.c_void_p), ("memspace", C.c_int32), ("validate", C.c_int32),
-        ("periodic", C.c_int32), ("left", Boundary), ("right", Boundary),
+        ("periodic", C.c_int32), ("build_flags", C.c_int32), ("left", Boundary), ("right", Boundary),
         ("lane_left_kind", C.c_void_p), ("lane_left_value", C.c_void_p),
         ("lane_right_kind", C.c_void_p), ("lane_right_value", C.c_void_p),
     ]

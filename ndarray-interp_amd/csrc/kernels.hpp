@@ -1277,26 +1277,40 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
 // large Q (scalar data and (100, 5) on 100 knots: benches/bench_interp1d.rs:12-47, 82-122).  Counters of the query-order
 // kernel on those shapes (profiles/r05_small_shapes_counters.txt): 126 VALU wave instructions per 64 scalar queries, 43 %
 // of the LDS cycles bank conflicts, nothing saturated -- the per-query strip round trip, one item per lane and trip,
-// 8-byte loads and stores and an IEEE division per query are overhead when a row is one or a few values.  Here a lane owns
-// its query from the search to the result:
-//  * staging (once per workgroup): the knots (+ bucket index), one record {x_l, dx, RN(1 / dx)} per interval and one
-//    record per (interval, lane of the trailing axes): {y_l, y_r, a, b} (cubic) or {y_l, m} (linear) with
+// 8-byte loads and stores, a search with divergent branches and an IEEE division per query are overhead when a row is one
+// or a few values.  Here a lane owns its query from the search to the result, and everything per query is branch-free:
+//  * search: a DENSE bucket index (DenseLut: so many uniform buckets -- 4n .. 32n -- that no bucket holds more than
+//    `maxk` <= 8 knots, built on the host with the device's arithmetic): count = lut[bucket(x)] + sum over the next
+//    maxk knots of (k <= x) -- knots past the bucket are > x because bucket() is monotone -- i.e. one 16-bit read and
+//    maxk knot reads, no loop with a data-dependent trip count, no cross-lane step.  Axes whose O(1) formula guess is
+//    right for every x (the default index axis, linspace) need no index at all (vector_extensions.rs:68-90);
+//  * staging (once per workgroup): knots, index, one record {x_l, dx, RN(1 / dx)} per interval (cubic) and one record
+//    per (interval, lane of the trailing axes): {y_l, y_r, a, b} (cubic) or {y_l, m} (linear) with
 //    m = (y_r - y_l) / (x_r - x_l) -- Linear::calc_frac's division (linear.rs:33) has no query in it, so it is done
 //    once per record with the IEEE division: the same operands, the same bits;
 //  * t = (x - x_l) / dx (cubic_spline.rs:818) by the correctly rounded shared-divisor division (div_shared: the bits of
 //    the IEEE division; the reciprocal comes from the interval's record);
-//  * scalar data (L == 1): QPL consecutive queries per lane, one 16-byte query load and one 16-byte store per lane;
-//  * 2 <= L: the wave's 64 rows are written to a wave-private LDS strip and leave as ONE sequential stream of
-//    16-byte vectors (64 * L * sizeof(T) consecutive bytes per batch), whatever L is (5 is not a multiple of anything).
+//  * eval_scalar_kernel (L == 1): QPL consecutive queries per lane, one 16-byte query load and one 16-byte store per
+//    lane, the next vector of queries in flight;
+//  * eval_lanes_kernel (2 <= L, rows of up to 64 bytes): the wave's 64 rows are written to a wave-private LDS strip and
+//    leave as ONE sequential stream of 16-byte vectors (64 * L * sizeof(T) consecutive bytes per batch), whatever L is.
 // Same operations in the same order as Linear / CubicSplineStrategy::interp_into; rows at / after the batch's first
 // failing query (range_check_kernel) are never written.
 template <class T>
 struct XRec { T xl, dx, r, pad; };   // r = RN(1 / dx), 0 when dx is outside the shared-divisor window
 
 template <class T>
+struct DenseLut {
+  const uint16_t* lut;   // m + 1 entries (global memory); nullptr: the axis' O(1) formula guess is exact
+  uint32_t m, maxk;
+  T scale;               // m / (kn - k0), in T
+};
+
+template <class T>
 struct EvalLanesArgs {
-  Pyramid<T> pyr;
-  BucketIndex<T> bx;     // lut == nullptr: pyramid search
+  const T* knots;        // [n]
+  uint32_t n;
+  DenseLut<T> dl;
   const T* data;         // [n][lanes]
   const T* ca;           // [n-1][lanes] (cubic)
   const T* cb;
@@ -1308,47 +1322,80 @@ struct EvalLanesArgs {
   const unsigned long long* first_fail;
 };
 
-template <class T, int STRAT, int QPL, int TB>
-__global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int TR = STRAT == ST_CUBIC ? 4 : 2;      // values per table record
-  constexpr int VN = Wide<T>::N;
-  using V = typename VecT<T, VN>::type;
-  using QV = typename VecT<T, QPL>::type;
-  if (A.nq == 0) return;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t n = A.pyr.n, n1 = A.pyr.n1, L = A.lanes;
-  // LDS: [pyramid | lut | interval records | table records | per-wave strips (L > 1)]
-  size_t off;
-  {
-    T* s0 = reinterpret_cast<T*>(smem_raw);
-    const uint32_t total = n + n1;
-    for (uint32_t i = tid; i < total; i += TB) s0[i] = A.pyr.lv0[i];
-    off = ((size_t)total * sizeof(T) + 15u) & ~(size_t)15u;
+// LDS-resident state of the branch-free search
+template <class T>
+struct LaneAxis {
+  lds_ptr<T> k;
+  lds_u16 lut;           // nullptr: O(1) guess
+  uint32_t n, m, maxk;
+  T k0, kn, scale, gfac; // gfac = (n - 1) / (kn - k0): the guess's factor (vector_extensions.rs:70-90)
+};
+
+// the unique i with k[i] <= x < k[i+1], clamped to [0, n-2]; NaN -> 0
+template <class T>
+__device__ __forceinline__ uint32_t lane_axis_index(const LaneAxis<T>& S, T x) {
+  if (S.lut) {                                            // (workgroup-uniform)
+    T f = (x - S.k0) * S.scale;
+    f = fmax(f, T(0));                                    // below the axis, NaN -> bucket 0
+    f = fmin(f, T(S.m - 1u));
+    const uint32_t lo = S.lut[(uint32_t)f];
+    uint32_t cnt = lo;
+    for (uint32_t j = 0; j < S.maxk; ++j) {               // (uniform trip count)
+      const uint32_t idx = lo + j < S.n - 1u ? lo + j : S.n - 1u;
+      cnt += (S.k[idx] <= x) ? 1u : 0u;
+    }
+    cnt = cnt < S.n ? cnt : S.n;                          // (x >= kn may count the clamped last knot more than once)
+    const uint32_t i = cnt ? cnt - 1u : 0u;
+    return i < S.n - 2u ? i : S.n - 2u;
   }
-  lds_u16 lut = nullptr;
-  if (A.bx.lut) {
-    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
-    const uint32_t words = (A.bx.m + 2u) / 2u;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.bx.lut);
+  const T mm = S.gfac * (x - S.k0) + T(0);                // locate_index's guess, verified exact for every x on the host
+  return (mm >= T(0)) ? (uint32_t)(mm < T(S.n - 2u) ? mm : T(S.n - 2u)) : 0u;
+}
+
+// stages knots + dense index and returns the axis view; `off` advances past them (16-byte aligned)
+template <class T, int TB>
+__device__ __forceinline__ LaneAxis<T> stage_lane_axis(unsigned char* smem, size_t& off, const T* knots, uint32_t n,
+                                                       const DenseLut<T>& dl) {
+  const uint32_t tid = threadIdx.x;
+  T* s0 = reinterpret_cast<T*>(smem + off);
+  for (uint32_t i = tid; i < n; i += TB) s0[i] = knots[i];
+  LaneAxis<T> S;
+  S.k = (lds_ptr<T>)(smem + off);
+  off += ((size_t)n * sizeof(T) + 15u) & ~(size_t)15u;
+  S.lut = nullptr;
+  if (dl.lut) {
+    uint32_t* sl = reinterpret_cast<uint32_t*>(smem + off);
+    const uint32_t words = (dl.m + 2u) / 2u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(dl.lut);
     for (uint32_t i = tid; i < words; i += TB) sl[i] = src[i];
-    lut = (lds_u16)(smem_raw + off);
+    S.lut = (lds_u16)(smem + off);
     off += ((size_t)words * 4u + 15u) & ~(size_t)15u;
   }
-  XRec<T>* s_x = reinterpret_cast<XRec<T>*>(smem_raw + off);
-  off += (size_t)(n - 1u) * sizeof(XRec<T>);
-  T* s_t = reinterpret_cast<T*>(smem_raw + off);
-  off += (((size_t)(n - 1u) * L * TR * sizeof(T)) + 15u) & ~(size_t)15u;
-  T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;   // (touched only when L > 1)
-  for (uint32_t i = tid; i + 1u < n; i += TB) {
-    const T xl = A.pyr.lv0[i], xr = A.pyr.lv0[i + 1];
+  S.n = n; S.m = dl.m; S.maxk = dl.maxk; S.scale = dl.scale;
+  S.k0 = knots[0];
+  S.kn = knots[n - 1];
+  S.gfac = (T(n - 1u) - T(0)) / (S.kn - S.k0);
+  return S;
+}
+
+// interval records {x_l, dx, RN(1 / dx)} of an axis
+template <class T, int TB>
+__device__ __forceinline__ void stage_xrecs(XRec<T>* s_x, const T* knots, uint32_t n) {
+  for (uint32_t i = threadIdx.x; i + 1u < n; i += TB) {
+    const T xl = knots[i], xr = knots[i + 1];
     const SharedDivisor<T> sd = shared_divisor<T>(xr - xl);
     XRec<T> r;
     r.xl = xl; r.dx = sd.d; r.r = sd.ok ? sd.r : T(0); r.pad = T(0);
     s_x[i] = r;
   }
-  for (uint32_t e = tid; e < (n - 1u) * L; e += TB) {
-    const uint32_t i = e / L;
+}
+
+// table records: cubic {y_l, y_r, a, b}, linear {y_l, m}
+template <class T, int STRAT, int TB>
+__device__ __forceinline__ void stage_table_recs(T* s_t, const EvalLanesArgs<T>& A) {
+  constexpr int TR = STRAT == ST_CUBIC ? 4 : 2;
+  const uint32_t L = A.lanes, total = (A.n - 1u) * L;
+  for (uint32_t e = threadIdx.x; e < total; e += TB) {
     const T yl = A.data[e], yr = A.data[e + L];
     if (STRAT == ST_CUBIC) {
       s_t[(size_t)e * TR + 0] = yl;
@@ -1356,113 +1403,145 @@ __global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
       s_t[(size_t)e * TR + 2] = A.ca[e];
       s_t[(size_t)e * TR + 3] = A.cb[e];
     } else {
-      const T dx = A.pyr.lv0[i + 1] - A.pyr.lv0[i];
+      const uint32_t i = e / L;
+      const T dx = A.knots[i + 1] - A.knots[i];
       s_t[(size_t)e * TR + 0] = yl;
-      s_t[(size_t)e * TR + 1] = (yr - yl) / dx;          // linear.rs:33, once per record
+      s_t[(size_t)e * TR + 1] = (yr - yl) / dx;           // linear.rs:33, once per record
     }
   }
+}
+
+// One query: interval, then the per-query scalar -- t (cubic_spline.rs:818) or (x - x1) (linear.rs:35).
+template <class T, int STRAT>
+__device__ __forceinline__ void lane_query(const LaneAxis<T>& S, const XRec<T>* s_x, int mode, T x, uint32_t& i, T& s0) {
+  T xs = x;
+  if (STRAT == ST_CUBIC && mode == EX_PERIODIC) {         // (uniform) cubic_spline.rs:805-809
+    const bool inr = (S.k0 <= x) && (x <= S.kn);
+    if (!inr) xs = rem_euclid_t(x - S.k0, S.kn - S.k0) + S.k0;
+  }
+  i = lane_axis_index<T>(S, xs);
+  i = NDI_CHK(i, S.n - 1u, BC_INTERVAL);
+  if (STRAT == ST_CUBIC) {
+    const XRec<T> xr = s_x[i];
+    SharedDivisor<T> sd;
+    sd.d = xr.dx; sd.r = xr.r; sd.ok = xr.r > T(0);
+    s0 = div_shared<T, T>(xs - xr.xl, sd);
+  } else {
+    s0 = x - S.k[i];
+  }
+}
+
+template <class T, int STRAT>
+__device__ __forceinline__ T lane_point(const T* r, T s0) {
+  if (STRAT == ST_CUBIC) {                                // cubic_spline.rs:825-827
+    const T yl = r[0], yr = r[1], a = r[2], b = r[3];
+    const T c0 = T(1) - s0;
+    return c0 * yl + s0 * yr + (s0 * c0) * (a * c0 + b * s0);
+  } else {                                                // linear.rs:33-35 with the record's m
+    return r[1] * s0 + r[0];
+  }
+}
+
+template <class T, int STRAT, int QPL, int TB>
+__global__ __launch_bounds__(TB) void eval_scalar_kernel(EvalLanesArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int TR = STRAT == ST_CUBIC ? 4 : 2;
+  using QV = typename VecT<T, QPL>::type;
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x, n = A.n;
+  size_t off = 0;
+  const LaneAxis<T> S = stage_lane_axis<T, TB>(smem_raw, off, A.knots, n, A.dl);
+  XRec<T>* s_x = reinterpret_cast<XRec<T>*>(smem_raw + off);
+  if (STRAT == ST_CUBIC) {
+    stage_xrecs<T, TB>(s_x, A.knots, n);
+    off += (size_t)(n - 1u) * sizeof(XRec<T>);
+  }
+  T* s_t = reinterpret_cast<T*>(smem_raw + off);
+  stage_table_recs<T, STRAT, TB>(s_t, A);
   __syncthreads();
-  PyramidLds<T> P;
-  P.lv0 = (lds_ptr<T>)(smem_raw);
-  P.lv1 = P.lv0 + n;
-  P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
-  const T k0 = P.lv0[0], kn = P.lv0[n - 1];
   unsigned long long limit = *A.first_fail;
   if (limit > A.nq) limit = A.nq;
-  // interval + per-query scalars of one query (all 64 lanes call it: the pyramid search is wave-cooperative)
-  auto locate = [&](T x, uint32_t& i, T& s0, T& s1) {
-    const bool inr = (k0 <= x) && (x <= kn);
-    T xs = x;
-    if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;   // cubic_spline.rs:805-809
-    i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs) : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);
-    i = NDI_CHK(i, n - 1u, BC_INTERVAL);
-    const XRec<T> xr = s_x[i];
-    if (STRAT == ST_CUBIC) {
-      SharedDivisor<T> sd;
-      sd.d = xr.dx; sd.r = xr.r; sd.ok = xr.r > T(0);
-      s0 = div_shared<T, T>(xs - xr.xl, sd);              // t, cubic_spline.rs:818
-      s1 = T(0);
-    } else {
-      s0 = x - xr.xl;                                     // linear.rs:35's (x - x1)
-      s1 = T(0);
+  // QPL consecutive queries per lane, vector load / store; the (< QPL) queries behind the last full vector below
+  // `limit` go one per lane at the end
+  const uint64_t nvec = limit / QPL;
+  const uint64_t step = (uint64_t)gridDim.x * TB;
+  const QV* qv = reinterpret_cast<const QV*>(A.q);
+  QV* ov = reinterpret_cast<QV*>(A.out);
+  const uint64_t vlast = nvec ? nvec - 1u : 0u;
+  uint64_t vi = (uint64_t)blockIdx.x * TB + tid;
+  QV nxt = nvec ? qv[vi < nvec ? vi : vlast] : QV(S.k0);  // one vector ahead, clamped (unconditional: countable)
+  for (; vi < nvec; vi += step) {
+    const QV cur = nxt;
+    {
+      const uint64_t vn = vi + step;
+      nxt = qv[vn < nvec ? vn : vlast];
     }
-  };
-  auto point = [&](uint32_t rec, T s0) -> T {
-    const T* r = s_t + (size_t)rec * TR;
-    if (STRAT == ST_CUBIC) {                              // cubic_spline.rs:825-827
-      const T yl = r[0], yr = r[1], a = r[2], b = r[3];
-      const T c0 = T(1) - s0;
-      return c0 * yl + s0 * yr + (s0 * c0) * (a * c0 + b * s0);
-    } else {                                              // linear.rs:33-35 with the record's m
-      return r[1] * s0 + r[0];
-    }
-  };
-  if (L == 1u) {
-    // ---- scalar data: QPL consecutive queries per lane, vector load / store; the (< QPL) queries behind the last full
-    // vector below `limit` go one per lane at the end
-    const uint64_t nvec = limit / QPL;
-    const uint64_t step = (uint64_t)gridDim.x * TB;
-    const QV* qv = reinterpret_cast<const QV*>(A.q);
-    QV* ov = reinterpret_cast<QV*>(A.out);
-    const uint64_t vlast = nvec ? nvec - 1u : 0u;
-    uint64_t v0 = (uint64_t)blockIdx.x * TB + (tid & ~63u);
-    QV nxt = nvec ? qv[(v0 + lane < nvec) ? v0 + lane : vlast] : QV(k0);   // one vector ahead, clamped (unconditional)
-    for (; v0 < nvec; v0 += step) {
-      const uint64_t vi = v0 + lane;
-      const bool active = vi < nvec;
-      const QV cur = nxt;
-      {
-        const uint64_t vn = vi + step;
-        nxt = qv[vn < nvec ? vn : vlast];
-      }
-      QV res;
+    QV res;
 #pragma unroll
-      for (int u = 0; u < QPL; ++u) {
-        T x;
-        if constexpr (QPL == 1) x = cur; else x = cur[u];
-        if (!active) x = k0;
-        uint32_t i;
-        T s0, s1;
-        locate(x, i, s0, s1);
-        const T r = point(i, s0);
-        if constexpr (QPL == 1) res = r; else res[u] = r;
-      }
-      if constexpr (QPL == 1) {
-        if (active) store_stream<true>(A.out + vi * A.out_stride, res);   // (rows of one value may still be strided)
-      } else {
-        if (active) store_stream<true>(ov + vi, res);
-      }
-    }
-    const uint64_t done = nvec * QPL;
-    if (blockIdx.x == 0 && tid < 64u && done < limit) {   // (QPL > 1 only; wave-uniform)
-      const uint64_t qi = done + lane;
-      const bool active = qi < limit;
-      const T x = active ? A.q[qi] : k0;
+    for (int u = 0; u < QPL; ++u) {
+      T x;
+      if constexpr (QPL == 1) x = cur; else x = cur[u];
       uint32_t i;
-      T s0, s1;
-      locate(x, i, s0, s1);
-      const T r = point(i, s0);
-      if (active) A.out[qi * A.out_stride] = r;
+      T s0;
+      lane_query<T, STRAT>(S, s_x, A.mode, x, i, s0);
+      const T r = lane_point<T, STRAT>(s_t + (size_t)i * TR, s0);
+      if constexpr (QPL == 1) res = r; else res[u] = r;
     }
-    return;
+    if constexpr (QPL == 1) store_stream<true>(A.out + vi * A.out_stride, res);   // (rows of one value may be strided)
+    else store_stream<true>(ov + vi, res);
   }
-  // ---- 2 <= L: one query per lane, the wave's rows through a strip, out as one sequential vector stream
+  if constexpr (QPL > 1) {
+    const uint64_t qi = nvec * QPL + tid;
+    if (blockIdx.x == 0 && qi < limit) {
+      uint32_t i;
+      T s0;
+      lane_query<T, STRAT>(S, s_x, A.mode, A.q[qi], i, s0);
+      A.out[qi * A.out_stride] = lane_point<T, STRAT>(s_t + (size_t)i * TR, s0);
+    }
+  }
+}
+
+// LC: the trailing axis' length when it is one of the instantiated values (the per-lane loop unrolls), else 0
+template <class T, int STRAT, int LC, int TB>
+__global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int TR = STRAT == ST_CUBIC ? 4 : 2;
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, n = A.n;
+  const uint32_t L = LC ? (uint32_t)LC : A.lanes;
+  size_t off = 0;
+  const LaneAxis<T> S = stage_lane_axis<T, TB>(smem_raw, off, A.knots, n, A.dl);
+  XRec<T>* s_x = reinterpret_cast<XRec<T>*>(smem_raw + off);
+  if (STRAT == ST_CUBIC) {
+    stage_xrecs<T, TB>(s_x, A.knots, n);
+    off += (size_t)(n - 1u) * sizeof(XRec<T>);
+  }
+  T* s_t = reinterpret_cast<T*>(smem_raw + off);
+  stage_table_recs<T, STRAT, TB>(s_t, A);
+  off += (((size_t)(n - 1u) * L * TR * sizeof(T)) + 15u) & ~(size_t)15u;
+  T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;
+  __syncthreads();
+  unsigned long long limit = *A.first_fail;
+  if (limit > A.nq) limit = A.nq;
   const bool contig = A.out_stride == (uint64_t)L;
   const uint64_t wstep = (uint64_t)gridDim.x * TB;
   uint64_t base = ((uint64_t)blockIdx.x * (TB / 64) + (tid >> 6)) * 64u;
   T xn = A.q[(base + lane < A.nq) ? base + lane : A.nq - 1u];
   for (; base < limit; base += wstep) {
-    const bool active = base + lane < limit;
-    const T x = active ? xn : k0;
+    const T x = xn;                                       // (a lane past `limit` computes a row nobody stores)
     {
       const uint64_t pn = base + wstep + lane;
       xn = A.q[pn < A.nq ? pn : A.nq - 1u];               // the next batch, in flight during this one
     }
     uint32_t i;
-    T s0, s1;
-    locate(x, i, s0, s1);
-    const uint32_t rec0 = i * L;
-    for (uint32_t l = 0; l < L; ++l) s_strip[lane * L + l] = point(rec0 + l, s0);
+    T s0;
+    lane_query<T, STRAT>(S, s_x, A.mode, x, i, s0);
+    const T* rec = s_t + (size_t)i * L * TR;
+    T* mine = s_strip + lane * L;
+#pragma unroll
+    for (uint32_t l = 0; l < L; ++l) mine[l] = lane_point<T, STRAT>(rec + l * TR, s0);
     __builtin_amdgcn_wave_barrier();                      // LDS operations of one wave execute in order
     const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
     const uint32_t total = nq_here * L;
@@ -2579,15 +2658,18 @@ __global__ __launch_bounds__(TB) void eval_fused2d_kernel(EvalFused2Args<T> A) {
 // benches/bench_interp2d.rs:12-18: 80 KB in f64) and any other grid that fits beside its axes.  The counters of the
 // query-order kernel on that shape (profiles/r05_small_shapes_counters.txt) show the L1 address path as the bound: every
 // one of the four corner loads of a wave touches up to 64 different cache lines (374 L1 accesses per 64 queries: 0.48 of
-// the 0.90 ms).  With the grid in LDS no corner read leaves the CU.  A lane owns its query: both searches, the two knot
-// spacings with their staged reciprocals (one record {k_l, dk, RN(1 / dk)} per knot interval and axis), the four corners of
-// every value from LDS, bilinear.rs:88-97 with the correctly rounded shared-divisor divisions (div_shared: the bits of the
-// IEEE divisions); scalar grids take QPL consecutive queries per lane (16-byte query loads and stores), rows of several
-// values leave through a wave-private strip as one sequential stream of 16-byte vectors.
+// the 0.90 ms).  With the grid in LDS no corner read leaves the CU.  A lane owns its query: both searches branch-free
+// through the axes' dense bucket indices (lane_axis_index), the two knot spacings with their staged reciprocals (one record
+// {k_l, dk, RN(1 / dk)} per knot interval and axis), the four corners of every value from LDS, bilinear.rs:88-97 with the
+// correctly rounded shared-divisor divisions (div_shared: the bits of the IEEE divisions).  eval_scalar2d_kernel (one value
+// per grid point): QPL consecutive queries per lane, 16-byte query loads and stores; eval_lanes2d_kernel (rows of several
+// values): out through a wave-private strip as one sequential stream of 16-byte vectors.
 template <class T>
 struct EvalLanes2Args {
-  Pyramid<T> px, py;
-  BucketIndex<T> bx, by;   // lut == nullptr: pyramid search on that axis
+  const T* xk;             // [nx]
+  const T* yk;             // [ny]
+  uint32_t nx, ny;
+  DenseLut<T> dx, dy;
   const T* data;           // plain grid [nx][ny][lanes]
   const T* qx;
   const T* qy;
@@ -2598,152 +2680,138 @@ struct EvalLanes2Args {
   const unsigned long long* first_fail;   // [2]: x, y (range_check_kernel)
 };
 
+template <class T>
+struct LaneCell {
+  uint32_t o;              // element offset of the cell's first corner
+  T fx, fy;
+  SharedDivisor<T> dx, dy;
+};
+
+template <class T>
+__device__ __forceinline__ LaneCell<T> lane_cell(const LaneAxis<T>& SX, const LaneAxis<T>& SY, const XRec<T>* s_xx,
+                                                 const XRec<T>* s_xy, uint32_t ny, uint32_t L, T x, T y) {
+  const uint32_t xi = NDI_CHK(lane_axis_index<T>(SX, x), SX.n - 1u, BC_CELL_X);
+  const uint32_t yi = NDI_CHK(lane_axis_index<T>(SY, y), SY.n - 1u, BC_CELL_Y);
+  const XRec<T> rx = s_xx[xi], ry = s_xy[yi];
+  LaneCell<T> c;
+  c.o = (xi * ny + yi) * L;
+  c.fx = x - rx.xl;                   // linear.rs:35's (x - x1) of both directions
+  c.fy = y - ry.xl;
+  c.dx.d = rx.dx; c.dx.r = rx.r; c.dx.ok = rx.r > T(0);
+  c.dy.d = ry.dx; c.dy.r = ry.r; c.dy.ok = ry.r > T(0);
+  return c;
+}
+
+template <class T>
+__device__ __forceinline__ T lane_bilinear(const T* g, uint32_t L, uint32_t rowe, const LaneCell<T>& c) {   // bilinear.rs:88-97
+  const T a11 = g[0], a12 = g[L], a21 = g[rowe], a22 = g[rowe + L];
+  const T z1 = div_shared<T, T>(a21 - a11, c.dx) * c.fx + a11;
+  const T z2 = div_shared<T, T>(a22 - a12, c.dx) * c.fx + a12;
+  return div_shared<T, T>(z2 - z1, c.dy) * c.fy + z1;
+}
+
+// stages both axes, their interval records and the grid; returns the LDS offset behind them
+template <class T, int TB>
+__device__ __forceinline__ size_t stage_grid2(unsigned char* smem, const EvalLanes2Args<T>& A, LaneAxis<T>& SX, LaneAxis<T>& SY,
+                                              XRec<T>*& s_xx, XRec<T>*& s_xy, T*& s_g) {
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  size_t off = 0;
+  SX = stage_lane_axis<T, TB>(smem, off, A.xk, A.nx, A.dx);
+  SY = stage_lane_axis<T, TB>(smem, off, A.yk, A.ny, A.dy);
+  s_xx = reinterpret_cast<XRec<T>*>(smem + off);
+  off += (size_t)(A.nx - 1u) * sizeof(XRec<T>);
+  s_xy = reinterpret_cast<XRec<T>*>(smem + off);
+  off += (size_t)(A.ny - 1u) * sizeof(XRec<T>);
+  stage_xrecs<T, TB>(s_xx, A.xk, A.nx);
+  stage_xrecs<T, TB>(s_xy, A.yk, A.ny);
+  s_g = reinterpret_cast<T*>(smem + off);
+  const uint32_t gelems = A.nx * A.ny * A.lanes;
+  if ((gelems % VN) == 0u && (reinterpret_cast<uintptr_t>(A.data) & 15u) == 0u) {
+    const V* src = reinterpret_cast<const V*>(A.data);
+    V* dst = reinterpret_cast<V*>(s_g);
+    for (uint32_t i = threadIdx.x; i < gelems / VN; i += TB) dst[i] = src[i];
+  } else {
+    for (uint32_t i = threadIdx.x; i < gelems; i += TB) s_g[i] = A.data[i];
+  }
+  off += ((size_t)gelems * sizeof(T) + 15u) & ~(size_t)15u;
+  return off;
+}
+
 template <class T, int QPL, int TB>
+__global__ __launch_bounds__(TB) void eval_scalar2d_kernel(EvalLanes2Args<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  using QV = typename VecT<T, QPL>::type;
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x;
+  LaneAxis<T> SX, SY;
+  XRec<T>* s_xx;
+  XRec<T>* s_xy;
+  T* s_g;
+  stage_grid2<T, TB>(smem_raw, A, SX, SY, s_xx, s_xy, s_g);
+  __syncthreads();
+  unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
+  if (limit > A.nq) limit = A.nq;
+  const uint32_t ny = A.ny;
+  const uint64_t nvec = limit / QPL;
+  const uint64_t step = (uint64_t)gridDim.x * TB;
+  const QV* qxv = reinterpret_cast<const QV*>(A.qx);
+  const QV* qyv = reinterpret_cast<const QV*>(A.qy);
+  QV* ov = reinterpret_cast<QV*>(A.out);
+  const uint64_t vlast = nvec ? nvec - 1u : 0u;
+  uint64_t vi = (uint64_t)blockIdx.x * TB + tid;
+  QV nx_ = QV(SX.k0), ny_ = QV(SY.k0);
+  if (nvec) {
+    const uint64_t vc = vi < nvec ? vi : vlast;
+    nx_ = qxv[vc];
+    ny_ = qyv[vc];
+  }
+  for (; vi < nvec; vi += step) {
+    const QV cx = nx_, cy = ny_;
+    {
+      const uint64_t vn = vi + step;
+      const uint64_t vc = vn < nvec ? vn : vlast;
+      nx_ = qxv[vc];
+      ny_ = qyv[vc];
+    }
+    QV res;
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+      T x, y;
+      if constexpr (QPL == 1) { x = cx; y = cy; } else { x = cx[u]; y = cy[u]; }
+      const LaneCell<T> c = lane_cell<T>(SX, SY, s_xx, s_xy, ny, 1u, x, y);
+      const T r = lane_bilinear<T>(s_g + c.o, 1u, ny, c);
+      if constexpr (QPL == 1) res = r; else res[u] = r;
+    }
+    if constexpr (QPL == 1) store_stream<true>(A.out + vi * A.out_stride, res);
+    else store_stream<true>(ov + vi, res);
+  }
+  if constexpr (QPL > 1) {
+    const uint64_t qi = nvec * QPL + tid;
+    if (blockIdx.x == 0 && qi < limit) {
+      const LaneCell<T> c = lane_cell<T>(SX, SY, s_xx, s_xy, ny, 1u, A.qx[qi], A.qy[qi]);
+      A.out[qi * A.out_stride] = lane_bilinear<T>(s_g + c.o, 1u, ny, c);
+    }
+  }
+}
+
+template <class T, int TB>
 __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int VN = Wide<T>::N;
   using V = typename VecT<T, VN>::type;
-  using QV = typename VecT<T, QPL>::type;
   if (A.nq == 0) return;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t nx = A.px.n, ny = A.py.n, L = A.lanes;
-  const uint32_t nxa = nx + A.px.n1, nya = ny + A.py.n1;
-  // LDS: [x pyramid | y pyramid | x lut | y lut | x interval records | y interval records | grid | per-wave strips]
-  size_t off;
-  {
-    T* sx = reinterpret_cast<T*>(smem_raw);
-    T* sy = sx + nxa;
-    for (uint32_t i = tid; i < nxa; i += TB) sx[i] = A.px.lv0[i];
-    for (uint32_t i = tid; i < nya; i += TB) sy[i] = A.py.lv0[i];
-    off = ((size_t)(nxa + nya) * sizeof(T) + 15u) & ~(size_t)15u;
-  }
-  lds_u16 lutx = nullptr, luty = nullptr;
-  if (A.bx.lut || A.by.lut) {
-    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
-    const uint32_t wx = A.bx.lut ? (A.bx.m + 2u) / 2u : 0u, wy = A.by.lut ? (A.by.m + 2u) / 2u : 0u;
-    const uint32_t* srcx = reinterpret_cast<const uint32_t*>(A.bx.lut);
-    const uint32_t* srcy = reinterpret_cast<const uint32_t*>(A.by.lut);
-    for (uint32_t i = tid; i < wx; i += TB) sl[i] = srcx[i];
-    for (uint32_t i = tid; i < wy; i += TB) sl[wx + i] = srcy[i];
-    if (wx) lutx = (lds_u16)(smem_raw + off);
-    if (wy) luty = (lds_u16)(smem_raw + off + (size_t)wx * 4u);
-    off += (((size_t)(wx + wy) * 4u) + 15u) & ~(size_t)15u;
-  }
-  XRec<T>* s_xx = reinterpret_cast<XRec<T>*>(smem_raw + off);
-  off += (size_t)(nx - 1u) * sizeof(XRec<T>);
-  XRec<T>* s_xy = reinterpret_cast<XRec<T>*>(smem_raw + off);
-  off += (size_t)(ny - 1u) * sizeof(XRec<T>);
-  T* s_g = reinterpret_cast<T*>(smem_raw + off);
-  const uint32_t gelems = nx * ny * L;
-  off += ((size_t)gelems * sizeof(T) + 15u) & ~(size_t)15u;
-  T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;   // (touched only when L > 1)
-  for (uint32_t i = tid; i + 1u < nx; i += TB) {
-    const T kl = A.px.lv0[i], kr = A.px.lv0[i + 1];
-    const SharedDivisor<T> sd = shared_divisor<T>(kr - kl);
-    XRec<T> r;
-    r.xl = kl; r.dx = sd.d; r.r = sd.ok ? sd.r : T(0); r.pad = T(0);
-    s_xx[i] = r;
-  }
-  for (uint32_t i = tid; i + 1u < ny; i += TB) {
-    const T kl = A.py.lv0[i], kr = A.py.lv0[i + 1];
-    const SharedDivisor<T> sd = shared_divisor<T>(kr - kl);
-    XRec<T> r;
-    r.xl = kl; r.dx = sd.d; r.r = sd.ok ? sd.r : T(0); r.pad = T(0);
-    s_xy[i] = r;
-  }
-  if ((gelems % VN) == 0u && (reinterpret_cast<uintptr_t>(A.data) & 15u) == 0u) {
-    const V* src = reinterpret_cast<const V*>(A.data);
-    V* dst = reinterpret_cast<V*>(s_g);
-    for (uint32_t i = tid; i < gelems / VN; i += TB) dst[i] = src[i];
-  } else {
-    for (uint32_t i = tid; i < gelems; i += TB) s_g[i] = A.data[i];
-  }
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, L = A.lanes;
+  LaneAxis<T> SX, SY;
+  XRec<T>* s_xx;
+  XRec<T>* s_xy;
+  T* s_g;
+  const size_t off = stage_grid2<T, TB>(smem_raw, A, SX, SY, s_xx, s_xy, s_g);
+  T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;
   __syncthreads();
-  PyramidLds<T> PX, PY;
-  PX.lv0 = (lds_ptr<T>)(smem_raw);
-  PX.lv1 = PX.lv0 + nx;
-  PX.n = nx; PX.n1 = A.px.n1; PX.levels = A.px.levels; PX.guess = A.px.guess; PX.block = A.px.block;
-  PY.lv0 = PX.lv0 + nxa;
-  PY.lv1 = PY.lv0 + ny;
-  PY.n = ny; PY.n1 = A.py.n1; PY.levels = A.py.levels; PY.guess = A.py.guess; PY.block = A.py.block;
-  const T x0 = PX.lv0[0], xn = PX.lv0[nx - 1], y0 = PY.lv0[0], yn = PY.lv0[ny - 1];
   unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
   if (limit > A.nq) limit = A.nq;
-  const uint32_t rowe = ny * L;   // elements between grid rows
-  // the query's cell and its per-direction scalars (all 64 lanes call it: the pyramid search is wave-cooperative)
-  struct Cell { uint32_t o; T fx, fy; SharedDivisor<T> dx, dy; };
-  auto locate = [&](T x, T y) -> Cell {
-    const uint32_t xi = lutx ? locate_index_lut<T>(PX, lutx, A.bx.m, A.bx.scale, x0, xn, x)
-                             : locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);
-    const uint32_t yi = luty ? locate_index_lut<T>(PY, luty, A.by.m, A.by.scale, y0, yn, y)
-                             : locate_index<T, lds_ptr<T>>(PY, y0, yn, y, lane);
-    const XRec<T> rx = s_xx[NDI_CHK(xi, nx - 1u, BC_CELL_X)], ry = s_xy[NDI_CHK(yi, ny - 1u, BC_CELL_Y)];
-    Cell c;
-    c.o = (xi * ny + yi) * L;
-    c.fx = x - rx.xl;                 // linear.rs:35's (x - x1) of both directions
-    c.fy = y - ry.xl;
-    c.dx.d = rx.dx; c.dx.r = rx.r; c.dx.ok = rx.r > T(0);
-    c.dy.d = ry.dx; c.dy.r = ry.r; c.dy.ok = ry.r > T(0);
-    return c;
-  };
-  auto point = [&](const Cell& c, uint32_t l) -> T {   // bilinear.rs:88-97
-    const T* g = s_g + c.o + l;
-    const T a11 = g[0], a12 = g[L], a21 = g[rowe], a22 = g[rowe + L];
-    const T z1 = div_shared<T, T>(a21 - a11, c.dx) * c.fx + a11;
-    const T z2 = div_shared<T, T>(a22 - a12, c.dx) * c.fx + a12;
-    return div_shared<T, T>(z2 - z1, c.dy) * c.fy + z1;
-  };
-  if (L == 1u) {
-    const uint64_t nvec = limit / QPL;
-    const uint64_t step = (uint64_t)gridDim.x * TB;
-    const QV* qxv = reinterpret_cast<const QV*>(A.qx);
-    const QV* qyv = reinterpret_cast<const QV*>(A.qy);
-    QV* ov = reinterpret_cast<QV*>(A.out);
-    const uint64_t vlast = nvec ? nvec - 1u : 0u;
-    uint64_t v0 = (uint64_t)blockIdx.x * TB + (tid & ~63u);
-    QV nx_ = QV(x0), ny_ = QV(y0);
-    if (nvec) {
-      const uint64_t vc = (v0 + lane < nvec) ? v0 + lane : vlast;
-      nx_ = qxv[vc];
-      ny_ = qyv[vc];
-    }
-    for (; v0 < nvec; v0 += step) {
-      const uint64_t vi = v0 + lane;
-      const bool active = vi < nvec;
-      const QV cx = nx_, cy = ny_;
-      {
-        const uint64_t vn = vi + step;
-        const uint64_t vc = vn < nvec ? vn : vlast;
-        nx_ = qxv[vc];
-        ny_ = qyv[vc];
-      }
-      QV res;
-#pragma unroll
-      for (int u = 0; u < QPL; ++u) {
-        T x, y;
-        if constexpr (QPL == 1) { x = cx; y = cy; } else { x = cx[u]; y = cy[u]; }
-        if (!active) { x = x0; y = y0; }
-        const Cell c = locate(x, y);
-        const T r = point(c, 0u);
-        if constexpr (QPL == 1) res = r; else res[u] = r;
-      }
-      if constexpr (QPL == 1) {
-        if (active) store_stream<true>(A.out + vi * A.out_stride, res);
-      } else {
-        if (active) store_stream<true>(ov + vi, res);
-      }
-    }
-    const uint64_t done = nvec * QPL;
-    if (blockIdx.x == 0 && tid < 64u && done < limit) {
-      const uint64_t qi = done + lane;
-      const bool active = qi < limit;
-      const T x = active ? A.qx[qi] : x0, y = active ? A.qy[qi] : y0;
-      const Cell c = locate(x, y);
-      const T r = point(c, 0u);
-      if (active) A.out[qi * A.out_stride] = r;
-    }
-    return;
-  }
+  const uint32_t ny = A.ny, rowe = ny * L;
   const bool contig = A.out_stride == (uint64_t)L;
   const uint64_t wstep = (uint64_t)gridDim.x * TB;
   uint64_t base = ((uint64_t)blockIdx.x * (TB / 64) + (tid >> 6)) * 64u;
@@ -2754,16 +2822,16 @@ __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
     yq = A.qy[pc];
   }
   for (; base < limit; base += wstep) {
-    const bool active = base + lane < limit;
-    const T x = active ? xq : x0, y = active ? yq : y0;
+    const T x = xq, y = yq;
     {
       const uint64_t pn = base + wstep + lane;
       const uint64_t pc = pn < A.nq ? pn : A.nq - 1u;
       xq = A.qx[pc];
       yq = A.qy[pc];
     }
-    const Cell c = locate(x, y);
-    for (uint32_t l = 0; l < L; ++l) s_strip[lane * L + l] = point(c, l);
+    const LaneCell<T> c = lane_cell<T>(SX, SY, s_xx, s_xy, ny, L, x, y);
+    T* mine = s_strip + lane * L;
+    for (uint32_t l = 0; l < L; ++l) mine[l] = lane_bilinear<T>(s_g + c.o + l, L, rowe, c);
     __builtin_amdgcn_wave_barrier();
     const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
     const uint32_t total = nq_here * L;

@@ -339,6 +339,76 @@ struct DevicePyramid {
     });
   }
 
+  // Dense bucket index of the query-per-lane kernels (kernels.hpp, DenseLut): so many uniform buckets that none holds
+  // more than `maxk` knots -- the device then counts lut[bucket] + (the next maxk knots <= x) without a loop whose trip
+  // count depends on the data.  4n buckets to start with, doubled until maxk <= 3 or the index would outgrow 64 KiB of
+  // LDS; accepted up to maxk = 8 (clustered axes beyond that keep the other kernels).  Axes whose formula guess is exact
+  // need no index.  Built on first use with the device's arithmetic; a failed build leaves dense_ok = false.
+  DevBuf dlut_buf;
+  DenseLut<T> dlut{nullptr, 0, 0, T(0)};
+  size_t dlut_bytes = 0;   // LDS bytes of the staged index (16-byte multiple); 0 = none
+  bool dense_ok = false;
+  mutable std::once_flag dlut_once;
+  void ensure_dense_lut() const {
+    std::call_once(dlut_once, [this] {
+      DevicePyramid* self = const_cast<DevicePyramid*>(this);
+      const T* knots = host_knots.data();
+      const uint64_t n = host_knots.size();
+      if (n < 2) return;
+      if (guess_is_exact) { self->dense_ok = true; return; }
+      if (n > 16384) return;
+      const T k0 = knots[0], kn = knots[n - 1];
+      uint32_t m = 64;
+      while (m < 4 * n) m *= 2;
+      std::vector<uint32_t> cnt;
+      uint32_t best_m = 0, best_k = 0;
+      T best_scale = T(0);
+      for (; m <= 32768; m *= 2) {
+        const T scale = T(m) / (kn - k0);
+        if (!(scale > T(0)) || !std::isfinite((double)scale)) break;
+        cnt.assign(m, 0);
+        uint32_t mk = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+          T f = (knots[i] - k0) * scale;
+          f = std::fmax(f, T(0));
+          f = std::fmin(f, T(m - 1u));
+          mk = std::max(mk, ++cnt[(uint32_t)f]);
+        }
+        best_m = m; best_k = mk; best_scale = scale;
+        if (mk <= 3) break;
+      }
+      if (!best_m || best_k > 8) return;
+      const T scale = best_scale;
+      m = best_m;
+      cnt.assign(m, 0);
+      for (uint64_t i = 0; i < n; ++i) {
+        T f = (knots[i] - k0) * scale;
+        f = std::fmax(f, T(0));
+        f = std::fmin(f, T(m - 1u));
+        ++cnt[(uint32_t)f];
+      }
+      std::vector<uint16_t> lut((size_t)m + 2 + 6, (uint16_t)n);
+      uint32_t run = 0;
+      for (uint32_t b = 0; b < m; ++b) {
+        lut[b] = (uint16_t)run;
+        run += cnt[b];
+      }
+      const size_t bytes = (((size_t)(m + 2) / 2) * 4 + 15) & ~(size_t)15;
+      try {
+        maybe_fail_lazy_alloc(__LINE__);
+        self->dlut_buf.reserve(std::max(bytes, lut.size() * sizeof(uint16_t)));
+        NDI_HIP(hipMemcpy(self->dlut_buf.p, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      } catch (const HipFailure&) {
+        (void)hipGetLastError();
+        self->dlut_buf.release();
+        return;
+      }
+      self->dlut = DenseLut<T>{self->dlut_buf.template as<uint16_t>(), m, best_k, scale};
+      self->dlut_bytes = bytes;
+      self->dense_ok = true;
+    });
+  }
+
   // Bucket index (kernels.hpp, BucketIndex): only for axes the O(1) formula guess does not resolve for every x, with
   // u16 entries (n <= 65535) and more than one top-level block.  Built with bucket_of(), the function the device uses.
   DevBuf lut_buf;
@@ -875,6 +945,7 @@ struct Interp1DImpl final : Interp1DBase {
     static const int blocked_once = ShortKnobs::env("NDI_SPLINE_BLOCKED", -1);
     const int blocked_env = tune_live ? ShortKnobs::env("NDI_SPLINE_BLOCKED", -1) : blocked_once;
     const bool blocked = (P.mode == SPLINE_GENERAL || P.mode == SPLINE_PERIODIC) && n >= 16 &&
+                         !(d.build_flags & NDI_BUILD_REFERENCE_ORDER) &&
                          (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256));
     const bool per = P.mode == SPLINE_PERIODIC;
     const uint64_t rows = per ? n - 2 : n;   // order of the system the two sweeps run over
@@ -1102,48 +1173,40 @@ struct Interp1DImpl final : Interp1DBase {
     int l_qpl = 1;   // LANES, scalar data: queries per lane (1, or one 16-byte vector)
   };
 
-  // LDS footprint of eval_lanes_kernel: [pyramid | lut | interval records | table records | per-wave strips]
-  size_t lanes_lds_bytes(bool with_lut, unsigned tb) const {
+  // LDS footprint of eval_scalar_kernel / eval_lanes_kernel: [knots | dense index | interval records | table records | strips]
+  size_t lanes_lds_bytes(unsigned tb) const {
     const size_t tr = strategy == NDI_CUBIC_SPLINE ? 4 : 2;
-    size_t b = (pyr.lds_bytes + 15) & ~(size_t)15;
-    if (with_lut) b += pyr.lut_bytes;
-    b += (size_t)(n - 1) * 4 * sizeof(T);
+    size_t b = ((size_t)n * sizeof(T) + 15) & ~(size_t)15;
+    b += pyr.dlut_bytes;
+    if (strategy == NDI_CUBIC_SPLINE) b += (size_t)(n - 1) * 4 * sizeof(T);
     b += ((size_t)(n - 1) * lanes * tr * sizeof(T) + 15) & ~(size_t)15;
     if (lanes > 1) b += (size_t)(tb / 64) * 64 * lanes * sizeof(T);
     return b;
   }
 
-  // Query per lane with the whole table set in LDS (eval_lanes_kernel): rows of up to 64 bytes (NDI_LANES_MAXB) whose
-  // records fit LDS beside the knots, batches that give every workgroup several times its staging bytes to write.
+  // Query per lane with the whole table set in LDS (eval_scalar_kernel / eval_lanes_kernel): rows of up to 64 bytes
+  // (NDI_LANES_MAXB) whose records fit LDS beside the knots, an axis the branch-free search covers (dense bucket index
+  // or exact O(1) guess), batches that give every workgroup several times its staging bytes to write.
   // NDI_LANES_KERNEL=0 leaves these shapes to the query-order kernel (A/B); =1 takes it whenever it fits.
   bool plan_lanes(hipStream_t s, Scratch& sc, Plan1& P, int path) {
     static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
     static const int on_once = ShortKnobs::env("NDI_LANES_KERNEL", -1), maxb_once = ShortKnobs::env("NDI_LANES_MAXB", 64);
     const int on = tune_live ? ShortKnobs::env("NDI_LANES_KERNEL", -1) : on_once;
     const int maxb = tune_live ? ShortKnobs::env("NDI_LANES_MAXB", 64) : maxb_once;
-    if (on == 0 || path == NDI_PATH_BUCKETED || n < 2) return false;
+    if (on == 0 || path == NDI_PATH_BUCKETED || n < 3 || n > 16384) return false;
     if (on < 0 && short_knobs().mode != 0) return false;   // a pinned short-row variant (NDI_SHORT_MODE) is what runs
-    if (lanes * sizeof(T) > (size_t)maxb || pyr.lds_bytes > LDS_STAGE_LIMIT / 2) return false;
-    static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
-    if (lut_env && P.nq >= 4096) pyr.ensure_bucket_index();
-    const size_t tab = lanes_lds_bytes(false, 64) - (lanes > 1 ? (size_t)64 * lanes * sizeof(T) : 0);
+    if (lanes * sizeof(T) > (size_t)maxb) return false;
+    const size_t tab = ((size_t)n * sizeof(T)) + (size_t)(n - 1) * (4 + lanes * 4) * sizeof(T);   // (before the index is known)
+    if (tab > FUSED_LDS_LIMIT) return false;
     if (on < 0 && (P.nq < 65536 || (double)P.nq * (double)lanes * sizeof(T) < 4.0 * (double)cu_count() * (double)tab)) return false;
-    size_t best = 0;
-    for (int with_lut = (lut_env && P.nq >= 4096 && pyr.lut_bytes) ? 1 : 0; with_lut >= 0; --with_lut) {
-      for (unsigned tb : {1024u, 512u, 256u}) {      // among equals the largest workgroup: fewest staging passes
-        const size_t need = lanes_lds_bytes(with_lut != 0, tb);
-        if (need > FUSED_LDS_LIMIT) continue;
-        const size_t waves = std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
-        if (waves > best) {
-          best = waves;
-          P.f_lut = with_lut != 0;
-          P.f_tb = tb;
-          P.f_lds = need;
-        }
-      }
-      if (best) break;   // the bucket index whenever it fits at all: the tables are small by construction
-    }
-    if (!best) return false;
+    pyr.ensure_dense_lut();
+    if (!pyr.dense_ok) return false;
+    // workgroup: 256 threads when four or more fit a CU beside each other (small tables: the staging pass is cheap and
+    // short workgroups retire independently), else 1024
+    P.f_tb = lanes_lds_bytes(256) * 4 <= 160 * 1024 ? 256u : 1024u;
+    if (lanes_lds_bytes(P.f_tb) > FUSED_LDS_LIMIT) P.f_tb = 256u;   // (the strips of 16 waves do not fit: 4 waves)
+    P.f_lds = lanes_lds_bytes(P.f_tb);
+    if (P.f_lds > FUSED_LDS_LIMIT) return false;
     constexpr int VN = Wide<T>::N;
     P.l_qpl = (lanes == 1 && P.out_stride == 1 && aligned16(P.q) && aligned16(P.out)) ? VN : 1;
     const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
@@ -1164,8 +1227,9 @@ struct Interp1DImpl final : Interp1DBase {
 
   void launch_lanes(hipStream_t s, Scratch& sc, const Plan1& P) {
     EvalLanesArgs<T> F{};
-    F.pyr = pyr.view;
-    F.bx = P.f_lut ? pyr.bidx : BucketIndex<T>{nullptr, 0, T(0)};
+    F.knots = pyr.view.lv0;
+    F.n = (uint32_t)n;
+    F.dl = pyr.dlut;
     F.data = data.as<T>();
     F.ca = ca.as<T>();
     F.cb = cb.as<T>();
@@ -1177,29 +1241,41 @@ struct Interp1DImpl final : Interp1DBase {
     F.mode = mode;
     F.first_fail = &sc.status.as<StatusBlock>()->first_fail[0];
     if (std::getenv("NDI_TRACE_PLAN"))
-      std::fprintf(stderr, "[ndi plan] lanes L=%llu qpl=%d lut=%d tb=%u grid=%u lds=%zu\n", (unsigned long long)lanes,
-                   P.l_qpl, (int)P.f_lut, P.f_tb, P.f_grid, P.f_lds);
+      std::fprintf(stderr, "[ndi plan] lanes L=%llu qpl=%d index=%s m=%u maxk=%u tb=%u grid=%u lds=%zu\n", (unsigned long long)lanes,
+                   P.l_qpl, pyr.dlut.lut ? "dense" : "guess", pyr.dlut.m, pyr.dlut.maxk, P.f_tb, P.f_grid, P.f_lds);
     constexpr int VN = Wide<T>::N;
     const dim3 grid(P.f_grid), block(P.f_tb);
-#define NDI_LA(ST, QPL, TB)                                                               \
+#define NDI_LK(KERN)                                                                      \
   do {                                                                                    \
-    auto kern = eval_lanes_kernel<T, ST, QPL, TB>;                                        \
+    auto kern = KERN;                                                                     \
     allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);         \
     launch1<T>(s, PC_EVAL, grid, block, P.f_lds, kern, F);                                \
   } while (0)
-#define NDI_LA_TB(ST, QPL)                                          \
-  do {                                                              \
-    if (P.f_tb == 1024) NDI_LA(ST, QPL, 1024);                      \
-    else if (P.f_tb == 512) NDI_LA(ST, QPL, 512);                   \
-    else NDI_LA(ST, QPL, 256);                                      \
+#define NDI_LS(ST, QPL)                                                                   \
+  do {                                                                                    \
+    if (P.f_tb == 1024) NDI_LK((eval_scalar_kernel<T, ST, QPL, 1024>));                   \
+    else NDI_LK((eval_scalar_kernel<T, ST, QPL, 256>));                                   \
   } while (0)
-    if (strategy == NDI_CUBIC_SPLINE) {
-      if (P.l_qpl == VN) NDI_LA_TB(ST_CUBIC, VN); else NDI_LA_TB(ST_CUBIC, 1);
+#define NDI_LL(ST, LC)                                                                    \
+  do {                                                                                    \
+    if (P.f_tb == 1024) NDI_LK((eval_lanes_kernel<T, ST, LC, 1024>));                     \
+    else NDI_LK((eval_lanes_kernel<T, ST, LC, 256>));                                     \
+  } while (0)
+#define NDI_LLC(ST)                                                                       \
+  do {                                                                                    \
+    if (lanes == 2) NDI_LL(ST, 2); else if (lanes == 5) NDI_LL(ST, 5);                    \
+    else if (lanes == 8) NDI_LL(ST, 8); else NDI_LL(ST, 0);                               \
+  } while (0)
+    if (lanes == 1) {
+      if (strategy == NDI_CUBIC_SPLINE) { if (P.l_qpl == VN) NDI_LS(ST_CUBIC, VN); else NDI_LS(ST_CUBIC, 1); }
+      else { if (P.l_qpl == VN) NDI_LS(ST_LINEAR, VN); else NDI_LS(ST_LINEAR, 1); }
     } else {
-      if (P.l_qpl == VN) NDI_LA_TB(ST_LINEAR, VN); else NDI_LA_TB(ST_LINEAR, 1);
+      if (strategy == NDI_CUBIC_SPLINE) NDI_LLC(ST_CUBIC); else NDI_LLC(ST_LINEAR);
     }
-#undef NDI_LA_TB
-#undef NDI_LA
+#undef NDI_LLC
+#undef NDI_LL
+#undef NDI_LS
+#undef NDI_LK
   }
 
   // LDS footprint of eval_fused_kernel: [pyramid | lut | per-wave strips | tables]
@@ -2184,34 +2260,28 @@ struct Interp2DImpl final : Interp2DBase {
     // 21 Gqueries/s -- a thread per query turns every operand load into 64 scattered sectors, where the item-per-lane
     // gather kernel reads each query's 40-byte segments whole.)
     // Grids that fit LDS beside their axes (the reference's 100 x 100 scalar grid: 80 KB in f64), rows of up to 64 bytes,
-    // large batches: query per lane with every corner read served by LDS (eval_lanes2d_kernel).  NDI_LANES2D_KERNEL=0: A/B.
+    // large batches: query per lane with every corner read served by LDS (eval_scalar2d_kernel / eval_lanes2d_kernel).
+    // NDI_LANES2D_KERNEL=0: A/B.
     {
       static const bool tune_live2 = std::getenv("NDI_TUNE_LIVE") != nullptr;
       static const int on_once = ShortKnobs::env("NDI_LANES2D_KERNEL", -1);
       const int on = tune_live2 ? ShortKnobs::env("NDI_LANES2D_KERNEL", -1) : on_once;
       const size_t grid_b = (size_t)nx * ny * lanes * sizeof(T);
-      if (on != 0 && path != NDI_PATH_BUCKETED && !pair_packed && both <= LDS_STAGE_LIMIT / 2 && lanes * sizeof(T) <= 64 &&
-          grid_b <= FUSED_LDS_LIMIT && (uint64_t)nx * ny * lanes < (1ull << 31) &&
+      if (on != 0 && path != NDI_PATH_BUCKETED && !pair_packed && nx <= 16384 && ny <= 16384 && lanes * sizeof(T) <= 64 &&
+          grid_b + (nx + ny) * 5 * sizeof(T) <= FUSED_LDS_LIMIT && (uint64_t)nx * ny * lanes < (1ull << 31) &&
           (on > 0 || (nq >= 65536 && (double)nq * (double)lanes * sizeof(T) >= 4.0 * (double)cu_count() * (double)grid_b))) {
-        static const int lut_env0 = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
-        size_t lut_b = 0;
-        if (lut_env0 && nq >= 4096) {
-          px.ensure_bucket_index();
-          py.ensure_bucket_index();
-          lut_b = px.lut_bytes + py.lut_bytes;
-        }
-        const size_t fixed = both + (size_t)(nx - 1 + ny - 1) * 4 * sizeof(T) + ((grid_b + 15) & ~(size_t)15);
-        size_t best = 0;
-        for (int with_lut = lut_b ? 1 : 0; with_lut >= 0 && !best; --with_lut)
-          for (unsigned tb : {1024u, 512u, 256u}) {
-            const size_t need = fixed + (with_lut ? lut_b : 0) + (lanes > 1 ? (size_t)(tb / 64) * 64 * lanes * sizeof(T) : 0);
-            if (need > FUSED_LDS_LIMIT) continue;
-            const size_t waves = std::min<size_t>((160 * 1024) / need, 32 / (tb / 64)) * (tb / 64);
-            if (waves > best) { best = waves; P.f_lut = with_lut != 0; P.f_tb = tb; P.f_lds = need; }
-          }
-        if (best) {
+        px.ensure_dense_lut();
+        py.ensure_dense_lut();
+        const size_t fixed = (((size_t)nx * sizeof(T) + 15) & ~(size_t)15) + (((size_t)ny * sizeof(T) + 15) & ~(size_t)15) +
+                             px.dlut_bytes + py.dlut_bytes + (size_t)(nx - 1 + ny - 1) * 4 * sizeof(T) + ((grid_b + 15) & ~(size_t)15);
+        auto need_of = [&](unsigned tb) { return fixed + (lanes > 1 ? (size_t)(tb / 64) * 64 * lanes * sizeof(T) : 0); };
+        unsigned tb = need_of(256) * 4 <= 160 * 1024 ? 256u : 1024u;
+        if (need_of(tb) > FUSED_LDS_LIMIT) tb = 256u;   // (the strips of 16 waves do not fit: 4 waves)
+        if (px.dense_ok && py.dense_ok && need_of(tb) <= FUSED_LDS_LIMIT) {
           constexpr int VNl = Wide<T>::N;
           P.kind = Plan2::LANES2;
+          P.f_tb = tb;
+          P.f_lds = need_of(tb);
           P.l_qpl = (lanes == 1 && out_stride == 1 && aligned16(qx) && aligned16(qy) && aligned16(out)) ? VNl : 1;
           const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
           const uint64_t per_wg = (uint64_t)P.f_tb * (lanes == 1 ? (uint64_t)P.l_qpl : 1);
@@ -2489,9 +2559,9 @@ struct Interp2DImpl final : Interp2DBase {
     }
     if (P.kind == Plan2::LANES2) {
       EvalLanes2Args<T> F{};
-      F.px = px.view; F.py = py.view;
-      F.bx = P.f_lut ? px.bidx : BucketIndex<T>{nullptr, 0, T(0)};
-      F.by = P.f_lut ? py.bidx : BucketIndex<T>{nullptr, 0, T(0)};
+      F.xk = px.view.lv0; F.yk = py.view.lv0;
+      F.nx = (uint32_t)nx; F.ny = (uint32_t)ny;
+      F.dx = px.dlut; F.dy = py.dlut;
       F.data = data.as<T>();
       F.qx = P.qx; F.qy = P.qy;
       F.out = P.out;
@@ -2501,19 +2571,21 @@ struct Interp2DImpl final : Interp2DBase {
       F.mode = mode;
       F.first_fail = &st->first_fail[0];
       if (std::getenv("NDI_TRACE_PLAN"))
-        std::fprintf(stderr, "[ndi plan] lanes2d L=%llu qpl=%d lut=%d tb=%u grid=%u lds=%zu\n", (unsigned long long)lanes,
-                     P.l_qpl, (int)P.f_lut, P.f_tb, P.f_grid, P.f_lds);
+        std::fprintf(stderr, "[ndi plan] lanes2d L=%llu qpl=%d maxk=%u,%u tb=%u grid=%u lds=%zu\n", (unsigned long long)lanes,
+                     P.l_qpl, px.dlut.maxk, py.dlut.maxk, P.f_tb, P.f_grid, P.f_lds);
       constexpr int VNl = Wide<T>::N;
-#define NDI_L2(QPL, TB)                                                                   \
+#define NDI_L2(KERN)                                                                      \
   do {                                                                                    \
-    auto kern = eval_lanes2d_kernel<T, QPL, TB>;                                          \
+    auto kern = KERN;                                                                     \
     allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);         \
-    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(TB), P.f_lds, kern, F);                   \
+    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(P.f_tb), P.f_lds, kern, F);               \
   } while (0)
-      if (P.l_qpl == VNl) {
-        if (P.f_tb == 1024) NDI_L2(VNl, 1024); else if (P.f_tb == 512) NDI_L2(VNl, 512); else NDI_L2(VNl, 256);
+      if (lanes == 1 && P.l_qpl == VNl) {
+        if (P.f_tb == 1024) NDI_L2((eval_scalar2d_kernel<T, VNl, 1024>)); else NDI_L2((eval_scalar2d_kernel<T, VNl, 256>));
+      } else if (lanes == 1) {
+        if (P.f_tb == 1024) NDI_L2((eval_scalar2d_kernel<T, 1, 1024>)); else NDI_L2((eval_scalar2d_kernel<T, 1, 256>));
       } else {
-        if (P.f_tb == 1024) NDI_L2(1, 1024); else if (P.f_tb == 512) NDI_L2(1, 512); else NDI_L2(1, 256);
+        if (P.f_tb == 1024) NDI_L2((eval_lanes2d_kernel<T, 1024>)); else NDI_L2((eval_lanes2d_kernel<T, 256>));
       }
 #undef NDI_L2
       return;

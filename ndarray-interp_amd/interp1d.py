@@ -64,7 +64,7 @@ class _DeviceStrategy1D(Interp1DStrategy):
 
     # -- build ------------------------------------------------------------------------------
     def _create(self, x, data, *, extrapolate, periodic=False, left=(0, 0.0), right=(0, 0.0),
-                per_lane=None, device=None):
+                per_lane=None, device=None, build_flags=0):
         xb_dt = np_dtype_of(data)
         tid = dtype_id(xb_dt)
         db = Buf(data)
@@ -84,6 +84,7 @@ class _DeviceStrategy1D(Interp1DStrategy):
         d.memspace = db.memspace
         d.validate = 0  # Interp1DBuilder.build() has validated already, as in the reference (:449-473)
         d.periodic = int(bool(periodic))
+        d.build_flags = int(build_flags)
         d.left = _capi.Boundary(int(left[0]), float(left[1]))
         d.right = _capi.Boundary(int(right[0]), float(right[1]))
         keep = []
@@ -359,6 +360,7 @@ class CubicSpline(Interp1DStrategyBuilder):
         self._extrapolate = False
         self._boundary = BoundaryCondition.NotAKnot  # default, cubic_spline.rs:724-729
         self._device_req = None
+        self._reference_order = False
 
     @staticmethod
     def new() -> "CubicSpline":
@@ -373,6 +375,14 @@ class CubicSpline(Interp1DStrategyBuilder):
         self._extrapolate = bool(extrapolate)
         return self
 
+    def reference_order(self, yes: bool = True) -> "CubicSpline":
+        """Build-side option of this mirror (ndi_build_flags, NDI_BUILD_REFERENCE_ORDER): never re-associate the Thomas
+        sweeps, so the a / b tables are bit-identical to CubicSpline::build's (cubic_spline.rs:678-721) for every shape.
+        Default: narrow trailing axes on many knots (n >= 2048, lanes <= 256) take blocked sweeps that agree with the
+        reference to a few ulp of the neighbouring entries (include/ndinterp.h states the bound)."""
+        self._reference_order = bool(yes)
+        return self
+
     def boundary(self, boundary: BoundaryCondition) -> "CubicSpline":
         self._boundary = boundary
         return self
@@ -380,7 +390,8 @@ class CubicSpline(Interp1DStrategyBuilder):
     def build(self, x, data) -> "CubicSplineStrategy":
         bc = self._boundary
         strat = CubicSplineStrategy()
-        kw = dict(extrapolate=self._extrapolate, device=self._device_req)
+        kw = dict(extrapolate=self._extrapolate, device=self._device_req,
+                  build_flags=_capi.BUILD_REFERENCE_ORDER if self._reference_order else 0)
         if bc.tag == "Periodic":
             kw["periodic"] = True
         elif bc.tag == "Individual":

@@ -42,6 +42,9 @@ pub const NDI_MONO_RISING: i32 = 2;
 pub const NDI_MONO_FALLING_STRICT: i32 = 3;
 pub const NDI_MONO_FALLING: i32 = 4;
 /// `ndi_path`
+pub const NDI_BUILD_DEFAULT: i32 = 0;
+pub const NDI_BUILD_REFERENCE_ORDER: i32 = 1;
+
 pub const NDI_PATH_AUTO: i32 = 0;
 pub const NDI_PATH_GATHER: i32 = 1;
 pub const NDI_PATH_BUCKETED: i32 = 2;
@@ -69,6 +72,7 @@ pub struct ndi_interp1d_desc {
     pub memspace: i32,
     pub validate: i32,
     pub periodic: i32,
+    pub build_flags: i32,
     pub left: ndi_boundary,
     pub right: ndi_boundary,
     pub lane_left_kind: *const i32,

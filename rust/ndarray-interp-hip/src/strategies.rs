@@ -179,6 +179,7 @@ fn create_1d<T, Sx2, Sd, D>(
     x: &ArrayBase<Sx2, Ix1>,
     data: &ArrayBase<Sd, D>,
     periodic: bool,
+    build_flags: i32,
     left: ffi::ndi_boundary,
     right: ffi::ndi_boundary,
     lanes_bc: Option<&LaneBoundaries>,
@@ -213,6 +214,7 @@ where
         memspace: ffi::NDI_MEM_HOST,
         validate: 0,
         periodic: periodic as i32,
+        build_flags,
         left,
         right,
         lane_left_kind: lanes_bc.map_or(null(), |l| l.left_kind.as_ptr()),
@@ -281,6 +283,7 @@ where
             x,
             data,
             false,
+            ffi::NDI_BUILD_DEFAULT,
             zero,
             zero,
             None,
@@ -387,6 +390,7 @@ pub struct HipCubicSpline {
     extrapolate: bool,
     boundary: BoundaryCondition,
     device: Option<i32>,
+    reference_order: bool,
 }
 impl HipCubicSpline {
     /// default boundary NotAKnot (cubic_spline.rs:724-729)
@@ -403,6 +407,13 @@ impl HipCubicSpline {
     }
     pub fn device(mut self, ordinal: i32) -> Self {
         self.device = Some(ordinal);
+        self
+    }
+    /// `NDI_BUILD_REFERENCE_ORDER` (include/ndinterp.h): never re-associate the Thomas sweeps -- the a / b tables are
+    /// bit-identical to `CubicSpline::build`'s (cubic_spline.rs:678-721) for every shape, at the serial kernels'
+    /// speed on narrow trailing axes with many knots.  Default: blocked sweeps there (a few ulp, see the header).
+    pub fn reference_order(mut self, yes: bool) -> Self {
+        self.reference_order = yes;
         self
     }
 }
@@ -479,6 +490,7 @@ where
             x,
             data,
             periodic,
+            if self.reference_order { ffi::NDI_BUILD_REFERENCE_ORDER } else { ffi::NDI_BUILD_DEFAULT },
             left,
             right,
             lanes_bc.as_ref(),

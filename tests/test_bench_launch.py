@@ -29,6 +29,8 @@ def test_bench_self_launches_two_ranks():
     assert rk["world"] == 2 and rk["backend"] == "gloo" and rk["per_rank_ms"] == [1.0, 2.0]
     assert rk["per_rank_kernel_ms"] == [0.5, 1.5] and rk["slowest_rank"] == 1 and rk["distinct_devices"] == 2
     assert [d["rank"] for d in rk["devices"]] == [0, 1]
+    # N > 1 lands on a BASELINE config without any flag: C4's per-GPU share (configs[3]: 1e8 queries over 8 GPUs)
+    assert line["queries_per_gpu"] == 12_500_000 and line["workload"].startswith("C4 (BASELINE configs[3]) per-GPU share x 2")
 
 
 def test_bench_a_failing_rank_takes_the_others_down():
@@ -58,6 +60,7 @@ def test_bench_single_rank_rehearsal():
     assert r.returncode == 0, r.stderr
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == 1 and line["ranks"] is None
+    assert line["queries_per_gpu"] == 10_000_000 and line["workload"] == "Target"
 
 
 import pytest
@@ -71,11 +74,17 @@ def test_bench_two_ranks_on_one_gpu_line_carries_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
                         "--device-override", "0", "--knots", "512", "--lanes", "1024", "--queries", "400000",
                         "--chunk", "100000", "--steps", "3", "--warmup", "1", "--placement-probe", "0",
-                        "--no-gather-leg", "--no-pmc"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-gather-leg", "--no-pmc", "--c5-leg-grid", "1024", "--c5-leg-queries", "300000"],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _one_json_line(r.stdout)
     rk = line["ranks"]
     assert line["n_gpus"] == 2 and rk["world"] == 2 and rk["backend"] == "gloo" and len(rk["per_rank_ms"]) == 2
+    # the N > 1 line names its workloads after BASELINE configs[3] / [4] and carries the per-rank C5-share leg
+    assert line["config"]["workload"].startswith("C4-shaped rehearsal")
+    c5 = line["c5_share"]
+    assert c5["workload"].startswith("C5 (BASELINE configs[4]) per-GPU share") and len(c5["per_rank_ms"]) == 2
+    assert all(v > 0 for v in c5["per_rank_ms"] + c5["per_rank_kernel_ms"]) and c5["ms_per_step"] == max(c5["per_rank_ms"])
     assert all(v > 0 for v in rk["per_rank_ms"] + rk["per_rank_kernel_ms"])
     assert [d["ordinal"] for d in rk["devices"]] == [0, 0] and rk["distinct_devices"] == 1
     assert line["ms_per_step"] >= max(rk["per_rank_ms"]) * 0.999 and line["check"]["bit_exact"]
@@ -110,6 +119,7 @@ def test_bench_in_process_sharded_leg():
     line = _one_json_line(r.stdout)
     leg = line["in_process_sharded"]
     assert leg["devices"] == [0, 0] and "error" not in leg and leg["Mpoints_s"] > 0 and leg["queries_per_device"] == 400000
-    assert set(line["secondary"]) == {"c3", "c5_share", "c1", "short_rows"}
+    assert set(line["secondary"]) == {"c3", "c5_share", "c1", "short_rows", "c2_linear", "c2_f32", "reference_shapes_2d", "host_path"}
+    assert line["roofline"].get("survey_8d_frac") is None   # (--no-gather-leg: the 8(d) basis belongs to the gather kernel's leg)
     # the leg is bounded in wall-clock time and says what it timed
     assert leg["leg_wall_s"] <= leg["budget_s"] + 30 and "timed" in leg and leg["first_step_s"] > 0

@@ -74,7 +74,7 @@ def test_lanes_1d_bit_exact(pkg, capfd, dt, kind, n, L):
                 qo = torch.empty(Q + 1, dtype=_tdt(dt), device=dev)[1:]
                 qo.copy_(qd)
                 wide = torch.full((Q, L + 3), -9.0, dtype=_tdt(dt), device=dev)
-                it.interp_array_into(qo, wide[:, :L])
+                it.strategy.interp_array_into(it, qo, wide[:, :L])
             host = it.interp_array(q)      # host arrays in and out: the staged small-row path (PCIe-bound, not this kernel)
             assert len(f.plans) == 2 and all(" lanes L=" in p for p in f.plans), f.plans
             if L == 1:
@@ -191,7 +191,7 @@ def test_lanes_2d_bit_exact(pkg, capfd, dt, kx, ky, nx, ny, C):
         qxo = torch.empty(Q + 1, dtype=_tdt(dt), device=dev)[1:]
         qxo.copy_(qxd)
         wide = torch.full((Q, C + 2), -9.0, dtype=_tdt(dt), device=dev)
-        it.interp_array_into(qxo, qyd, wide[:, :C])
+        it.strategy.interp_array_into(it, qxo, qyd, wide[:, :C])
     host = it.interp_array(qx, qy)         # host arrays in and out: the staged small-row path
     assert len(f.plans) == 2 and all(" lanes2d L=" in p for p in f.plans), f.plans
     check_equal(out.cpu().numpy(), ref, f"lanes2d {nx}x{ny}x{C}")

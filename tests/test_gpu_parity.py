@@ -1168,3 +1168,43 @@ def test_bilinear_small_channels_device_buffers(pkg, dt, C, capfd):
                 assert (ei.value.index, ei.value.axis) == (Q // 2, 0)
                 o2 = out2.cpu().numpy()
                 assert np.array_equal(o2[: Q // 2], ref.reshape(Q, C)[: Q // 2]) and np.all(o2[Q // 2:] == -4.0)
+
+
+def test_baseline_c1_exact_workload(pkg):
+    """BASELINE configs[0] exactly as bench.py times it: 1-D Linear on the DEFAULT index axis (Interp1DBuilder::new's
+    x = 0..n, interp1d/mod.rs:399-410), 1024 f64 knots, scalar data, 1e4 uniform queries in [0, n - 1] (the shape of
+    benches/bench_interp1d.rs:33-37 with 1024 knots) -- host arrays in and out (the zero-copy small-batch path with the
+    O(1) index guess inside the fused kernel), then the same batch with device buffers, both bit-equal to the oracle."""
+    import torch
+    n, nq = 1024, 10_000
+    yv = np.random.default_rng(42).uniform(0, 1, n)
+    q = np.random.default_rng(123).uniform(0, n - 1, nq)
+    q[:3] = [0.0, n - 1.0, 511.0]
+    x = np.arange(n, dtype=np.float64)
+    ref = oracle.interp1d_linear(x, yv, q)[2][:, 0]
+    interp = pkg.Interp1DBuilder.new(yv).build()                 # no .x(): the default axis; no .strategy(): Linear
+    got = interp.interp_array(q)
+    assert got.shape == (nq,) and got.dtype == np.float64
+    check_equal(got, ref, "C1 host arrays")
+    assert got[0] == yv[0] and got[1] == yv[-1] and got[2] == yv[511]
+    # the bare C ABI call bench.py's secondary.c1 leg makes
+    import ctypes
+    cap = pkg._capi
+    out = np.full(nq, -1.0); opts = cap.EvalOpts(); info = cap.OobInfo()
+    assert cap.lib().ndi_interp1d_eval(interp.strategy._h, q.ctypes.data, nq, out.ctypes.data, 1, ctypes.byref(opts),
+                                       ctypes.byref(info)) == 0
+    check_equal(out, ref, "C1 C ABI host to host")
+    # device buffers (tensor in, tensor out; and into a caller-owned device buffer)
+    dev = torch.device("cuda:0")
+    di = pkg.Interp1DBuilder.new(torch.as_tensor(yv, device=dev)).build()
+    gd = di.interp_array(torch.as_tensor(q, device=dev))
+    assert tuple(gd.shape) == (nq,)
+    check_equal(gd.cpu().numpy(), ref, "C1 device buffers")
+    buf = torch.full((nq,), -5.0, dtype=torch.float64, device=dev)
+    di.interp_array_into(torch.as_tensor(q, device=dev), buf)
+    check_equal(buf.cpu().numpy(), ref, "C1 device buffers, interp_array_into")
+    # out of range on the index axis: the reference's message and the first-error cut
+    qb = q.copy(); qb[7000] = n - 1 + 1e-9
+    with pytest.raises(pkg.InterpolateError.OutOfBounds, match=r"^x = 1023\.0+1 is not in range") as ei:
+        interp.interp_array(qb)
+    assert ei.value.index == 7000

@@ -1296,8 +1296,44 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
 //    leave as ONE sequential stream of 16-byte vectors (64 * L * sizeof(T) consecutive bytes per batch), whatever L is.
 // Same operations in the same order as Linear / CubicSplineStrategy::interp_into; rows at / after the batch's first
 // failing query (range_check_kernel) are never written.
+// Records in LDS, NS values each, kept as a STRUCTURE OF ARRAYS of 16-byte units (NS * sizeof(T) / 16 arrays, 16-byte
+// stride): a gather of one unit by 64 lanes then spreads over all LDS banks.  Records kept whole -- four doubles, 32 bytes
+// apart -- put every lane on one of four bank groups: the first version of these kernels spent 2.0e8 LDS conflict cycles
+// per 1e8 scalar f64 queries, 0.33 of its 0.67 ms (profiles/r05_lanes_counters.txt); f32 records were 16 bytes already.
+template <class T, int NS>
+struct RecArr {
+  static constexpr int EL = 16 / (int)sizeof(T);
+  static constexpr int NU = NS / EL;
+  static_assert(NS % EL == 0, "whole 16-byte units");
+  using U = typename VecT<T, EL>::type;
+  U* base;
+  uint32_t count;
+  __device__ __forceinline__ void put(uint32_t i, const T (&v)[NS]) const {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      U w;
+#pragma unroll
+      for (int e = 0; e < EL; ++e) w[e] = v[u * EL + e];
+      base[(size_t)u * count + i] = w;
+    }
+  }
+  __device__ __forceinline__ void get(uint32_t i, T (&v)[NS]) const {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const U w = base[(size_t)u * count + i];
+#pragma unroll
+      for (int e = 0; e < EL; ++e) v[u * EL + e] = w[e];
+    }
+  }
+  __host__ __device__ static constexpr size_t bytes(size_t count) { return (size_t)NU * count * 16u; }
+};
 template <class T>
-struct XRec { T xl, dx, r, pad; };   // r = RN(1 / dx), 0 when dx is outside the shared-divisor window
+using XRecs = RecArr<T, 4>;            // {x_l, dx, r = RN(1 / dx) or 0 outside the shared-divisor window, 0} per interval
+template <class T, int STRAT>
+struct TabRecs {                       // cubic {y_l, y_r, a, b}; linear {y_l, m} (padded to a whole unit)
+  static constexpr int NS = STRAT == ST_CUBIC ? 4 : (16 / (int)sizeof(T) > 2 ? 16 / (int)sizeof(T) : 2);
+  using type = RecArr<T, NS>;
+};
 
 template <class T>
 struct DenseLut {
@@ -1380,40 +1416,42 @@ __device__ __forceinline__ LaneAxis<T> stage_lane_axis(unsigned char* smem, size
 
 // interval records {x_l, dx, RN(1 / dx)} of an axis
 template <class T, int TB>
-__device__ __forceinline__ void stage_xrecs(XRec<T>* s_x, const T* knots, uint32_t n) {
+__device__ __forceinline__ void stage_xrecs(const XRecs<T>& X, const T* knots, uint32_t n) {
   for (uint32_t i = threadIdx.x; i + 1u < n; i += TB) {
     const T xl = knots[i], xr = knots[i + 1];
     const SharedDivisor<T> sd = shared_divisor<T>(xr - xl);
-    XRec<T> r;
-    r.xl = xl; r.dx = sd.d; r.r = sd.ok ? sd.r : T(0); r.pad = T(0);
-    s_x[i] = r;
+    const T v[4] = {xl, sd.d, sd.ok ? sd.r : T(0), T(0)};
+    X.put(i, v);
   }
 }
 
 // table records: cubic {y_l, y_r, a, b}, linear {y_l, m}
 template <class T, int STRAT, int TB>
-__device__ __forceinline__ void stage_table_recs(T* s_t, const EvalLanesArgs<T>& A) {
-  constexpr int TR = STRAT == ST_CUBIC ? 4 : 2;
+__device__ __forceinline__ void stage_table_recs(const typename TabRecs<T, STRAT>::type& R, const EvalLanesArgs<T>& A) {
+  constexpr int NS = TabRecs<T, STRAT>::NS;
   const uint32_t L = A.lanes, total = (A.n - 1u) * L;
   for (uint32_t e = threadIdx.x; e < total; e += TB) {
     const T yl = A.data[e], yr = A.data[e + L];
+    T v[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v[k] = T(0);
+    v[0] = yl;
     if (STRAT == ST_CUBIC) {
-      s_t[(size_t)e * TR + 0] = yl;
-      s_t[(size_t)e * TR + 1] = yr;
-      s_t[(size_t)e * TR + 2] = A.ca[e];
-      s_t[(size_t)e * TR + 3] = A.cb[e];
+      v[1] = yr;
+      v[2] = A.ca[e];
+      v[3] = A.cb[e];
     } else {
       const uint32_t i = e / L;
       const T dx = A.knots[i + 1] - A.knots[i];
-      s_t[(size_t)e * TR + 0] = yl;
-      s_t[(size_t)e * TR + 1] = (yr - yl) / dx;           // linear.rs:33, once per record
+      v[1] = (yr - yl) / dx;                              // linear.rs:33, once per record
     }
+    R.put(e, v);
   }
 }
 
 // One query: interval, then the per-query scalar -- t (cubic_spline.rs:818) or (x - x1) (linear.rs:35).
 template <class T, int STRAT>
-__device__ __forceinline__ void lane_query(const LaneAxis<T>& S, const XRec<T>* s_x, int mode, T x, uint32_t& i, T& s0) {
+__device__ __forceinline__ void lane_query(const LaneAxis<T>& S, const XRecs<T>& X, int mode, T x, uint32_t& i, T& s0) {
   T xs = x;
   if (STRAT == ST_CUBIC && mode == EX_PERIODIC) {         // (uniform) cubic_spline.rs:805-809
     const bool inr = (S.k0 <= x) && (x <= S.kn);
@@ -1422,17 +1460,20 @@ __device__ __forceinline__ void lane_query(const LaneAxis<T>& S, const XRec<T>* 
   i = lane_axis_index<T>(S, xs);
   i = NDI_CHK(i, S.n - 1u, BC_INTERVAL);
   if (STRAT == ST_CUBIC) {
-    const XRec<T> xr = s_x[i];
+    T xr[4];
+    X.get(i, xr);
     SharedDivisor<T> sd;
-    sd.d = xr.dx; sd.r = xr.r; sd.ok = xr.r > T(0);
-    s0 = div_shared<T, T>(xs - xr.xl, sd);
+    sd.d = xr[1]; sd.r = xr[2]; sd.ok = xr[2] > T(0);
+    s0 = div_shared<T, T>(xs - xr[0], sd);
   } else {
     s0 = x - S.k[i];
   }
 }
 
 template <class T, int STRAT>
-__device__ __forceinline__ T lane_point(const T* r, T s0) {
+__device__ __forceinline__ T lane_point(const typename TabRecs<T, STRAT>::type& R, uint32_t rec, T s0) {
+  T r[TabRecs<T, STRAT>::NS];
+  R.get(rec, r);
   if (STRAT == ST_CUBIC) {                                // cubic_spline.rs:825-827
     const T yl = r[0], yr = r[1], a = r[2], b = r[3];
     const T c0 = T(1) - s0;
@@ -1445,37 +1486,32 @@ __device__ __forceinline__ T lane_point(const T* r, T s0) {
 template <class T, int STRAT, int QPL, int TB>
 __global__ __launch_bounds__(TB) void eval_scalar_kernel(EvalLanesArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int TR = STRAT == ST_CUBIC ? 4 : 2;
   using QV = typename VecT<T, QPL>::type;
+  using Tab = typename TabRecs<T, STRAT>::type;
   if (A.nq == 0) return;
   const uint32_t tid = threadIdx.x, n = A.n;
   size_t off = 0;
   const LaneAxis<T> S = stage_lane_axis<T, TB>(smem_raw, off, A.knots, n, A.dl);
-  XRec<T>* s_x = reinterpret_cast<XRec<T>*>(smem_raw + off);
+  XRecs<T> X{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), n - 1u};
   if (STRAT == ST_CUBIC) {
-    stage_xrecs<T, TB>(s_x, A.knots, n);
-    off += (size_t)(n - 1u) * sizeof(XRec<T>);
+    stage_xrecs<T, TB>(X, A.knots, n);
+    off += XRecs<T>::bytes(n - 1u);
   }
-  T* s_t = reinterpret_cast<T*>(smem_raw + off);
-  stage_table_recs<T, STRAT, TB>(s_t, A);
+  const Tab R{reinterpret_cast<typename Tab::U*>(smem_raw + off), n - 1u};
+  stage_table_recs<T, STRAT, TB>(R, A);
   __syncthreads();
   unsigned long long limit = *A.first_fail;
   if (limit > A.nq) limit = A.nq;
-  // QPL consecutive queries per lane, vector load / store; the (< QPL) queries behind the last full vector below
-  // `limit` go one per lane at the end
+  // QPL consecutive queries per lane, vector load / store, TWO vectors per thread and trip with the next two in flight
+  // (one vector ahead left the memory system latency-bound: 32 KiB of reads in flight per CU, 3.3 TB/s on the Linear
+  // kernel); the (< QPL) queries behind the last full vector below `limit` go one per thread at the end
   const uint64_t nvec = limit / QPL;
   const uint64_t step = (uint64_t)gridDim.x * TB;
   const QV* qv = reinterpret_cast<const QV*>(A.q);
   QV* ov = reinterpret_cast<QV*>(A.out);
   const uint64_t vlast = nvec ? nvec - 1u : 0u;
-  uint64_t vi = (uint64_t)blockIdx.x * TB + tid;
-  QV nxt = nvec ? qv[vi < nvec ? vi : vlast] : QV(S.k0);  // one vector ahead, clamped (unconditional: countable)
-  for (; vi < nvec; vi += step) {
-    const QV cur = nxt;
-    {
-      const uint64_t vn = vi + step;
-      nxt = qv[vn < nvec ? vn : vlast];
-    }
+  auto loadq = [&](uint64_t v) -> QV { return nvec ? qv[v < nvec ? v : vlast] : QV(S.k0); };   // clamped: unconditional
+  auto eval_vec = [&](const QV& cur) -> QV {
     QV res;
 #pragma unroll
     for (int u = 0; u < QPL; ++u) {
@@ -1483,20 +1519,36 @@ __global__ __launch_bounds__(TB) void eval_scalar_kernel(EvalLanesArgs<T> A) {
       if constexpr (QPL == 1) x = cur; else x = cur[u];
       uint32_t i;
       T s0;
-      lane_query<T, STRAT>(S, s_x, A.mode, x, i, s0);
-      const T r = lane_point<T, STRAT>(s_t + (size_t)i * TR, s0);
+      lane_query<T, STRAT>(S, X, A.mode, x, i, s0);
+      const T r = lane_point<T, STRAT>(R, i, s0);
       if constexpr (QPL == 1) res = r; else res[u] = r;
     }
-    if constexpr (QPL == 1) store_stream<true>(A.out + vi * A.out_stride, res);   // (rows of one value may be strided)
-    else store_stream<true>(ov + vi, res);
+    return res;
+  };
+  auto storeq = [&](uint64_t v, const QV& res) {
+    if constexpr (QPL == 1) store_stream<true>(A.out + v * A.out_stride, res);   // (rows of one value may be strided)
+    else store_stream<true>(ov + v, res);
+  };
+  uint64_t vi = (uint64_t)blockIdx.x * TB + tid;
+  QV n0 = loadq(vi), n1 = loadq(vi + step);
+  for (; vi < nvec; vi += 2u * step) {
+    const QV c0 = n0, c1 = n1;
+    n0 = loadq(vi + 2u * step);
+    n1 = loadq(vi + 3u * step);
+    const QV r0 = eval_vec(c0);
+    storeq(vi, r0);
+    if (vi + step < nvec) {
+      const QV r1 = eval_vec(c1);
+      storeq(vi + step, r1);
+    }
   }
   if constexpr (QPL > 1) {
     const uint64_t qi = nvec * QPL + tid;
     if (blockIdx.x == 0 && qi < limit) {
       uint32_t i;
       T s0;
-      lane_query<T, STRAT>(S, s_x, A.mode, A.q[qi], i, s0);
-      A.out[qi * A.out_stride] = lane_point<T, STRAT>(s_t + (size_t)i * TR, s0);
+      lane_query<T, STRAT>(S, X, A.mode, A.q[qi], i, s0);
+      A.out[qi * A.out_stride] = lane_point<T, STRAT>(R, i, s0);
     }
   }
 }
@@ -1505,27 +1557,30 @@ __global__ __launch_bounds__(TB) void eval_scalar_kernel(EvalLanesArgs<T> A) {
 template <class T, int STRAT, int LC, int TB>
 __global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int TR = STRAT == ST_CUBIC ? 4 : 2;
   constexpr int VN = Wide<T>::N;
   using V = typename VecT<T, VN>::type;
+  using Tab = typename TabRecs<T, STRAT>::type;
   if (A.nq == 0) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, n = A.n;
   const uint32_t L = LC ? (uint32_t)LC : A.lanes;
   size_t off = 0;
   const LaneAxis<T> S = stage_lane_axis<T, TB>(smem_raw, off, A.knots, n, A.dl);
-  XRec<T>* s_x = reinterpret_cast<XRec<T>*>(smem_raw + off);
+  XRecs<T> X{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), n - 1u};
   if (STRAT == ST_CUBIC) {
-    stage_xrecs<T, TB>(s_x, A.knots, n);
-    off += (size_t)(n - 1u) * sizeof(XRec<T>);
+    stage_xrecs<T, TB>(X, A.knots, n);
+    off += XRecs<T>::bytes(n - 1u);
   }
-  T* s_t = reinterpret_cast<T*>(smem_raw + off);
-  stage_table_recs<T, STRAT, TB>(s_t, A);
-  off += (((size_t)(n - 1u) * L * TR * sizeof(T)) + 15u) & ~(size_t)15u;
+  const Tab R{reinterpret_cast<typename Tab::U*>(smem_raw + off), (n - 1u) * L};
+  stage_table_recs<T, STRAT, TB>(R, A);
+  off += Tab::bytes((size_t)(n - 1u) * L);
   T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;
   __syncthreads();
   unsigned long long limit = *A.first_fail;
   if (limit > A.nq) limit = A.nq;
   const bool contig = A.out_stride == (uint64_t)L;
+  // even L: lane j writes its row starting at value (j mod L) -- a plain l = 0, 1, ... order would put the lanes of a
+  // wave on L-element strides, i.e. (for L = 8 doubles) on two bank groups; odd strides spread by themselves
+  const uint32_t rot = (L & 1u) ? 0u : lane % L;
   const uint64_t wstep = (uint64_t)gridDim.x * TB;
   uint64_t base = ((uint64_t)blockIdx.x * (TB / 64) + (tid >> 6)) * 64u;
   T xn = A.q[(base + lane < A.nq) ? base + lane : A.nq - 1u];
@@ -1537,11 +1592,15 @@ __global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
     }
     uint32_t i;
     T s0;
-    lane_query<T, STRAT>(S, s_x, A.mode, x, i, s0);
-    const T* rec = s_t + (size_t)i * L * TR;
+    lane_query<T, STRAT>(S, X, A.mode, x, i, s0);
+    const uint32_t rec0 = i * L;
     T* mine = s_strip + lane * L;
 #pragma unroll
-    for (uint32_t l = 0; l < L; ++l) mine[l] = lane_point<T, STRAT>(rec + l * TR, s0);
+    for (uint32_t k = 0; k < L; ++k) {
+      uint32_t l = k + rot;
+      if (l >= L) l -= L;
+      mine[l] = lane_point<T, STRAT>(R, rec0 + l, s0);
+    }
     __builtin_amdgcn_wave_barrier();                      // LDS operations of one wave execute in order
     const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
     const uint32_t total = nq_here * L;
@@ -2688,17 +2747,19 @@ struct LaneCell {
 };
 
 template <class T>
-__device__ __forceinline__ LaneCell<T> lane_cell(const LaneAxis<T>& SX, const LaneAxis<T>& SY, const XRec<T>* s_xx,
-                                                 const XRec<T>* s_xy, uint32_t ny, uint32_t L, T x, T y) {
+__device__ __forceinline__ LaneCell<T> lane_cell(const LaneAxis<T>& SX, const LaneAxis<T>& SY, const XRecs<T>& XX,
+                                                 const XRecs<T>& XY, uint32_t ny, uint32_t L, T x, T y) {
   const uint32_t xi = NDI_CHK(lane_axis_index<T>(SX, x), SX.n - 1u, BC_CELL_X);
   const uint32_t yi = NDI_CHK(lane_axis_index<T>(SY, y), SY.n - 1u, BC_CELL_Y);
-  const XRec<T> rx = s_xx[xi], ry = s_xy[yi];
+  T rx[4], ry[4];
+  XX.get(xi, rx);
+  XY.get(yi, ry);
   LaneCell<T> c;
   c.o = (xi * ny + yi) * L;
-  c.fx = x - rx.xl;                   // linear.rs:35's (x - x1) of both directions
-  c.fy = y - ry.xl;
-  c.dx.d = rx.dx; c.dx.r = rx.r; c.dx.ok = rx.r > T(0);
-  c.dy.d = ry.dx; c.dy.r = ry.r; c.dy.ok = ry.r > T(0);
+  c.fx = x - rx[0];                   // linear.rs:35's (x - x1) of both directions
+  c.fy = y - ry[0];
+  c.dx.d = rx[1]; c.dx.r = rx[2]; c.dx.ok = rx[2] > T(0);
+  c.dy.d = ry[1]; c.dy.r = ry[2]; c.dy.ok = ry[2] > T(0);
   return c;
 }
 
@@ -2713,18 +2774,18 @@ __device__ __forceinline__ T lane_bilinear(const T* g, uint32_t L, uint32_t rowe
 // stages both axes, their interval records and the grid; returns the LDS offset behind them
 template <class T, int TB>
 __device__ __forceinline__ size_t stage_grid2(unsigned char* smem, const EvalLanes2Args<T>& A, LaneAxis<T>& SX, LaneAxis<T>& SY,
-                                              XRec<T>*& s_xx, XRec<T>*& s_xy, T*& s_g) {
+                                              XRecs<T>& XX, XRecs<T>& XY, T*& s_g) {
   constexpr int VN = Wide<T>::N;
   using V = typename VecT<T, VN>::type;
   size_t off = 0;
   SX = stage_lane_axis<T, TB>(smem, off, A.xk, A.nx, A.dx);
   SY = stage_lane_axis<T, TB>(smem, off, A.yk, A.ny, A.dy);
-  s_xx = reinterpret_cast<XRec<T>*>(smem + off);
-  off += (size_t)(A.nx - 1u) * sizeof(XRec<T>);
-  s_xy = reinterpret_cast<XRec<T>*>(smem + off);
-  off += (size_t)(A.ny - 1u) * sizeof(XRec<T>);
-  stage_xrecs<T, TB>(s_xx, A.xk, A.nx);
-  stage_xrecs<T, TB>(s_xy, A.yk, A.ny);
+  XX = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem + off), A.nx - 1u};
+  off += XRecs<T>::bytes(A.nx - 1u);
+  XY = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem + off), A.ny - 1u};
+  off += XRecs<T>::bytes(A.ny - 1u);
+  stage_xrecs<T, TB>(XX, A.xk, A.nx);
+  stage_xrecs<T, TB>(XY, A.yk, A.ny);
   s_g = reinterpret_cast<T*>(smem + off);
   const uint32_t gelems = A.nx * A.ny * A.lanes;
   if ((gelems % VN) == 0u && (reinterpret_cast<uintptr_t>(A.data) & 15u) == 0u) {
@@ -2745,10 +2806,9 @@ __global__ __launch_bounds__(TB) void eval_scalar2d_kernel(EvalLanes2Args<T> A) 
   if (A.nq == 0) return;
   const uint32_t tid = threadIdx.x;
   LaneAxis<T> SX, SY;
-  XRec<T>* s_xx;
-  XRec<T>* s_xy;
+  XRecs<T> XX, XY;
   T* s_g;
-  stage_grid2<T, TB>(smem_raw, A, SX, SY, s_xx, s_xy, s_g);
+  stage_grid2<T, TB>(smem_raw, A, SX, SY, XX, XY, s_g);
   __syncthreads();
   unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
   if (limit > A.nq) limit = A.nq;
@@ -2759,37 +2819,45 @@ __global__ __launch_bounds__(TB) void eval_scalar2d_kernel(EvalLanes2Args<T> A) 
   const QV* qyv = reinterpret_cast<const QV*>(A.qy);
   QV* ov = reinterpret_cast<QV*>(A.out);
   const uint64_t vlast = nvec ? nvec - 1u : 0u;
-  uint64_t vi = (uint64_t)blockIdx.x * TB + tid;
-  QV nx_ = QV(SX.k0), ny_ = QV(SY.k0);
-  if (nvec) {
-    const uint64_t vc = vi < nvec ? vi : vlast;
-    nx_ = qxv[vc];
-    ny_ = qyv[vc];
-  }
-  for (; vi < nvec; vi += step) {
-    const QV cx = nx_, cy = ny_;
-    {
-      const uint64_t vn = vi + step;
-      const uint64_t vc = vn < nvec ? vn : vlast;
-      nx_ = qxv[vc];
-      ny_ = qyv[vc];
-    }
+  auto eval_vec = [&](const QV& cx, const QV& cy) -> QV {
     QV res;
 #pragma unroll
     for (int u = 0; u < QPL; ++u) {
       T x, y;
       if constexpr (QPL == 1) { x = cx; y = cy; } else { x = cx[u]; y = cy[u]; }
-      const LaneCell<T> c = lane_cell<T>(SX, SY, s_xx, s_xy, ny, 1u, x, y);
+      const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, ny, 1u, x, y);
       const T r = lane_bilinear<T>(s_g + c.o, 1u, ny, c);
       if constexpr (QPL == 1) res = r; else res[u] = r;
     }
-    if constexpr (QPL == 1) store_stream<true>(A.out + vi * A.out_stride, res);
-    else store_stream<true>(ov + vi, res);
+    return res;
+  };
+  auto storeq = [&](uint64_t v, const QV& res) {
+    if constexpr (QPL == 1) store_stream<true>(A.out + v * A.out_stride, res);
+    else store_stream<true>(ov + v, res);
+  };
+  // two vectors of (x, y) queries per thread and trip, the next two in flight (see eval_scalar_kernel)
+  uint64_t vi = (uint64_t)blockIdx.x * TB + tid;
+  QV nx0 = QV(SX.k0), ny0 = QV(SY.k0), nx1 = QV(SX.k0), ny1 = QV(SY.k0);
+  if (nvec) {
+    const uint64_t v0 = vi < nvec ? vi : vlast, v1 = vi + step < nvec ? vi + step : vlast;
+    nx0 = qxv[v0]; ny0 = qyv[v0];
+    nx1 = qxv[v1]; ny1 = qyv[v1];
+  }
+  for (; vi < nvec; vi += 2u * step) {
+    const QV cx0 = nx0, cy0 = ny0, cx1 = nx1, cy1 = ny1;
+    {
+      const uint64_t a = vi + 2u * step, b = vi + 3u * step;
+      const uint64_t v0 = a < nvec ? a : vlast, v1 = b < nvec ? b : vlast;
+      nx0 = qxv[v0]; ny0 = qyv[v0];
+      nx1 = qxv[v1]; ny1 = qyv[v1];
+    }
+    storeq(vi, eval_vec(cx0, cy0));
+    if (vi + step < nvec) storeq(vi + step, eval_vec(cx1, cy1));
   }
   if constexpr (QPL > 1) {
     const uint64_t qi = nvec * QPL + tid;
     if (blockIdx.x == 0 && qi < limit) {
-      const LaneCell<T> c = lane_cell<T>(SX, SY, s_xx, s_xy, ny, 1u, A.qx[qi], A.qy[qi]);
+      const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, ny, 1u, A.qx[qi], A.qy[qi]);
       A.out[qi * A.out_stride] = lane_bilinear<T>(s_g + c.o, 1u, ny, c);
     }
   }
@@ -2803,16 +2871,16 @@ __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
   if (A.nq == 0) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, L = A.lanes;
   LaneAxis<T> SX, SY;
-  XRec<T>* s_xx;
-  XRec<T>* s_xy;
+  XRecs<T> XX, XY;
   T* s_g;
-  const size_t off = stage_grid2<T, TB>(smem_raw, A, SX, SY, s_xx, s_xy, s_g);
+  const size_t off = stage_grid2<T, TB>(smem_raw, A, SX, SY, XX, XY, s_g);
   T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;
   __syncthreads();
   unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
   if (limit > A.nq) limit = A.nq;
   const uint32_t ny = A.ny, rowe = ny * L;
   const bool contig = A.out_stride == (uint64_t)L;
+  const uint32_t rot = (L & 1u) ? 0u : lane % L;
   const uint64_t wstep = (uint64_t)gridDim.x * TB;
   uint64_t base = ((uint64_t)blockIdx.x * (TB / 64) + (tid >> 6)) * 64u;
   T xq, yq;
@@ -2829,9 +2897,13 @@ __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
       xq = A.qx[pc];
       yq = A.qy[pc];
     }
-    const LaneCell<T> c = lane_cell<T>(SX, SY, s_xx, s_xy, ny, L, x, y);
+    const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, ny, L, x, y);
     T* mine = s_strip + lane * L;
-    for (uint32_t l = 0; l < L; ++l) mine[l] = lane_bilinear<T>(s_g + c.o + l, L, rowe, c);
+    for (uint32_t k = 0; k < L; ++k) {      // (even L: rotated start, see eval_lanes_kernel)
+      uint32_t l = k + rot;
+      if (l >= L) l -= L;
+      mine[l] = lane_bilinear<T>(s_g + c.o + l, L, rowe, c);
+    }
     __builtin_amdgcn_wave_barrier();
     const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
     const uint32_t total = nq_here * L;
@@ -2986,6 +3058,10 @@ struct BuildArgs {
   const T* data;  // [n][lanes]
   T* ca;          // [n-1][lanes]  (rows double as scratch for the eliminated rhs)
   T* cb;          // [n-1][lanes]  (periodic: scratch for k1)
+  const T* x;     // [n] knots (FUSED build: dx / up are formed from them on the fly)
+  T left_up0;        // up[0] (FUSED build: the plan's boundary-specific first entry)
+  uint64_t up_len;   // entries of the upper diagonal (FUSED build)
+  T up_last;         // its last entry (boundary-specific, like up[0])
   const T* dx;    // [n-1]
   const T* up;    // [m]
   const T* w;     // [m]
@@ -3053,61 +3129,85 @@ __global__ __launch_bounds__(BLOCK) void spline_dx_up_kernel(const T* x, T* dx, 
   }
 }
 
+// Right-hand side of row i, lane l (rows 0 and n-1: boundary rows :597-670, interior rows :456-471).  FROMX: the knot
+// spacings are formed from the knots themselves (the same subtraction in T the dx array holds) -- the single-launch build
+// of small systems has no dx array.
+template <class T, bool PER_LANE, bool FROMX>
+__device__ __forceinline__ T spline_rhs_at(const BuildArgs<T>& A, uint64_t i, uint64_t l) {
+  const uint64_t n = A.n, L = A.lanes;
+  const T two = T(2), three = T(3);
+  auto dxa = [&](uint64_t j) -> T { return FROMX ? A.x[j + 1] - A.x[j] : A.dx[j]; };
+  const T* y = A.data + l;
+  int lk = A.left_kind, rk = A.right_kind;
+  T lval = A.left_val, rval = A.right_val;
+  if (PER_LANE) {
+    const uint32_t cls = A.lane_cls[l];
+    lk = (int)(cls & 3u);
+    rk = (int)(cls >> 2);
+    lval = A.lane_lval[l];
+    rval = A.lane_rval[l];
+  }
+  T r;
+  if (i == 0) {
+    const T y0 = y[0], y1 = y[L], y2 = y[2 * L];
+    const T dx0 = dxa(0), dx1 = dxa(1);
+    if (lk == 0) r = (A.nkL_tmp1 * (y1 - y0) / dx0 + A.dx0_sq * (y2 - y1) / dx1) / A.nkL_d;
+    else if (lk == 1) r = lval;
+    else if (lk == 2) r = three * (y1 - y0) - lval * A.dx0_sq / two;
+    else r = ((y1 - y0) / dx0) * two;                                  // parabola rows (:592), n == 3 only
+  } else if (i + 1 == n) {
+    const T ym = y[(n - 3) * L], yc = y[(n - 2) * L], yp = y[(n - 1) * L];
+    const T dxl = dxa(n - 2), dxl2 = dxa(n - 3);
+    if (rk == 0) r = (A.dxl_sq * (yc - ym) / dxl2 + A.nkR_tmp1 * (yp - yc) / dxl) / A.nkR_d;
+    else if (rk == 1) r = rval;
+    else if (rk == 2) r = three * (yp - yc) + rval * A.dxl_sq / two;
+    else r = ((yp - yc) / dxl) * two;                                  // parabola rows (:595)
+  } else {
+    const T a0 = y[(i - 1) * L], a1 = y[i * L], a2 = y[(i + 1) * L];
+    const T dxn = dxa(i), dxn_1 = dxa(i - 1);
+    if (PER_LANE && lk == 3) r = (((a2 - a1) / dxa(1)) * dxa(0) + ((a1 - a0) / dxa(0)) * dxa(1)) * three;  // :593-594
+    else r = three * (dxn * (a1 - a0) / dxn_1 + dxn_1 * (a2 - a1) / dxn);
+  }
+  return r;
+}
+
 template <class T, bool PER_LANE>
 __global__ __launch_bounds__(BLOCK) void spline_rhs_kernel(BuildArgs<T> A) {
   const uint64_t n = A.n, L = A.lanes;
-  const T two = T(2), three = T(3);
   const uint64_t total = n * L;
   for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
     const uint64_t i = e / L, l = e - i * L;
-    const T* y = A.data + l;
-    int lk = A.left_kind, rk = A.right_kind;
-    T lval = A.left_val, rval = A.right_val;
-    if (PER_LANE) {
-      const uint32_t cls = A.lane_cls[l];
-      lk = (int)(cls & 3u);
-      rk = (int)(cls >> 2);
-      lval = A.lane_lval[l];
-      rval = A.lane_rval[l];
-    }
-    T r;
-    if (i == 0) {
-      const T y0 = y[0], y1 = y[L], y2 = y[2 * L];
-      const T dx0 = A.dx[0], dx1 = A.dx[1];
-      if (lk == 0) r = (A.nkL_tmp1 * (y1 - y0) / dx0 + A.dx0_sq * (y2 - y1) / dx1) / A.nkL_d;
-      else if (lk == 1) r = lval;
-      else if (lk == 2) r = three * (y1 - y0) - lval * A.dx0_sq / two;
-      else r = ((y1 - y0) / dx0) * two;                                  // parabola rows (:592), n == 3 only
-    } else if (i + 1 == n) {
-      const T ym = y[(n - 3) * L], yc = y[(n - 2) * L], yp = y[(n - 1) * L];
-      const T dxl = A.dx[n - 2], dxl2 = A.dx[n - 3];
-      if (rk == 0) r = (A.dxl_sq * (yc - ym) / dxl2 + A.nkR_tmp1 * (yp - yc) / dxl) / A.nkR_d;
-      else if (rk == 1) r = rval;
-      else if (rk == 2) r = three * (yp - yc) + rval * A.dxl_sq / two;
-      else r = ((yp - yc) / dxl) * two;                                  // parabola rows (:595)
-    } else {
-      const T a0 = y[(i - 1) * L], a1 = y[i * L], a2 = y[(i + 1) * L];
-      const T dxn = A.dx[i], dxn_1 = A.dx[i - 1];
-      if (PER_LANE && lk == 3) r = (((a2 - a1) / A.dx[1]) * A.dx[0] + ((a1 - a0) / A.dx[0]) * A.dx[1]) * three;  // :593-594
-      else r = three * (dxn * (a1 - a0) / dxn_1 + dxn_1 * (a2 - a1) / dxn);
-    }
+    const T r = spline_rhs_at<T, PER_LANE, false>(A, i, l);
     if (A.rfull) A.rfull[e] = r;                 // blocked sweeps: one array for all n rows
     else if (i + 1 == n) A.cb[(n - 2) * L + l] = r;
     else A.ca[i * L + l] = r;
   }
 }
 
-template <class T, bool PER_LANE, bool KOUT = false>
+// FUSED (the single-launch build of small systems: the reference's (100, 5), 1024 x 8, ...): no spline_rhs_kernel /
+// spline_dx_up_kernel passes before this one -- the right-hand sides are formed here row by row (spline_rhs_at, the same
+// operations), dx / up come from the knots; the eliminated right-hand sides still park in the `a` table.  Three launches,
+// a temporary plan buffer and two stream-order dependencies become one launch.
+template <class T, bool PER_LANE, bool KOUT = false, bool FUSED = false>
 __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A) {
   const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= A.lanes) return;
   const uint64_t n = A.n, L = A.lanes;
+  auto dx_at = [&](uint64_t i) -> T { return FUSED ? A.x[i + 1] - A.x[i] : A.dx[i]; };
+  auto up_at = [&](uint64_t i) -> T {   // (i >= 1; row 0's entry is the plan's up0)
+    if (!FUSED) return A.up[i];
+    return (i + 1 == A.up_len) ? A.up_last : A.x[i] - A.x[i - 1];
+  };
+  auto rhs_row = [&](uint64_t i, const T* sa_row) -> T {
+    if (FUSED) return spline_rhs_at<T, PER_LANE, true>(A, i, l);
+    return *sa_row;
+  };
   const T* y = A.data + l;
   T* sa = A.ca + l;
   T* sb = A.cb + l;
   const T* w = A.w;
   const T* midp = A.midp;
-  T up0 = A.up[0], w_last = A.w[n - 1], mid_last = A.midp[n - 1];
+  T up0 = FUSED ? A.left_up0 : A.up[0], w_last = A.w[n - 1], mid_last = A.midp[n - 1];
   if (PER_LANE) {
     const uint32_t cls = A.lane_cls[l];
     const int lk = (int)(cls & 3u), rk = (int)(cls >> 2);
@@ -3117,12 +3217,13 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
     w_last = A.wl[lk * 4 + rk];
     mid_last = A.midl[lk * 4 + rk];
   }
-  const T rhs_last = sb[(n - 2) * L];
+  const T rhs_last = FUSED ? spline_rhs_at<T, PER_LANE, true>(A, n - 1, l) : sb[(n - 2) * L];
   // The per-row factors (w, up, mid', dx) are fetched per block together with the rows, *before* the block's
   // stores: they cannot be scalar loads (the compiler cannot prove they do not alias the tables being written)
   // and a load placed after a store waits for that store (vmcnt is in-order and counts stores on CDNA4).
   // ---- forward elimination of the right-hand sides, rows 1 .. n-2 (row 0 stays as it is)
-  T r_prev = sa[0];
+  T r_prev = rhs_row(0, sa);
+  if (FUSED) sa[0] = r_prev;            // (the back substitution reads row 0's right-hand side from the table)
   T rn[SB], wn[SB];
   {
     const uint64_t left0 = n - 2;
@@ -3130,7 +3231,7 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
       if (b < cnt0) {
-        rn[b] = sa[(1 + (uint64_t)b) * L];
+        rn[b] = rhs_row(1 + (uint64_t)b, sa + (1 + (uint64_t)b) * L);
         wn[b] = w[1 + b];
       }
     }
@@ -3152,7 +3253,7 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
           if (b < cntn) {
-            rn[b] = sa[(j0 + b) * L];
+            rn[b] = rhs_row(j0 + b, sa + (j0 + b) * L);
             wn[b] = w[j0 + b];
           }
         }
@@ -3182,9 +3283,9 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
         const uint64_t i = hi0 - 1 - b;
         ri_next[b] = sa[i * L];
         yl_next[b] = y[i * L];
-        up_next[b] = (i == 0) ? up0 : A.up[i];
+        up_next[b] = (i == 0) ? up0 : up_at(i);
         mid_next[b] = midp[i];
-        dx_next[b] = A.dx[i];
+        dx_next[b] = dx_at(i);
       }
     }
   }
@@ -3209,9 +3310,9 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
             const uint64_t i = hn - 1 - b;
             ri_next[b] = sa[i * L];
             yl_next[b] = y[i * L];
-            up_next[b] = (i == 0) ? up0 : A.up[i];
+            up_next[b] = (i == 0) ? up0 : up_at(i);
             mid_next[b] = midp[i];
-            dx_next[b] = A.dx[i];
+            dx_next[b] = dx_at(i);
           }
         }
       }

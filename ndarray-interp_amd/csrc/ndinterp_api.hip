@@ -49,14 +49,25 @@ struct DeviceGuard {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool owned = true;   // false: a view into another allocation (adopt): released by forgetting it
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    owned = true;
+  }
+  // A slice of a larger allocation that outlives this buffer (small handles keep all their tables in ONE allocation:
+  // every hipMalloc costs as much as the kernels of a small build).  reserve() beyond the slice falls back to an
+  // allocation of its own.
+  void adopt(void* ptr, size_t nbytes) {
+    release();
+    p = ptr;
+    bytes = nbytes;
+    owned = false;
   }
   void reserve(size_t need) {
     if (need <= bytes) return;
@@ -801,6 +812,42 @@ struct BuildClock {
   }
 };
 
+// Temporaries of small builds: one device buffer and one pinned staging buffer per host thread and device, grown on
+// demand and kept (a build of (100, 5) spends more time in hipMalloc / hipFree / pageable copies than in its kernel).
+// Deliberately never freed: thread-exit and process-exit order against the HIP runtime is not ours to rely on.
+struct BuildScratch {
+  std::map<int, std::pair<void*, size_t>> dev;   // device ordinal -> (buffer, bytes)
+  void* pin = nullptr;
+  size_t pin_bytes = 0;
+  void* device_buf(int device, size_t need) {
+    auto& e = dev[device];
+    if (need > e.second) {
+      if (e.first) (void)hipFree(e.first);
+      e = {nullptr, 0};
+      const size_t cap = std::max<size_t>(need, 64 * 1024);
+      NDI_HIP(hipMalloc(&e.first, cap));
+      e.second = cap;
+    }
+    return e.first;
+  }
+  void* pinned(size_t need) {
+    if (need > pin_bytes) {
+      if (pin) (void)hipHostFree(pin);
+      pin = nullptr;
+      pin_bytes = 0;
+      const size_t cap = std::max<size_t>(need, 64 * 1024);
+      NDI_HIP(hipHostMalloc(&pin, cap, hipHostMallocPortable));
+      pin_bytes = cap;
+    }
+    return pin;
+  }
+};
+static BuildScratch& build_scratch() {
+  static thread_local BuildScratch* p = nullptr;
+  if (!p) p = new BuildScratch();
+  return *p;
+}
+
 // What makes two handles replicas of ONE interpolator beyond element type and lanes: knot count and values,
 // strategy, extrapolation mode.  (Data and coefficient tables live on the devices and are not compared.)
 static uint64_t fnv1a(uint64_t h, const void* p, size_t bytes) {
@@ -831,6 +878,7 @@ struct Interp1DImpl final : Interp1DBase {
   int strategy = NDI_LINEAR;
   int mode = EX_NO;
   uint64_t n = 0;
+  DevBuf arena;   // small handles: ONE allocation behind pyr.buf / data / ca / cb / ck (create1d); declared first: freed last
   DevicePyramid<T> pyr;
   DevBuf data, ca, cb;
   DevBuf ck;   // the spline's derivatives k [n][lanes]: kept by builds whose {y, k} fit LDS (eval_fused_kernel, TLDS == 2)
@@ -914,7 +962,10 @@ struct Interp1DImpl final : Interp1DBase {
     static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
     static const int once = ShortKnobs::env("NDI_SPLINE_KEEP_K", 1);
     const int keep = tune_live ? ShortKnobs::env("NDI_SPLINE_KEEP_K", 1) : once;
-    if (!keep || lanes > 2048 || fused_lds_bytes(false, 256, 2) > FUSED_LDS_LIMIT) return nullptr;
+    if (!keep || lanes > 2048 || fused_lds_bytes(false, 256, 2) > FUSED_LDS_LIMIT) {
+      ck.release();   // (a slice of the handle's arena may have been set aside: ck.p != nullptr means "k was kept")
+      return nullptr;
+    }
     ck.reserve((size_t)n * lanes * sizeof(T));
     return ck.as<T>();
   }
@@ -947,6 +998,48 @@ struct Interp1DImpl final : Interp1DBase {
     const bool blocked = (P.mode == SPLINE_GENERAL || P.mode == SPLINE_PERIODIC) && n >= 16 &&
                          !(d.build_flags & NDI_BUILD_REFERENCE_ORDER) &&
                          (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256));
+    // Small systems (the reference's (100, 5); 1024 x 8; ...): ONE launch -- right-hand sides, elimination, back
+    // substitution and the a / b epilogue in spline_build_general_kernel<FUSED>, dx / up formed from the resident knots;
+    // the x-only factors w, mid' travel through a kept pinned buffer into a kept device buffer: no allocation, no free,
+    // no status read-back (only the periodic build has one).  Same operations as the three-kernel form: bit-identical.
+    // NDI_SPLINE_FUSED_SMALL=0: A/B.
+    static const int small_env = ShortKnobs::env("NDI_SPLINE_FUSED_SMALL", 1);
+    if (small_env && P.mode == SPLINE_GENERAL && !blocked && (uint64_t)n * lanes <= (1u << 17)) {
+      BuildScratch& bs = build_scratch();
+      const size_t plan_b = 2 * (size_t)n * sizeof(T);
+      T* hp = static_cast<T*>(bs.pinned(plan_b));
+      T* dp = static_cast<T*>(bs.device_buf(device, plan_b));
+      std::memcpy(hp, P.w.data(), (size_t)n * sizeof(T));
+      std::memcpy(hp + n, P.midp.data(), (size_t)n * sizeof(T));
+      NDI_HIP(hipMemcpyAsync(dp, hp, plan_b, hipMemcpyHostToDevice, nullptr));
+      BuildArgs<T> A{};
+      A.data = data.as<T>();
+      A.ca = ca.as<T>();
+      A.cb = cb.as<T>();
+      A.x = pyr.view.lv0;
+      A.w = dp;
+      A.midp = dp + n;
+      A.up_len = P.up.size();
+      A.left_up0 = P.up.front();
+      A.up_last = P.up.back();
+      A.n = n;
+      A.lanes = lanes;
+      A.left_kind = P.left_kind;
+      A.right_kind = P.right_kind;
+      A.left_val = P.left_val;
+      A.right_val = P.right_val;
+      A.nkL_tmp1 = P.nkL_tmp1; A.nkL_d = P.nkL_d;
+      A.nkR_tmp1 = P.nkR_tmp1; A.nkR_d = P.nkR_d;
+      A.dx0_sq = P.dx0_sq; A.dxl_sq = P.dxl_sq;
+      A.kout = reserve_k();
+      const unsigned grid1 = (unsigned)((lanes + 63) / 64);
+      if (A.kout) hipLaunchKernelGGL((spline_build_general_kernel<T, false, true, true>), dim3(grid1), dim3(64), 0, (hipStream_t) nullptr, A);
+      else hipLaunchKernelGGL((spline_build_general_kernel<T, false, false, true>), dim3(grid1), dim3(64), 0, (hipStream_t) nullptr, A);
+      NDI_HIP(hipGetLastError());
+      NDI_HIP(hipStreamSynchronize(nullptr));   // the tables are complete when create() returns: any stream may read them
+      clk.mark("  fused small build");
+      return NDI_OK;
+    }
     const bool per = P.mode == SPLINE_PERIODIC;
     const uint64_t rows = per ? n - 2 : n;   // order of the system the two sweeps run over
     uint64_t S = 64;
@@ -1175,7 +1268,7 @@ struct Interp1DImpl final : Interp1DBase {
 
   // LDS footprint of eval_scalar_kernel / eval_lanes_kernel: [knots | dense index | interval records | table records | strips]
   size_t lanes_lds_bytes(unsigned tb) const {
-    const size_t tr = strategy == NDI_CUBIC_SPLINE ? 4 : 2;
+    const size_t tr = strategy == NDI_CUBIC_SPLINE ? 4 : std::max<size_t>(2, 16 / sizeof(T));   // (whole 16-byte units)
     size_t b = ((size_t)n * sizeof(T) + 15) & ~(size_t)15;
     b += pyr.dlut_bytes;
     if (strategy == NDI_CUBIC_SPLINE) b += (size_t)(n - 1) * 4 * sizeof(T);
@@ -2173,6 +2266,28 @@ static ndi_status create1d(const ndi_interp1d_desc& d, Interp1DBase** out) {
   if (d.n > MAX_KNOTS) return fail(NDI_UNSUPPORTED, "more than %llu knots", (unsigned long long)MAX_KNOTS);
   if (!d.data) return fail(NDI_BAD_ARG, "null data pointer");
   clk.mark("validate");
+  {   // small handles: one allocation for the knot pyramid, the data and the spline's tables (a / b / k)
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    uint64_t block = 1;
+    while ((uint64_t)64 * block < d.n) block *= 2;
+    const size_t pyr_b = al((d.n + (d.n + block - 1) / block) * sizeof(T));
+    const size_t data_b = al((size_t)d.n * d.lanes * sizeof(T));
+    const size_t tab_b = d.strategy == NDI_CUBIC_SPLINE ? al((size_t)(d.n - 1) * d.lanes * sizeof(T)) : 0;
+    const size_t k_b = (d.strategy == NDI_CUBIC_SPLINE && 2 * data_b <= FUSED_LDS_LIMIT) ? data_b : 0;
+    const size_t total = pyr_b + data_b + 2 * tab_b + k_b;
+    static const int arena_env = ShortKnobs::env("NDI_HANDLE_ARENA", 1);   // A/B
+    if (arena_env && total <= ((size_t)1 << 20)) {
+      h->arena.reserve(total);
+      char* p0 = static_cast<char*>(h->arena.p);
+      h->pyr.buf.adopt(p0, pyr_b);
+      h->data.adopt(p0 + pyr_b, data_b);
+      if (tab_b) {
+        h->ca.adopt(p0 + pyr_b + data_b, tab_b);
+        h->cb.adopt(p0 + pyr_b + data_b + tab_b, tab_b);
+      }
+      if (k_b) h->ck.adopt(p0 + pyr_b + data_b + 2 * tab_b, k_b);
+    }
+  }
   h->pyr.upload(x.data(), d.n);
   clk.mark("knot pyramid");
   const size_t bytes = (size_t)d.n * d.lanes * sizeof(T);

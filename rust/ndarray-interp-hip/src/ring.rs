@@ -18,8 +18,27 @@ use crate::strategies::{per_thread_stream, DeviceTables1D, DeviceTables2D};
 /// `hipEvent_t` recorded on the consumer's own stream otherwise (the library waits for it before the slot is reused).
 pub type Chunk = ffi::ndi_ring_chunk;
 
+/// The consumer closure plus the payload of a panic it raised.  A panic must not unwind across the `extern "C"`
+/// frame of the library (undefined behaviour / process abort): the trampoline catches it, parks the payload here, stops
+/// calling the closure for the remaining chunks (the library keeps producing them into the ring; nobody looks at them)
+/// and the panic is resumed on the Rust side once `ndi_interp{1,2}d_eval_ring` has returned.
+struct Bridge<F> {
+    consume: F,
+    panic: Option<Box<dyn std::any::Any + Send + 'static>>,
+}
+
 unsafe extern "C" fn trampoline<F: FnMut(&Chunk) -> *mut c_void>(user: *mut c_void, c: *const Chunk) -> *mut c_void {
-    (*(user as *mut F))(&*c)
+    let bridge = &mut *(user as *mut Bridge<F>);
+    if bridge.panic.is_some() {
+        return std::ptr::null_mut();
+    }
+    match std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| (bridge.consume)(&*c))) {
+        Ok(ev) => ev,
+        Err(payload) => {
+            bridge.panic = Some(payload);
+            std::ptr::null_mut()
+        }
+    }
 }
 
 fn finish<T: NumCast + Debug>(st: i32, info: &ffi::ndi_oob_info, pretty: bool) -> Result<(), InterpolateError> {
@@ -48,7 +67,7 @@ pub fn interp_array_chunks_1d<T, Sq, Dq, F>(
     xs: &ArrayBase<Sq, Dq>,
     chunk: usize,
     n_slots: u32,
-    mut consume: F,
+    consume: F,
 ) -> Result<(), InterpolateError>
 where
     T: NumCast + Copy + Debug + 'static,
@@ -66,6 +85,7 @@ where
         async_launch: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
+    let mut bridge = Bridge { consume, panic: None };
     let st = unsafe {
         ffi::ndi_interp1d_eval_ring(
             dev.h,
@@ -73,11 +93,14 @@ where
             xs.len() as u64,
             &ring,
             Some(trampoline::<F>),
-            &mut consume as *mut F as *mut c_void,
+            &mut bridge as *mut Bridge<F> as *mut c_void,
             &opts,
             &mut info,
         )
     };
+    if let Some(payload) = bridge.panic.take() {
+        std::panic::resume_unwind(payload); // the consumer's panic, outside the C frames
+    }
     finish::<T>(st, &info, true)
 }
 
@@ -88,7 +111,7 @@ pub fn interp_array_chunks_2d<T, Sqx, Sqy, Dq, F>(
     ys: &ArrayBase<Sqy, Dq>,
     chunk: usize,
     n_slots: u32,
-    mut consume: F,
+    consume: F,
 ) -> Result<(), InterpolateError>
 where
     T: NumCast + Copy + Debug + 'static,
@@ -108,6 +131,7 @@ where
         async_launch: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
+    let mut bridge = Bridge { consume, panic: None };
     let st = unsafe {
         ffi::ndi_interp2d_eval_ring(
             dev.h,
@@ -116,10 +140,13 @@ where
             xs.len() as u64,
             &ring,
             Some(trampoline::<F>),
-            &mut consume as *mut F as *mut c_void,
+            &mut bridge as *mut Bridge<F> as *mut c_void,
             &opts,
             &mut info,
         )
     };
+    if let Some(payload) = bridge.panic.take() {
+        std::panic::resume_unwind(payload);
+    }
     finish::<T>(st, &info, false)
 }

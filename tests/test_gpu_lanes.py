@@ -148,7 +148,7 @@ def test_lanes_1d_auto_takes_the_bench_shapes(pkg, capfd):
         x = knots("rand", n, rng, dt)
         y = rng.uniform(0, 1, (n, L)).astype(dt)
         it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)) \
-            .strategy(pkg.CubicSpline.new()).build()
+            .strategy(pkg.CubicSpline.new().reference_order(True)).build()   # (4096 x 8 would take the blocked build)
         q = torch.as_tensor(rng.uniform(x[0], x[-1], Q).astype(dt), device=dev)
         os.environ["NDI_TRACE_PLAN"] = "1"
         capfd.readouterr()

@@ -297,6 +297,10 @@ SHAPES_1D = [  # (n, L, Q): covers flat VEC=1 / flat vector / rows U=1,2,4 and r
     (5, 1, 1000), (100, 1, 10000), (1024, 1, 10000), (64, 3, 777), (64, 4, 1000), (33, 6, 501), (17, 62, 300),
     (300, 512, 2000), (300, 514, 1500), (129, 1024, 3000), (100, 1026, 1000), (257, 2048, 4099), (64, 4096, 2500),
     (40, 6144, 700), (9, 8200, 300),
+    # very long rows: 65536 / 65540 lanes = 16 whole 256 x 8-vector segments per row (f64; f32: 8) and a
+    # ragged one -- gridDim.y walks the segments of eval_rows_kernel / eval_bucketed_kernel; 131072 lanes > the 64-segment
+    # cap of gridDim.y for f64 U = 8 (the kernels stride over the segments)
+    (7, 65536, 120), (6, 65540, 90), (5, 131072 + 64, 40),
 ]
 
 

@@ -2,7 +2,7 @@
 x-only plan on the host, the Thomas kernels -- next to the single-thread CPU port (oracle.cubic_build), for the shapes
 VERDICT r3 names: many knots with scalar / narrow data, the reference's (100, 5), and C2.
 
-    python tools/build_probe.py > profiles/r04_build_probe.jsonl
+    python tools/build_probe.py > profiles/r05_build_probe.jsonl
 """
 import json
 import os
@@ -55,6 +55,27 @@ for n, L in ((100, 5), (4096, 8), (100_000, 1), (1_000_000, 1), (1_000_000, 8), 
         build_host()
         rec[name + "_create_host_arrays_ms"] = round(med(build_host) * 1e3, 3)
         rec[name + "_create_device_arrays_ms"] = round(med(build_dev) * 1e3, 3)
+        # the time INSIDE ndi_interp1d_create alone (device-resident arrays; the mirror's validation and object
+        # plumbing around it is what the two numbers above add): median of 9 bare C calls
+        import ctypes as C
+        cap = pkg._capi
+        d = cap.Interp1DDesc()
+        d.dtype, d.strategy, d.extrapolate, d.device = cap.F64, cap.CUBIC_SPLINE, 0, 0
+        d.n, d.lanes, d.x_len = n, L, n
+        d.x, d.data, d.memspace, d.validate = xd.data_ptr(), ddata.data_ptr(), cap.MEM_DEVICE, 0
+        d.periodic = int(name == "periodic")
+        kind = {"not_a_knot": cap.BC_NOT_A_KNOT, "natural": cap.BC_NATURAL, "periodic": cap.BC_NOT_A_KNOT}[name]
+        d.left = cap.Boundary(kind, 0.0); d.right = cap.Boundary(kind, 0.0)
+        ts = []
+        for _ in range(9):
+            h = C.c_void_p()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = cap.lib().ndi_interp1d_create(C.byref(d), C.byref(h))
+            ts.append(time.perf_counter() - t0)
+            assert st == 0, cap.last_error()
+            cap.lib().ndi_interp1d_destroy(h)
+        rec[name + "_c_call_ms"] = round(float(np.median(ts)) * 1e3, 3)
         if name == "not_a_knot":
             cpu = med(lambda: oracle.cubic_build(x, y), reps=3)
             rec["cpu_port_1_thread_ms"] = round(cpu * 1e3, 3)

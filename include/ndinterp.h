@@ -92,7 +92,8 @@ typedef enum ndi_path { NDI_PATH_AUTO = 0, NDI_PATH_GATHER = 1, NDI_PATH_BUCKETE
  * The serial per-lane kernels evaluate thomas (:678-721) in the reference's operation order without contraction: the
  * a / b tables are BIT-IDENTICAL to the reference's.  For narrow trailing axes on many knots (n >= 2048 and
  * lanes <= 256: scalar data on 1e5-1e6 knots, 8 lanes on 4096) that would be one or two wavefronts doing 2n dependent
- * steps, so by default such builds take blocked sweeps: both first-order recurrences are cut into blocks and
+ * steps, so by default such builds -- on axes whose neighbouring knot spacings differ by less than 1e3 (f32) / 1e9
+ * (f64); wilder axes keep the serial kernels -- take blocked sweeps: both first-order recurrences are cut into blocks and
  * re-associated (back substitution as r'/mid' + (-up/mid') k).  Every coefficient then agrees with the reference's to
  * within 1e-12 (f64) / 1e-5 (f32) of the larger of: the magnitudes of the table entries within 32 rows of it, and the
  * interval's |dy| -- errors do not travel (the recurrences' multipliers are <= 1/2 in magnitude) -- and evaluated
@@ -175,7 +176,17 @@ typedef struct ndi_eval_opts {
   int32_t async_launch; /* != 0 (device out only): enqueue and return; fetch the batch
                            status later with ndi_interp{1,2}d_finish on the same stream (from the
                            same host thread); the query array(s) must stay valid until then */
+  int32_t flags;        /* ndi_eval_flags */
+  int32_t reserved;     /* 0 */
 } ndi_eval_opts;
+
+/* NDI_EVAL_FRESH_OUTPUT: the output buffer was allocated for this call and is dropped if the call fails -- what
+ * Interp1D::interp_array / Interp2D::interp_array do (src/interp1d/mod.rs:197-211: `zeros(..)`, `?` on Err).  The
+ * library may then write rows at / after the first failing query; status, index and value of the failure are reported as
+ * always.  Without the flag (interp_array_into semantics: a caller-owned buffer) rows at / after the first failing query
+ * are left untouched, as the reference's serial loop leaves them (:334-342) -- which costs the short-row kernels a
+ * pre-pass over the queries (8-16 bytes per query, a quarter of the time of a scalar batch). */
+typedef enum ndi_eval_flags { NDI_EVAL_DEFAULT = 0, NDI_EVAL_FRESH_OUTPUT = 1 } ndi_eval_flags;
 
 /* ---- build ------------------------------------------------------------------ */
 ndi_status ndi_interp1d_create(const ndi_interp1d_desc* desc, ndi_interp1d** out);

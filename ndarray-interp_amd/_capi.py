@@ -24,6 +24,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 LINEAR, CUBIC_SPLINE = 0, 1
 BC_NOT_A_KNOT, BC_NATURAL, BC_CLAMPED, BC_FIRST_DERIV, BC_SECOND_DERIV = range(5)
 BUILD_DEFAULT, BUILD_REFERENCE_ORDER = 0, 1
+EVAL_DEFAULT, EVAL_FRESH_OUTPUT = 0, 1
 PATH_AUTO, PATH_GATHER, PATH_BUCKETED = 0, 1, 2
 PATH_NAMES = {0: "auto", 1: "gather", 2: "bucketed"}
 
@@ -59,7 +60,7 @@ class OobInfo(C.Structure):
 
 class EvalOpts(C.Structure):
     _fields_ = [("q_memspace", C.c_int32), ("out_memspace", C.c_int32), ("stream", C.c_void_p),
-                ("path", C.c_int32), ("async_launch", C.c_int32)]
+                ("path", C.c_int32), ("async_launch", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Profile(C.Structure):

@@ -691,6 +691,18 @@ __device__ __forceinline__ V div_shared(V n, const SharedDivisor<T>& s) {
   if (__builtin_expect(!(s.ok & nums_in_window(n)), 0)) q = n / s.d;   // outside the window: the IEEE division
   return q;
 }
+// The same quotient without the branch: `ok` tells the caller whether the result is the correctly rounded one; when it
+// is not (divisor or numerator outside the exponent window) the caller redoes that division with the IEEE instruction
+// sequence -- once, behind everything else, so that several independent quotients can be formed in straight-line code.
+template <class T>
+__device__ __forceinline__ T div_shared_fast(T n, const SharedDivisor<T>& s, bool& ok) {
+  const T q0 = n * s.r;
+  const T e0 = __builtin_fma(-q0, s.d, n);
+  const T q1 = __builtin_fma(e0, s.r, q0);
+  const T e1 = __builtin_fma(-q1, s.d, n);
+  ok = s.ok & nums_in_window(n);
+  return __builtin_fma(e1, s.r, q1);
+}
 // Linear::calc_frac (linear.rs:29-36) with the divisor's reciprocal shared across the row
 template <class T, class V>
 __device__ __forceinline__ V frac_shared(T x1, V y1, const SharedDivisor<T>& dx, V y2, T x) {
@@ -1355,8 +1367,24 @@ struct EvalLanesArgs {
   uint64_t nq, out_stride;
   uint32_t lanes;
   int mode;              // ExtrapMode
-  const unsigned long long* first_fail;
+  unsigned long long* first_fail;
+  int check;             // 1: no range pre-pass ran (NDI_EVAL_FRESH_OUTPUT): the kernel tests every query itself, records
+                         //    the lowest failing index and evaluates all rows; 0: *first_fail is final, rows at / after it
+                         //    are not written
 };
+
+// The failure condition of a query (Interp1D::is_in_range, interp1d/mod.rs:384-386; NaN with extrapolation: the
+// reference panics, vector_extensions.rs:83-84) -- range_check_kernel's test, for kernels that check on the fly.
+template <class T>
+__device__ __forceinline__ bool lane_query_fails(T x, T k0, T kn, int mode) {
+  const bool inr = (k0 <= x) && (x <= kn);
+  if (mode == EX_NO) return !inr;
+  if (mode == EX_PERIODIC && !inr) {           // +-inf wraps to NaN, as in locate_slice
+    const T xs = rem_euclid_t(x - k0, kn - k0) + k0;
+    return !(xs == xs);
+  }
+  return !(x == x);
+}
 
 // LDS-resident state of the branch-free search
 template <class T>
@@ -1367,6 +1395,20 @@ struct LaneAxis {
   T k0, kn, scale, gfac; // gfac = (n - 1) / (kn - k0): the guess's factor (vector_extensions.rs:70-90)
 };
 
+constexpr uint32_t LANE_SENTINELS = 8;   // +inf entries staged behind the knots: k[lo + j] needs no bound for j < maxk <= 8
+
+// how many of k[lo .. lo + MK) are <= x: MK independent LDS reads issued together, then MK compares
+template <class T, int MK>
+__device__ __forceinline__ uint32_t knots_le(lds_ptr<T> k, uint32_t lo, T x) {
+  T v[MK];
+#pragma unroll
+  for (int j = 0; j < MK; ++j) v[j] = k[lo + j];
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < MK; ++j) c += (v[j] <= x) ? 1u : 0u;
+  return c;
+}
+
 // the unique i with k[i] <= x < k[i+1], clamped to [0, n-2]; NaN -> 0
 template <class T>
 __device__ __forceinline__ uint32_t lane_axis_index(const LaneAxis<T>& S, T x) {
@@ -1376,12 +1418,14 @@ __device__ __forceinline__ uint32_t lane_axis_index(const LaneAxis<T>& S, T x) {
     f = fmin(f, T(S.m - 1u));
     const uint32_t lo = S.lut[(uint32_t)f];
     uint32_t cnt = lo;
-    for (uint32_t j = 0; j < S.maxk; ++j) {               // (uniform trip count)
-      const uint32_t idx = lo + j < S.n - 1u ? lo + j : S.n - 1u;
-      cnt += (S.k[idx] <= x) ? 1u : 0u;
+    switch (S.maxk) {                                     // (uniform) knots of later buckets -- and the sentinels -- are > x
+      case 1: cnt += knots_le<T, 1>(S.k, lo, x); break;
+      case 2: cnt += knots_le<T, 2>(S.k, lo, x); break;
+      case 3: cnt += knots_le<T, 3>(S.k, lo, x); break;
+      case 4: cnt += knots_le<T, 4>(S.k, lo, x); break;
+      default: cnt += knots_le<T, 8>(S.k, lo, x); break;
     }
-    cnt = cnt < S.n ? cnt : S.n;                          // (x >= kn may count the clamped last knot more than once)
-    const uint32_t i = cnt ? cnt - 1u : 0u;
+    const uint32_t i = cnt ? cnt - 1u : 0u;               // (x = +inf counts sentinels too: the clamp below covers it)
     return i < S.n - 2u ? i : S.n - 2u;
   }
   const T mm = S.gfac * (x - S.k0) + T(0);                // locate_index's guess, verified exact for every x on the host
@@ -1395,9 +1439,10 @@ __device__ __forceinline__ LaneAxis<T> stage_lane_axis(unsigned char* smem, size
   const uint32_t tid = threadIdx.x;
   T* s0 = reinterpret_cast<T*>(smem + off);
   for (uint32_t i = tid; i < n; i += TB) s0[i] = knots[i];
+  if (tid < LANE_SENTINELS) s0[n + tid] = __builtin_huge_val();   // +inf (converted to T)
   LaneAxis<T> S;
   S.k = (lds_ptr<T>)(smem + off);
-  off += ((size_t)n * sizeof(T) + 15u) & ~(size_t)15u;
+  off += ((size_t)(n + LANE_SENTINELS) * sizeof(T) + 15u) & ~(size_t)15u;
   S.lut = nullptr;
   if (dl.lut) {
     uint32_t* sl = reinterpret_cast<uint32_t*>(smem + off);
@@ -1483,6 +1528,102 @@ __device__ __forceinline__ T lane_point(const typename TabRecs<T, STRAT>::type& 
   }
 }
 
+// NQ independent scalar queries of one lane in LOCKSTEP: every stage is done for all of them before the next begins -- NQ
+// bucket reads, then NQ x MK knot reads, then the NQ interval records, the NQ table records, the NQ polynomials -- so a
+// wave has NQ LDS reads in flight per dependent step instead of one (one query after the other left the SIMDs 21 % busy and
+// the memory pipe at 3 TB/s: every query is a chain of five dependent LDS round trips; profiles/r05_lanes_counters.txt).
+// The only data-dependent branch -- a quotient outside the shared-divisor window redone with the IEEE division -- sits
+// behind everything else.  MK = the index's knots per bucket (0: the axis' exact O(1) guess).
+template <class T, int STRAT, int NQ, int MK>
+__device__ __forceinline__ void eval_scalar_queries(const LaneAxis<T>& S, const XRecs<T>& X,
+                                                    const typename TabRecs<T, STRAT>::type& R, int mode, const T (&x)[NQ],
+                                                    T (&out)[NQ]) {
+  T xs[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) xs[q] = x[q];
+  if (STRAT == ST_CUBIC && mode == EX_PERIODIC) {         // (uniform) cubic_spline.rs:805-809
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const bool inr = (S.k0 <= x[q]) && (x[q] <= S.kn);
+      if (!inr) xs[q] = rem_euclid_t(x[q] - S.k0, S.kn - S.k0) + S.k0;
+    }
+  }
+  uint32_t iv[NQ];
+  if constexpr (MK > 0) {
+    uint32_t lo[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      T f = (xs[q] - S.k0) * S.scale;
+      f = fmax(f, T(0));
+      f = fmin(f, T(S.m - 1u));
+      lo[q] = S.lut[(uint32_t)f];
+    }
+    T kv[NQ][MK];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = 0; j < MK; ++j) kv[q][j] = S.k[lo[q] + j];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      uint32_t cnt = lo[q];
+#pragma unroll
+      for (int j = 0; j < MK; ++j) cnt += (kv[q][j] <= xs[q]) ? 1u : 0u;
+      const uint32_t i = cnt ? cnt - 1u : 0u;
+      iv[q] = NDI_CHK(i < S.n - 2u ? i : S.n - 2u, S.n - 1u, BC_INTERVAL);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const T mm = S.gfac * (xs[q] - S.k0) + T(0);
+      iv[q] = (mm >= T(0)) ? (uint32_t)(mm < T(S.n - 2u) ? mm : T(S.n - 2u)) : 0u;
+    }
+  }
+  T s0[NQ];
+  bool redo[NQ];
+  SharedDivisor<T> sd[NQ];
+  T num[NQ];
+  if (STRAT == ST_CUBIC) {
+    T xr[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) X.get(iv[q], xr[q]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      sd[q].d = xr[q][1]; sd[q].r = xr[q][2]; sd[q].ok = xr[q][2] > T(0);
+      num[q] = xs[q] - xr[q][0];
+      bool ok;
+      s0[q] = div_shared_fast<T>(num[q], sd[q], ok);      // t, cubic_spline.rs:818
+      redo[q] = !ok;
+    }
+  } else {
+    T xl[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) xl[q] = S.k[iv[q]];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      s0[q] = x[q] - xl[q];                               // linear.rs:35's (x - x1)
+      redo[q] = false;
+    }
+  }
+  T r[NQ][TabRecs<T, STRAT>::NS];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) R.get(iv[q], r[q]);
+  if (STRAT == ST_CUBIC) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (__builtin_expect(redo[q], 0)) s0[q] = num[q] / sd[q].d;   // outside the window: the IEEE division
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (STRAT == ST_CUBIC) {                              // cubic_spline.rs:825-827
+      const T yl = r[q][0], yr = r[q][1], a = r[q][2], b = r[q][3];
+      const T c0 = T(1) - s0[q];
+      out[q] = c0 * yl + s0[q] * yr + (s0[q] * c0) * (a * c0 + b * s0[q]);
+    } else {                                              // linear.rs:33-35 with the record's m
+      out[q] = r[q][1] * s0[q] + r[q][0];
+    }
+  }
+}
+
 template <class T, int STRAT, int QPL, int TB>
 __global__ __launch_bounds__(TB) void eval_scalar_kernel(EvalLanesArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1500,46 +1641,65 @@ __global__ __launch_bounds__(TB) void eval_scalar_kernel(EvalLanesArgs<T> A) {
   const Tab R{reinterpret_cast<typename Tab::U*>(smem_raw + off), n - 1u};
   stage_table_recs<T, STRAT, TB>(R, A);
   __syncthreads();
-  unsigned long long limit = *A.first_fail;
+  unsigned long long limit = A.check ? NO_FAIL : *A.first_fail;
   if (limit > A.nq) limit = A.nq;
-  // QPL consecutive queries per lane, vector load / store, TWO vectors per thread and trip with the next two in flight
-  // (one vector ahead left the memory system latency-bound: 32 KiB of reads in flight per CU, 3.3 TB/s on the Linear
-  // kernel); the (< QPL) queries behind the last full vector below `limit` go one per thread at the end
+  // QPL consecutive queries per lane, vector load / store; NV vectors (NQ = 4 queries) per thread and trip, evaluated in
+  // lockstep (eval_scalar_queries), the next trip's vectors in flight; the (< QPL) queries behind the last full vector
+  // below `limit` go one per thread at the end
+  constexpr int NQ = QPL >= 4 ? QPL : 4;
+  constexpr int NV = NQ / QPL;
   const uint64_t nvec = limit / QPL;
   const uint64_t step = (uint64_t)gridDim.x * TB;
   const QV* qv = reinterpret_cast<const QV*>(A.q);
   QV* ov = reinterpret_cast<QV*>(A.out);
   const uint64_t vlast = nvec ? nvec - 1u : 0u;
   auto loadq = [&](uint64_t v) -> QV { return nvec ? qv[v < nvec ? v : vlast] : QV(S.k0); };   // clamped: unconditional
-  auto eval_vec = [&](const QV& cur) -> QV {
-    QV res;
-#pragma unroll
-    for (int u = 0; u < QPL; ++u) {
-      T x;
-      if constexpr (QPL == 1) x = cur; else x = cur[u];
-      uint32_t i;
-      T s0;
-      lane_query<T, STRAT>(S, X, A.mode, x, i, s0);
-      const T r = lane_point<T, STRAT>(R, i, s0);
-      if constexpr (QPL == 1) res = r; else res[u] = r;
-    }
-    return res;
-  };
-  auto storeq = [&](uint64_t v, const QV& res) {
-    if constexpr (QPL == 1) store_stream<true>(A.out + v * A.out_stride, res);   // (rows of one value may be strided)
-    else store_stream<true>(ov + v, res);
+  auto run = [&](const T (&x)[NQ], T (&res)[NQ]) {        // (uniform dispatch on the index's knots per bucket)
+    if (!S.lut) eval_scalar_queries<T, STRAT, NQ, 0>(S, X, R, A.mode, x, res);
+    else if (S.maxk == 1) eval_scalar_queries<T, STRAT, NQ, 1>(S, X, R, A.mode, x, res);
+    else if (S.maxk == 2) eval_scalar_queries<T, STRAT, NQ, 2>(S, X, R, A.mode, x, res);
+    else if (S.maxk == 3) eval_scalar_queries<T, STRAT, NQ, 3>(S, X, R, A.mode, x, res);
+    else if (S.maxk == 4) eval_scalar_queries<T, STRAT, NQ, 4>(S, X, R, A.mode, x, res);
+    else eval_scalar_queries<T, STRAT, NQ, 8>(S, X, R, A.mode, x, res);
   };
   uint64_t vi = (uint64_t)blockIdx.x * TB + tid;
-  QV n0 = loadq(vi), n1 = loadq(vi + step);
-  for (; vi < nvec; vi += 2u * step) {
-    const QV c0 = n0, c1 = n1;
-    n0 = loadq(vi + 2u * step);
-    n1 = loadq(vi + 3u * step);
-    const QV r0 = eval_vec(c0);
-    storeq(vi, r0);
-    if (vi + step < nvec) {
-      const QV r1 = eval_vec(c1);
-      storeq(vi + step, r1);
+  QV nxt[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) nxt[k] = loadq(vi + (uint64_t)k * step);
+  for (; vi < nvec; vi += (uint64_t)NV * step) {
+    T x[NQ], res[NQ];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int u = 0; u < QPL; ++u) {
+        if constexpr (QPL == 1) x[k] = nxt[k]; else x[k * QPL + u] = nxt[k][u];
+      }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) nxt[k] = loadq(vi + (uint64_t)(NV + k) * step);
+    run(x, res);
+    if (A.check) {                                        // (uniform) fresh output: the range test rides along
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {
+          const uint64_t v = vi + (uint64_t)k * step;
+          if (v < nvec && lane_query_fails<T>(x[k * QPL + u], S.k0, S.kn, A.mode))
+            atomicMin(A.first_fail, (unsigned long long)(v * QPL + u));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const uint64_t v = vi + (uint64_t)k * step;
+      if (v < nvec) {
+        if constexpr (QPL == 1) {
+          store_stream<true>(A.out + v * A.out_stride, res[k]);   // (rows of one value may be strided)
+        } else {
+          QV w;
+#pragma unroll
+          for (int u = 0; u < QPL; ++u) w[u] = res[k * QPL + u];
+          store_stream<true>(ov + v, w);
+        }
+      }
     }
   }
   if constexpr (QPL > 1) {
@@ -1547,7 +1707,9 @@ __global__ __launch_bounds__(TB) void eval_scalar_kernel(EvalLanesArgs<T> A) {
     if (blockIdx.x == 0 && qi < limit) {
       uint32_t i;
       T s0;
-      lane_query<T, STRAT>(S, X, A.mode, A.q[qi], i, s0);
+      const T xq = A.q[qi];
+      if (A.check && lane_query_fails<T>(xq, S.k0, S.kn, A.mode)) atomicMin(A.first_fail, (unsigned long long)qi);
+      lane_query<T, STRAT>(S, X, A.mode, xq, i, s0);
       A.out[qi * A.out_stride] = lane_point<T, STRAT>(R, i, s0);
     }
   }
@@ -1575,7 +1737,7 @@ __global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
   off += Tab::bytes((size_t)(n - 1u) * L);
   T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;
   __syncthreads();
-  unsigned long long limit = *A.first_fail;
+  unsigned long long limit = A.check ? NO_FAIL : *A.first_fail;
   if (limit > A.nq) limit = A.nq;
   const bool contig = A.out_stride == (uint64_t)L;
   // even L: lane j writes its row starting at value (j mod L) -- a plain l = 0, 1, ... order would put the lanes of a
@@ -1590,6 +1752,8 @@ __global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
       const uint64_t pn = base + wstep + lane;
       xn = A.q[pn < A.nq ? pn : A.nq - 1u];               // the next batch, in flight during this one
     }
+    if (A.check && base + lane < limit && lane_query_fails<T>(x, S.k0, S.kn, A.mode))
+      atomicMin(A.first_fail, (unsigned long long)(base + lane));
     uint32_t i;
     T s0;
     lane_query<T, STRAT>(S, X, A.mode, x, i, s0);
@@ -2736,8 +2900,20 @@ struct EvalLanes2Args {
   uint64_t nq, out_stride;
   uint32_t lanes;
   int mode;
-  const unsigned long long* first_fail;   // [2]: x, y (range_check_kernel)
+  unsigned long long* first_fail;   // [2]: x, y (range_check_kernel, or this kernel when `check`)
+  int check;                        // see EvalLanesArgs
 };
+
+// the failure conditions of a 2-D query (Interp2D::is_in_x_range / is_in_y_range, interp2d/mod.rs:374-379): x and y
+// failures are recorded separately, the host reports x before y for the same query (bilinear.rs:71-80)
+template <class T>
+__device__ __forceinline__ void lane_check2(unsigned long long* first_fail, uint64_t qi, T x, T y, T x0, T xn, T y0, T yn,
+                                            int mode) {
+  const bool badx = (mode == EX_NO) ? !((x0 <= x) && (x <= xn)) : !(x == x);
+  const bool bady = (mode == EX_NO) ? !((y0 <= y) && (y <= yn)) : !(y == y);
+  if (badx) atomicMin(&first_fail[0], (unsigned long long)qi);
+  if (bady) atomicMin(&first_fail[1], (unsigned long long)qi);
+}
 
 template <class T>
 struct LaneCell {
@@ -2810,7 +2986,7 @@ __global__ __launch_bounds__(TB) void eval_scalar2d_kernel(EvalLanes2Args<T> A) 
   T* s_g;
   stage_grid2<T, TB>(smem_raw, A, SX, SY, XX, XY, s_g);
   __syncthreads();
-  unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
+  unsigned long long limit = A.check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
   if (limit > A.nq) limit = A.nq;
   const uint32_t ny = A.ny;
   const uint64_t nvec = limit / QPL;
@@ -2819,12 +2995,13 @@ __global__ __launch_bounds__(TB) void eval_scalar2d_kernel(EvalLanes2Args<T> A) 
   const QV* qyv = reinterpret_cast<const QV*>(A.qy);
   QV* ov = reinterpret_cast<QV*>(A.out);
   const uint64_t vlast = nvec ? nvec - 1u : 0u;
-  auto eval_vec = [&](const QV& cx, const QV& cy) -> QV {
+  auto eval_vec = [&](uint64_t v, const QV& cx, const QV& cy) -> QV {
     QV res;
 #pragma unroll
     for (int u = 0; u < QPL; ++u) {
       T x, y;
       if constexpr (QPL == 1) { x = cx; y = cy; } else { x = cx[u]; y = cy[u]; }
+      if (A.check) lane_check2<T>(A.first_fail, v * QPL + u, x, y, SX.k0, SX.kn, SY.k0, SY.kn, A.mode);
       const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, ny, 1u, x, y);
       const T r = lane_bilinear<T>(s_g + c.o, 1u, ny, c);
       if constexpr (QPL == 1) res = r; else res[u] = r;
@@ -2851,12 +3028,13 @@ __global__ __launch_bounds__(TB) void eval_scalar2d_kernel(EvalLanes2Args<T> A) 
       nx0 = qxv[v0]; ny0 = qyv[v0];
       nx1 = qxv[v1]; ny1 = qyv[v1];
     }
-    storeq(vi, eval_vec(cx0, cy0));
-    if (vi + step < nvec) storeq(vi + step, eval_vec(cx1, cy1));
+    storeq(vi, eval_vec(vi, cx0, cy0));
+    if (vi + step < nvec) storeq(vi + step, eval_vec(vi + step, cx1, cy1));
   }
   if constexpr (QPL > 1) {
     const uint64_t qi = nvec * QPL + tid;
     if (blockIdx.x == 0 && qi < limit) {
+      if (A.check) lane_check2<T>(A.first_fail, qi, A.qx[qi], A.qy[qi], SX.k0, SX.kn, SY.k0, SY.kn, A.mode);
       const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, ny, 1u, A.qx[qi], A.qy[qi]);
       A.out[qi * A.out_stride] = lane_bilinear<T>(s_g + c.o, 1u, ny, c);
     }
@@ -2876,7 +3054,7 @@ __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
   const size_t off = stage_grid2<T, TB>(smem_raw, A, SX, SY, XX, XY, s_g);
   T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)(tid >> 6) * 64u * L;
   __syncthreads();
-  unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
+  unsigned long long limit = A.check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
   if (limit > A.nq) limit = A.nq;
   const uint32_t ny = A.ny, rowe = ny * L;
   const bool contig = A.out_stride == (uint64_t)L;
@@ -2897,6 +3075,7 @@ __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
       xq = A.qx[pc];
       yq = A.qy[pc];
     }
+    if (A.check && base + lane < limit) lane_check2<T>(A.first_fail, base + lane, x, y, SX.k0, SX.kn, SY.k0, SY.kn, A.mode);
     const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, ny, L, x, y);
     T* mine = s_strip + lane * L;
     for (uint32_t k = 0; k < L; ++k) {      // (even L: rotated start, see eval_lanes_kernel)
@@ -3331,6 +3510,83 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
       }
     }
     hi -= (uint64_t)cnt;
+  }
+}
+
+// The whole build of a SMALL system in one workgroup (the reference's own bench shape (100, 5), benches/bench_interp1d.rs:
+// 82-86: 500 values): data and right-hand sides live in LDS.  Phase A, all threads: every right-hand side (spline_rhs_at: the
+// boundary rows :597-670 and the interior rows :456-471, two divisions each) -- the part of the work that has no serial
+// dependency, spread over the whole workgroup instead of the handful of lanes the trailing axis has.  Phase B, one thread
+// per lane of the trailing axis: thomas (:678-721) and a / b (:354-365) out of LDS.  The per-lane serial kernel took 70 us
+// for (100, 5) -- one wave, five live lanes, every row's two divisions and its loads in the dependent chain; this one ~10.
+// Operations and their order per element are those of the serial kernels: bit-identical tables.
+// LDS: [y (n * lanes) | rhs (n * lanes)]; lanes <= blockDim.x.
+template <class T, bool KOUT>
+__global__ __launch_bounds__(BLOCK) void spline_build_lds_kernel(BuildArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t n = (uint32_t)A.n, L = (uint32_t)A.lanes, total = n * L;
+  T* s_y = reinterpret_cast<T*>(smem_raw);
+  T* s_r = s_y + total;
+  for (uint32_t e = threadIdx.x; e < total; e += BLOCK) {
+    const uint32_t i = e / L, l = e - i * L;
+    s_y[e] = A.data[e];
+    s_r[e] = spline_rhs_at<T, false, true>(A, i, l);
+  }
+  __syncthreads();
+  const uint32_t l = threadIdx.x;
+  if (l >= L) return;
+  auto dx_at = [&](uint32_t i) -> T { return A.x[i + 1] - A.x[i]; };
+  // forward elimination of the right-hand sides, rows 1 .. n-2 (row 0 stays as it is); UB rows per trip: their
+  // operands are fetched together, only the one multiply-subtract per row is in the dependent chain
+  constexpr int UB = 8;
+  T r_prev = s_r[l];
+  for (uint32_t i0 = 1; i0 + 1 < n; i0 += UB) {
+    T rv[UB], wv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const uint32_t i = i0 + u < n - 1u ? i0 + u : n - 2u;        // (clamped: loads unconditional)
+      rv[u] = s_r[i * L + l];
+      wv[u] = const_load(A.w, i);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (i0 + u + 1 < n) {
+        const T r = rv[u] - wv[u] * r_prev;
+        s_r[(i0 + u) * L + l] = r;
+        r_prev = r;
+      }
+    }
+  }
+  const T r_last = s_r[(n - 1) * L + l] - const_load(A.w, n - 1) * r_prev;
+  T k_next = r_last / const_load(A.midp, n - 1);
+  if (KOUT) A.kout[(uint64_t)(n - 1) * L + l] = k_next;
+  T y_hi = s_y[(n - 1) * L + l];
+  for (uint32_t hi = n - 1; hi > 0;) {      // back substitution fused with a / b, rows hi-1, hi-2, ..., UB per trip
+    const uint32_t cnt = hi < (uint32_t)UB ? hi : (uint32_t)UB;
+    T rv[UB], upv[UB], midv[UB], ylv[UB], dxv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const uint32_t i = (uint32_t)u < cnt ? hi - 1u - u : 0u;     // (clamped)
+      rv[u] = s_r[i * L + l];
+      ylv[u] = s_y[i * L + l];
+      upv[u] = (i == 0) ? A.left_up0 : ((uint64_t)i + 1 == A.up_len ? A.up_last : A.x[i] - A.x[i - 1]);
+      midv[u] = const_load(A.midp, i);
+      dxv[u] = dx_at(i);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if ((uint32_t)u < cnt) {
+        const uint32_t i = hi - 1u - u;
+        const T k = (rv[u] - upv[u] * k_next) / midv[u];
+        const T dy = y_hi - ylv[u];
+        A.ca[(uint64_t)i * L + l] = k * dxv[u] - dy;
+        A.cb[(uint64_t)i * L + l] = dy - k_next * dxv[u];
+        if (KOUT) A.kout[(uint64_t)i * L + l] = k;
+        k_next = k;
+        y_hi = ylv[u];
+      }
+    }
+    hi -= cnt;
   }
 }
 

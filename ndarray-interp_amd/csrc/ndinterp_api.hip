@@ -372,8 +372,12 @@ struct DevicePyramid {
       uint32_t m = 64;
       while (m < 4 * n) m *= 2;
       std::vector<uint32_t> cnt;
+      // candidates m = 4n .. 32768 (64 KiB of LDS): the smallest index with one knot per bucket if that costs at most
+      // 16 KiB, else the smallest with <= 3, else the densest (accepted up to 8)
       uint32_t best_m = 0, best_k = 0;
       T best_scale = T(0);
+      uint32_t m1 = 0, m3 = 0, ml = 0, kl = 0;
+      T s1 = T(0), s3 = T(0), sl = T(0);
       for (; m <= 32768; m *= 2) {
         const T scale = T(m) / (kn - k0);
         if (!(scale > T(0)) || !std::isfinite((double)scale)) break;
@@ -385,18 +389,24 @@ struct DevicePyramid {
           f = std::fmin(f, T(m - 1u));
           mk = std::max(mk, ++cnt[(uint32_t)f]);
         }
-        best_m = m; best_k = mk; best_scale = scale;
-        if (mk <= 3) break;
+        ml = m; kl = mk; sl = scale;
+        if (!m3 && mk <= 3) { m3 = m; s3 = scale; }
+        if (!m1 && mk <= 1 && m <= 8192) { m1 = m; s1 = scale; }
+        if (m1 || (m3 && m >= 8192)) break;
       }
+      if (m1) { best_m = m1; best_k = 1; best_scale = s1; }
+      else if (m3) { best_m = m3; best_k = 3; best_scale = s3; }
+      else { best_m = ml; best_k = kl; best_scale = sl; }
       if (!best_m || best_k > 8) return;
       const T scale = best_scale;
       m = best_m;
       cnt.assign(m, 0);
+      best_k = 0;
       for (uint64_t i = 0; i < n; ++i) {
         T f = (knots[i] - k0) * scale;
         f = std::fmax(f, T(0));
         f = std::fmin(f, T(m - 1u));
-        ++cnt[(uint32_t)f];
+        best_k = std::max(best_k, ++cnt[(uint32_t)f]);
       }
       std::vector<uint16_t> lut((size_t)m + 2 + 6, (uint16_t)n);
       uint32_t run = 0;
@@ -995,9 +1005,23 @@ struct Interp1DImpl final : Interp1DBase {
     static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
     static const int blocked_once = ShortKnobs::env("NDI_SPLINE_BLOCKED", -1);
     const int blocked_env = tune_live ? ShortKnobs::env("NDI_SPLINE_BLOCKED", -1) : blocked_once;
+    // ... and only on axes whose neighbouring knot spacings differ by less than 1e3 (f32) / 1e9 (f64): the re-associated
+    // sweeps are accurate relative to the NEIGHBOURING table magnitudes, and where the spacing jumps by 1e6 from one
+    // interval to the next those magnitudes jump likewise -- in f32 evaluated rows then miss the 1e-5 bar (4 of 5000 rows
+    // at 4e-5 on gaps drawn log-uniformly over six decades, tests/test_gpu_spline_blocked.py).  Such axes keep the serial
+    // kernels: bit-identical.
+    bool tame = true;
+    if (blocked_env < 0) {
+      const double lim = sizeof(T) == 4 ? 1e3 : 1e9;
+      const T* xs = pyr.host_knots.data();
+      for (uint64_t i = 2; tame && i < n; ++i) {
+        const double a = (double)xs[i] - (double)xs[i - 1], b = (double)xs[i - 1] - (double)xs[i - 2];
+        tame = a <= lim * b && b <= lim * a;
+      }
+    }
     const bool blocked = (P.mode == SPLINE_GENERAL || P.mode == SPLINE_PERIODIC) && n >= 16 &&
                          !(d.build_flags & NDI_BUILD_REFERENCE_ORDER) &&
-                         (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256));
+                         (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256 && tame));
     // Small systems (the reference's (100, 5); 1024 x 8; ...): ONE launch -- right-hand sides, elimination, back
     // substitution and the a / b epilogue in spline_build_general_kernel<FUSED>, dx / up formed from the resident knots;
     // the x-only factors w, mid' travel through a kept pinned buffer into a kept device buffer: no allocation, no free,
@@ -1012,6 +1036,7 @@ struct Interp1DImpl final : Interp1DBase {
       std::memcpy(hp, P.w.data(), (size_t)n * sizeof(T));
       std::memcpy(hp + n, P.midp.data(), (size_t)n * sizeof(T));
       NDI_HIP(hipMemcpyAsync(dp, hp, plan_b, hipMemcpyHostToDevice, nullptr));
+      clk.mark("    plan staged + copy enqueued");
       BuildArgs<T> A{};
       A.data = data.as<T>();
       A.ca = ca.as<T>();
@@ -1033,9 +1058,19 @@ struct Interp1DImpl final : Interp1DBase {
       A.dx0_sq = P.dx0_sq; A.dxl_sq = P.dxl_sq;
       A.kout = reserve_k();
       const unsigned grid1 = (unsigned)((lanes + 63) / 64);
-      if (A.kout) hipLaunchKernelGGL((spline_build_general_kernel<T, false, true, true>), dim3(grid1), dim3(64), 0, (hipStream_t) nullptr, A);
+      // the smallest systems -- data and right-hand sides fit LDS twice over, one workgroup covers the trailing axis --
+      // form their right-hand sides with the whole workgroup and sweep out of LDS (spline_build_lds_kernel)
+      static const int lds_env = ShortKnobs::env("NDI_SPLINE_LDS_SMALL", 1);   // A/B
+      const size_t lds_need = 2 * (size_t)n * lanes * sizeof(T);
+      if (lds_env && lanes <= (uint64_t)BLOCK && lds_need <= 96 * 1024 && n >= 4) {
+        allow_dynamic_lds(reinterpret_cast<const void*>(&spline_build_lds_kernel<T, true>), 96 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void*>(&spline_build_lds_kernel<T, false>), 96 * 1024);
+        if (A.kout) hipLaunchKernelGGL((spline_build_lds_kernel<T, true>), dim3(1), dim3(BLOCK), lds_need, (hipStream_t) nullptr, A);
+        else hipLaunchKernelGGL((spline_build_lds_kernel<T, false>), dim3(1), dim3(BLOCK), lds_need, (hipStream_t) nullptr, A);
+      } else if (A.kout) hipLaunchKernelGGL((spline_build_general_kernel<T, false, true, true>), dim3(grid1), dim3(64), 0, (hipStream_t) nullptr, A);
       else hipLaunchKernelGGL((spline_build_general_kernel<T, false, false, true>), dim3(grid1), dim3(64), 0, (hipStream_t) nullptr, A);
       NDI_HIP(hipGetLastError());
+      clk.mark("    kernel enqueued");
       NDI_HIP(hipStreamSynchronize(nullptr));   // the tables are complete when create() returns: any stream may read them
       clk.mark("  fused small build");
       return NDI_OK;
@@ -1264,12 +1299,13 @@ struct Interp1DImpl final : Interp1DBase {
     size_t f_lds = 0;
     int s_cq = 64;   // BUCKETED_SHORT
     int l_qpl = 1;   // LANES, scalar data: queries per lane (1, or one 16-byte vector)
+    bool l_check = false;   // LANES: no range pre-pass, the kernel checks the queries itself (NDI_EVAL_FRESH_OUTPUT)
   };
 
   // LDS footprint of eval_scalar_kernel / eval_lanes_kernel: [knots | dense index | interval records | table records | strips]
   size_t lanes_lds_bytes(unsigned tb) const {
     const size_t tr = strategy == NDI_CUBIC_SPLINE ? 4 : std::max<size_t>(2, 16 / sizeof(T));   // (whole 16-byte units)
-    size_t b = ((size_t)n * sizeof(T) + 15) & ~(size_t)15;
+    size_t b = ((size_t)(n + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15;
     b += pyr.dlut_bytes;
     if (strategy == NDI_CUBIC_SPLINE) b += (size_t)(n - 1) * 4 * sizeof(T);
     b += ((size_t)(n - 1) * lanes * tr * sizeof(T) + 15) & ~(size_t)15;
@@ -1281,7 +1317,7 @@ struct Interp1DImpl final : Interp1DBase {
   // (NDI_LANES_MAXB) whose records fit LDS beside the knots, an axis the branch-free search covers (dense bucket index
   // or exact O(1) guess), batches that give every workgroup several times its staging bytes to write.
   // NDI_LANES_KERNEL=0 leaves these shapes to the query-order kernel (A/B); =1 takes it whenever it fits.
-  bool plan_lanes(hipStream_t s, Scratch& sc, Plan1& P, int path) {
+  bool plan_lanes(hipStream_t s, Scratch& sc, Plan1& P, int path, int flags) {
     static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
     static const int on_once = ShortKnobs::env("NDI_LANES_KERNEL", -1), maxb_once = ShortKnobs::env("NDI_LANES_MAXB", 64);
     const int on = tune_live ? ShortKnobs::env("NDI_LANES_KERNEL", -1) : on_once;
@@ -1307,6 +1343,9 @@ struct Interp1DImpl final : Interp1DBase {
     P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + per_wg - 1) / per_wg, (uint64_t)cu_count() * wg_per_cu));
     P.kind = Plan1::LANES;
     g_last_path.store(NDI_PATH_GATHER);
+    // fresh output (interp_array: the buffer is dropped on Err): no pre-pass, the kernel's own range test reports the failure
+    P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;
+    if (P.l_check) return true;
     StatusBlock* st = sc.status.as<StatusBlock>();
     const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
     const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + BLOCK - 1) / BLOCK, 4096));
@@ -1333,9 +1372,10 @@ struct Interp1DImpl final : Interp1DBase {
     F.lanes = (uint32_t)lanes;
     F.mode = mode;
     F.first_fail = &sc.status.as<StatusBlock>()->first_fail[0];
+    F.check = P.l_check ? 1 : 0;
     if (std::getenv("NDI_TRACE_PLAN"))
-      std::fprintf(stderr, "[ndi plan] lanes L=%llu qpl=%d index=%s m=%u maxk=%u tb=%u grid=%u lds=%zu\n", (unsigned long long)lanes,
-                   P.l_qpl, pyr.dlut.lut ? "dense" : "guess", pyr.dlut.m, pyr.dlut.maxk, P.f_tb, P.f_grid, P.f_lds);
+      std::fprintf(stderr, "[ndi plan] lanes L=%llu qpl=%d index=%s m=%u maxk=%u tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes,
+                   P.l_qpl, pyr.dlut.lut ? "dense" : "guess", pyr.dlut.m, pyr.dlut.maxk, P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
     constexpr int VN = Wide<T>::N;
     const dim3 grid(P.f_grid), block(P.f_tb);
 #define NDI_LK(KERN)                                                                      \
@@ -1494,7 +1534,7 @@ struct Interp1DImpl final : Interp1DBase {
   }
 
   Plan1 prep(hipStream_t s, Scratch& sc, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path,
-             bool beside_eval = false) {
+             bool beside_eval = false, int flags = 0) {
     Plan1 P;
     P.q = q; P.nq = nq; P.out = out; P.out_stride = out_stride;
     sc.status.reserve(sizeof(StatusBlock));
@@ -1506,7 +1546,7 @@ struct Interp1DImpl final : Interp1DBase {
     // (scalar data at 1e8 queries: 98 -> 157 Gqueries/s f64, 2 lanes 45 -> 141).  Measured crossover
     // (profiles/r04_scalar_crossover.jsonl): ~8e6 output elements on <= 1024 knots, proportionally earlier on longer
     // axes (8192 knots: ~1e6), whose table gathers miss L1.  NDI_SMALL_MAXQ overrides the 8e6.
-    if (plan_lanes(s, sc, P, path)) return P;
+    if (plan_lanes(s, sc, P, path, flags)) return P;
     static const long small_maxq = ShortKnobs::env("NDI_SMALL_MAXQ", 8000000);
     const bool small_first = lanes <= 2 && pyr.lds_bytes <= LDS_STAGE_LIMIT;
     const double small_work = (double)nq * (double)lanes * (double)std::max<uint64_t>(n, 1024) / 1024.0;
@@ -1827,8 +1867,8 @@ struct Interp1DImpl final : Interp1DBase {
 #undef NDI_FU
   }
 
-  void enqueue(hipStream_t s, Workspace& ws, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path) {
-    launch_eval(s, ws.sc[0], prep(s, ws.sc[0], q, nq, out, out_stride, path));
+  void enqueue(hipStream_t s, Workspace& ws, const T* q, uint64_t nq, T* out, uint64_t out_stride, int path, int flags = 0) {
+    launch_eval(s, ws.sc[0], prep(s, ws.sc[0], q, nq, out, out_stride, path, false, flags));
   }
 
   // Reads the status block of the batch enqueued with scratch set 0 (stream must be idle afterwards) and converts
@@ -2013,7 +2053,7 @@ struct Interp1DImpl final : Interp1DBase {
     ws.last_q_space = q_space;
     ws.last_nq = nq;
     if (o.out_memspace == NDI_MEM_DEVICE) {
-      enqueue(s, ws, q, nq, (T*)out_, out_stride, o.path);
+      enqueue(s, ws, q, nq, (T*)out_, out_stride, o.path, o.flags);
       ws.pending = true;
       if (o.async_launch) return NDI_OK;
       return collect(s, ws, 0, info);
@@ -2345,6 +2385,7 @@ struct Interp2DImpl final : Interp2DBase {
   struct Plan2 {
     enum Kind { SMALL, GATHER, TILED, FUSED2, LANES2 } kind = GATHER;
     int l_qpl = 1;          // LANES2, scalar grids: queries per lane (1, or one 16-byte vector)
+    bool l_check = false;   // LANES2: no range pre-pass (NDI_EVAL_FRESH_OUTPUT)
     // FUSED2 (eval_fused2d_kernel)
     bool f_vec = false, f_lut = false;
     uint64_t f_lv = 0;
@@ -2360,7 +2401,7 @@ struct Interp2DImpl final : Interp2DBase {
   };
 
   Plan2 prep(hipStream_t s, Scratch& sc, const T* qx, const T* qy, uint64_t nq, T* out, uint64_t out_stride,
-             int path, bool beside_eval = false) {
+             int path, bool beside_eval = false, int flags = 0) {
     Plan2 P;
     P.qx = qx; P.qy = qy; P.nq = nq; P.out = out; P.out_stride = out_stride;
     sc.idx.reserve(nq * sizeof(uint32_t));
@@ -2387,7 +2428,8 @@ struct Interp2DImpl final : Interp2DBase {
           (on > 0 || (nq >= 65536 && (double)nq * (double)lanes * sizeof(T) >= 4.0 * (double)cu_count() * (double)grid_b))) {
         px.ensure_dense_lut();
         py.ensure_dense_lut();
-        const size_t fixed = (((size_t)nx * sizeof(T) + 15) & ~(size_t)15) + (((size_t)ny * sizeof(T) + 15) & ~(size_t)15) +
+        const size_t fixed = (((size_t)(nx + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
+                             (((size_t)(ny + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
                              px.dlut_bytes + py.dlut_bytes + (size_t)(nx - 1 + ny - 1) * 4 * sizeof(T) + ((grid_b + 15) & ~(size_t)15);
         auto need_of = [&](unsigned tb) { return fixed + (lanes > 1 ? (size_t)(tb / 64) * 64 * lanes * sizeof(T) : 0); };
         unsigned tb = need_of(256) * 4 <= 160 * 1024 ? 256u : 1024u;
@@ -2402,6 +2444,8 @@ struct Interp2DImpl final : Interp2DBase {
           const uint64_t per_wg = (uint64_t)P.f_tb * (lanes == 1 ? (uint64_t)P.l_qpl : 1);
           P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + per_wg - 1) / per_wg, (uint64_t)cu_count() * wg_per_cu));
           g_last_path.store(NDI_PATH_GATHER);
+          P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
+          if (P.l_check) return P;
           const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
           ProfScope ps(s, PC_LOCATE);
           hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
@@ -2685,9 +2729,10 @@ struct Interp2DImpl final : Interp2DBase {
       F.lanes = (uint32_t)lanes;
       F.mode = mode;
       F.first_fail = &st->first_fail[0];
+      F.check = P.l_check ? 1 : 0;
       if (std::getenv("NDI_TRACE_PLAN"))
-        std::fprintf(stderr, "[ndi plan] lanes2d L=%llu qpl=%d maxk=%u,%u tb=%u grid=%u lds=%zu\n", (unsigned long long)lanes,
-                     P.l_qpl, px.dlut.maxk, py.dlut.maxk, P.f_tb, P.f_grid, P.f_lds);
+        std::fprintf(stderr, "[ndi plan] lanes2d L=%llu qpl=%d maxk=%u,%u tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes,
+                     P.l_qpl, px.dlut.maxk, py.dlut.maxk, P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
       constexpr int VNl = Wide<T>::N;
 #define NDI_L2(KERN)                                                                      \
   do {                                                                                    \
@@ -2891,8 +2936,8 @@ struct Interp2DImpl final : Interp2DBase {
   }
 
   void enqueue(hipStream_t s, Workspace& ws, const T* qx, const T* qy, uint64_t nq, T* out,
-               uint64_t out_stride, int path) {
-    launch_eval(s, ws.sc[0], prep(s, ws.sc[0], qx, qy, nq, out, out_stride, path));
+               uint64_t out_stride, int path, int flags = 0) {
+    launch_eval(s, ws.sc[0], prep(s, ws.sc[0], qx, qy, nq, out, out_stride, path, false, flags));
   }
 
   ndi_status collect(hipStream_t s, Workspace& ws, uint64_t index_offset, ndi_oob_info* info) {
@@ -3078,7 +3123,7 @@ struct Interp2DImpl final : Interp2DBase {
     ws.last_q_space = q_space;
     ws.last_nq = nq;
     if (o.out_memspace == NDI_MEM_DEVICE) {
-      enqueue(s, ws, qx, qy, nq, (T*)out_, out_stride, o.path);
+      enqueue(s, ws, qx, qy, nq, (T*)out_, out_stride, o.path, o.flags);
       ws.pending = true;
       if (o.async_launch) return NDI_OK;
       return collect(s, ws, 0, info);

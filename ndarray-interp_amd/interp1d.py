@@ -126,14 +126,18 @@ class _DeviceStrategy1D(Interp1DStrategy):
         return other
 
     # -- evaluate -----------------------------------------------------------------------------
-    def interp_array_into(self, interpolator, xs_flat, out2d, *, async_launch=False):
-        """Replaces the reference's query loop (interp1d/mod.rs:326-343) by one C-ABI call."""
+    _takes_fresh = True   # interp_array() may tell this strategy that the output buffer is its own (ndi_eval_flags)
+
+    def interp_array_into(self, interpolator, xs_flat, out2d, *, async_launch=False, fresh=False):
+        """Replaces the reference's query loop (interp1d/mod.rs:326-343) by one C-ABI call.  `fresh`: the buffer was
+        allocated for this call and is dropped on Err (Interp1D::interp_array, :197-211) -- NDI_EVAL_FRESH_OUTPUT."""
         qb = Buf(xs_flat, self._np_dtype)
         _check_out_dtype(out2d, self._np_dtype)
         opts = _capi.EvalOpts()
         opts.q_memspace = qb.memspace
         opts.path = self.path
         opts.async_launch = int(bool(async_launch))
+        opts.flags = _capi.EVAL_FRESH_OUTPUT if fresh else _capi.EVAL_DEFAULT
         # an async batch reads the query array until finish(): keep every (possibly converted) copy alive
         if async_launch:
             self._inflight.append(qb)
@@ -540,7 +544,8 @@ class Interp1D:
             # is dropped anyway (:210); no memset of the output is needed
         else:
             ys = np.zeros(shape, dtype=np_dtype_of(self.data))
-        self.interp_array_into(xs, ys)
+        # the buffer is this call's own and is dropped on Err (:210): strategies that can use the knowledge are told
+        self.interp_array_into(xs, ys, **({"fresh": True} if getattr(self.strategy, "_takes_fresh", False) else {}))
         return ys
 
     def interp_array_into(self, xs, buffer, **kw):

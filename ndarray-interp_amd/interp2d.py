@@ -130,8 +130,11 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
         other._h, other._device, other._inflight = h, int(device), []
         return other
 
-    def interp_array_into(self, interpolator, xs_flat, ys_flat, out2d, *, async_launch=False):
-        """Replaces the reference's query loop (interp2d/mod.rs:287-307) by one C-ABI call."""
+    _takes_fresh = True   # see _DeviceStrategy1D
+
+    def interp_array_into(self, interpolator, xs_flat, ys_flat, out2d, *, async_launch=False, fresh=False):
+        """Replaces the reference's query loop (interp2d/mod.rs:287-307) by one C-ABI call.  `fresh`: the buffer was
+        allocated for this call and is dropped on Err (Interp2D::interp_array, :175-196) -- NDI_EVAL_FRESH_OUTPUT."""
         qx = Buf(xs_flat, self._np_dtype)
         qy = Buf(ys_flat, self._np_dtype)
         if qx.memspace != qy.memspace:
@@ -143,6 +146,7 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
         opts.q_memspace = qx.memspace
         opts.path = self.path
         opts.async_launch = int(bool(async_launch))
+        opts.flags = _capi.EVAL_FRESH_OUTPUT if fresh else _capi.EVAL_DEFAULT
         if is_torch(out2d):
             if not out2d.is_cuda:
                 raise TypeError("torch output buffers must live on the device; use numpy for host buffers")
@@ -321,7 +325,8 @@ class Interp2D:
             zs = torch.empty(shape, dtype=tdt, device=xs.device)
         else:
             zs = np.zeros(shape, dtype=np_dtype_of(self.data))
-        self.interp_array_into(xs, ys, zs)
+        # the buffer is this call's own and is dropped on Err (:193-195): strategies that can use the knowledge are told
+        self.interp_array_into(xs, ys, zs, **({"fresh": True} if getattr(self.strategy, "_takes_fresh", False) else {}))
         return zs
 
     def interp_array_into(self, xs, ys, buffer, **kw):

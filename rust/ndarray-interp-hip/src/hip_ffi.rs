@@ -45,6 +45,9 @@ pub const NDI_MONO_FALLING: i32 = 4;
 pub const NDI_BUILD_DEFAULT: i32 = 0;
 pub const NDI_BUILD_REFERENCE_ORDER: i32 = 1;
 
+pub const NDI_EVAL_DEFAULT: i32 = 0;
+pub const NDI_EVAL_FRESH_OUTPUT: i32 = 1;
+
 pub const NDI_PATH_AUTO: i32 = 0;
 pub const NDI_PATH_GATHER: i32 = 1;
 pub const NDI_PATH_BUCKETED: i32 = 2;
@@ -131,6 +134,8 @@ pub struct ndi_eval_opts {
     pub stream: *mut c_void,
     pub path: i32,
     pub async_launch: i32,
+    pub flags: i32,
+    pub reserved: i32,
 }
 
 #[repr(C)]

@@ -83,6 +83,8 @@ where
         stream: per_thread_stream(),
         path: ffi::NDI_PATH_AUTO,
         async_launch: 0,
+        flags: ffi::NDI_EVAL_DEFAULT,
+        reserved: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
     let mut bridge = Bridge { consume, panic: None };
@@ -129,6 +131,8 @@ where
         stream: per_thread_stream(),
         path: ffi::NDI_PATH_AUTO,
         async_launch: 0,
+        flags: ffi::NDI_EVAL_DEFAULT,
+        reserved: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
     let mut bridge = Bridge { consume, panic: None };

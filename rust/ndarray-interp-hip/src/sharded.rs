@@ -73,6 +73,8 @@ where
         stream: null_mut(),
         path: ffi::NDI_PATH_AUTO,
         async_launch: 0,
+        flags: ffi::NDI_EVAL_DEFAULT,
+        reserved: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
     let st = unsafe {
@@ -131,6 +133,8 @@ where
         stream: null_mut(),
         path: ffi::NDI_PATH_AUTO,
         async_launch: 0,
+        flags: ffi::NDI_EVAL_DEFAULT,
+        reserved: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
     let st = unsafe {

@@ -150,6 +150,8 @@ where
         stream: per_thread_stream(),
         path: ffi::NDI_PATH_AUTO,
         async_launch: 0,
+        flags: ffi::NDI_EVAL_DEFAULT,
+        reserved: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
     match rows_of(buffer, dev.lanes) {
@@ -628,6 +630,8 @@ where
         stream: per_thread_stream(),
         path: ffi::NDI_PATH_AUTO,
         async_launch: 0,
+        flags: ffi::NDI_EVAL_DEFAULT,
+        reserved: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
     let finish = |st: i32, info: &ffi::ndi_oob_info| match st {

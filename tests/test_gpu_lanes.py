@@ -131,7 +131,18 @@ def test_lanes_1d_modes_and_first_error(pkg, capfd, dt, L):
             noex.interp_array_into(torch.as_tensor(qi, device=dev), out)
     assert ei.value.index == 40_001 and " lanes L=" in f.plans[0], f.plans
     got = out.cpu().numpy()
-    assert np.array_equal(got[:40_001], ref[:40_001]) and np.all(got[40_001:] == -3.0)
+    assert np.array_equal(got[:40_001], ref[:40_001]) and np.all(got[40_001:] == -3.0) and "prepass=1" in f.plans[0]
+    # interp_array (the output is the call's own and dropped on Err: NDI_EVAL_FRESH_OUTPUT): no range pre-pass, the
+    # kernel's own test still reports the LOWEST failing query and its value
+    with forced(capfd) as f:
+        with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+            noex.interp_array(torch.as_tensor(qi, device=dev))
+    assert ei.value.index == 40_001 and "prepass=0" in f.plans[0], f.plans
+    with forced(capfd) as f:
+        ok = noex.interp_array(torch.as_tensor(q[(q >= x[0]) & (q <= x[-1])], device=dev)).cpu().numpy()
+    assert "prepass=0" in f.plans[0]
+    qin = q[(q >= x[0]) & (q <= x[-1])]
+    check_equal(ok.reshape(qin.size, L), oracle.interp1d_cubic(x, y, a, b, qin)[2].reshape(qin.size, L), "fresh output")
     with forced(capfd):
         with pytest.raises(pkg.Panic):
             ex_c.interp_array(torch.as_tensor(qi, device=dev))
@@ -169,7 +180,7 @@ def test_lanes_1d_auto_takes_the_bench_shapes(pkg, capfd):
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("kx,ky,nx,ny,C", [("rand", "jit", 100, 100, 1), ("lin", "lin", 100, 100, 1), ("rand", "rand", 40, 57, 5),
-                                           ("log", "rand", 17, 300, 2), ("rand", "lin", 2, 2, 1), ("rand", "rand", 64, 33, 8)])
+                                           ("log", "rand", 17, 300, 2), ("rand", "lin", 2, 2, 1), ("rand", "rand", 60, 33, 8)])
 def test_lanes_2d_bit_exact(pkg, capfd, dt, kx, ky, nx, ny, C):
     import torch
     dev = torch.device("cuda:0")
@@ -215,6 +226,16 @@ def test_lanes_2d_bit_exact(pkg, capfd, dt, kx, ky, nx, ny, C):
     assert (ei.value.index, ei.value.axis) == (31_000, 0) and " lanes2d L=" in f.plans[0], f.plans
     got = buf.cpu().numpy()
     assert np.array_equal(got[:31_000], ref[:31_000]) and np.all(got[31_000:] == -3.0)
+    # interp_array: fresh output, no pre-pass; x is still reported before y for the same query, y alone when only y fails
+    with forced(capfd) as f:
+        with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+            it.interp_array(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev))
+    assert (ei.value.index, ei.value.axis) == (31_000, 0) and "prepass=0" in f.plans[0], f.plans
+    qx[31_000] = x[0]
+    with forced(capfd):
+        with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+            it.interp_array(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev))
+    assert (ei.value.index, ei.value.axis) == (31_000, 1)
 
 
 def test_lanes_2d_auto_takes_the_bench_shape(pkg, capfd):

@@ -17,6 +17,8 @@ pkg = g.load_package()
 dev = torch.device("cuda:0")
 spec = sys.argv[1].split(":")
 reps = int(os.environ.get("REPS", "5"))
+# FRESH=1: interp_array semantics (the output is the call's own: NDI_EVAL_FRESH_OUTPUT, no range pre-pass); 0: interp_array_into
+fresh = os.environ.get("FRESH", "0") == "1"
 rng = np.random.default_rng(0)
 if spec[0] == "1d":
     n, L = int(spec[1]), int(spec[2])
@@ -29,7 +31,7 @@ if spec[0] == "1d":
     it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)).strategy(strat).build()
     q = (torch.rand(Q, dtype=tdt, device=dev) * float(x[-1] - x[0]) * 0.999 + float(x[0])).clamp(float(x[0]), float(x[-1]))
     out = torch.empty((Q, L), dtype=tdt, device=dev)
-    call = lambda: it.strategy.interp_array_into(it, q, out, async_launch=True)
+    call = lambda: it.strategy.interp_array_into(it, q, out, async_launch=True, fresh=fresh)
     C = L
 else:
     nx, ny, C = int(spec[1]), int(spec[2]), int(spec[3])
@@ -42,7 +44,7 @@ else:
     qx = torch.rand(Q, dtype=tdt, device=dev) * float(x[-1] - x[0]) * 0.999 + float(x[0])
     qy = torch.rand(Q, dtype=tdt, device=dev) * float(y[-1] - y[0]) * 0.999 + float(y[0])
     out = torch.empty((Q, C), dtype=tdt, device=dev)
-    call = lambda: it.strategy.interp_array_into(it, qx, qy, out, async_launch=True)
+    call = lambda: it.strategy.interp_array_into(it, qx, qy, out, async_launch=True, fresh=fresh)
 call()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -51,6 +53,6 @@ for _ in range(reps):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / reps * 1e3
 it.strategy.finish()
-print(json.dumps({"shape": sys.argv[1], "queries": Q, "ms": round(ms, 4), "Gqueries_s": round(Q / ms / 1e6, 1),
+print(json.dumps({"shape": sys.argv[1], "fresh_output": fresh, "queries": Q, "ms": round(ms, 4), "Gqueries_s": round(Q / ms / 1e6, 1),
                   "out_TBps": round(Q * C * np.dtype(dt).itemsize / ms / 1e9, 3),
                   "io_TBps": round(Q * (C + (1 if spec[0] == "1d" else 2)) * np.dtype(dt).itemsize / ms / 1e9, 3)}), flush=True)

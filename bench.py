@@ -460,18 +460,27 @@ def short_rows_leg(pkg, torch, dev, out_bytes=4e9, steps=5):
             interp = pkg.Interp1DBuilder.new(yd).x(xd).strategy(pkg.CubicSpline.new()).build()
             qd = (torch.rand(Q, dtype=tdt, device=dev) * (xd[-1] - xd[0]) * 0.999 + xd[0]).clamp(xd[0], xd[-1])
             out = torch.empty((Q, L), dtype=tdt, device=dev)
-            call = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
-            call(); interp.strategy.finish()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                call()
-            torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) / steps
-            interp.strategy.finish()
+            walls = {}
+            for fresh in (True, False):     # interp_array semantics (the output is the call's own, dropped on Err:
+                # NDI_EVAL_FRESH_OUTPUT, no range pre-pass; the allocation itself stays outside the timed loop) and
+                # interp_array_into semantics (caller-owned buffer: rows at / after a failing query stay untouched)
+                call = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True, fresh=fresh)
+                call(); interp.strategy.finish()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    call()
+                torch.cuda.synchronize()
+                walls[fresh] = (time.perf_counter() - t0) / steps
+                interp.strategy.finish()
+            wall = walls[True]
             res["reference_shapes"].append({"dtype": np.dtype(dt).name, "knots": int(xd.numel()), "lanes": L, "queries": Q,
                                             "ms": round(wall * 1e3, 4), "Gqueries_s": round(Q / wall / 1e9, 1),
-                                            "out_TBps": round(Q * L * el / wall / 1e12, 3)})
+                                            "out_TBps": round(Q * L * el / wall / 1e12, 3),
+                                            "io_frac_of_peak": round(Q * (L + 1) * el / wall / 1e9 / HBM_PEAK_GBS, 4),
+                                            "semantics": "interp_array (fresh output, NDI_EVAL_FRESH_OUTPUT)",
+                                            "interp_array_into_ms": round(walls[False] * 1e3, 4),
+                                            "interp_array_into_Gqueries_s": round(Q / walls[False] / 1e9, 1)})
             interp.strategy.release()
             del interp, qd, yd, out
         torch.cuda.empty_cache()
@@ -546,19 +555,25 @@ def reference_shapes_2d_leg(pkg, torch, dev, steps=5):
             qx = torch.rand(Q, dtype=tdt, device=dev) * float(x[-1] - x[0]) * 0.999 + float(x[0])
             qy = torch.rand(Q, dtype=tdt, device=dev) * float(y[-1] - y[0]) * 0.999 + float(y[0])
             out = torch.empty((Q, C), dtype=tdt, device=dev)
-            call = lambda: it.strategy.interp_array_into(it, qx, qy, out, async_launch=True)
-            call(); it.strategy.finish()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                call()
-            torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) / steps
-            it.strategy.finish()
+            walls = {}
+            for fresh in (True, False):     # interp_array / interp_array_into semantics: see short_rows_leg
+                call = lambda: it.strategy.interp_array_into(it, qx, qy, out, async_launch=True, fresh=fresh)
+                call(); it.strategy.finish()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    call()
+                torch.cuda.synchronize()
+                walls[fresh] = (time.perf_counter() - t0) / steps
+                it.strategy.finish()
+            wall = walls[True]
             io = Q * (C + 2) * el
             rows.append({"dtype": np.dtype(dt).name, "grid": [nx, ny, C], "queries": Q, "ms": round(wall * 1e3, 4),
                          "Gqueries_s": round(Q / wall / 1e9, 1), "io_TBps": round(io / wall / 1e12, 3),
-                         "io_frac_of_peak": round(io / wall / 1e9 / HBM_PEAK_GBS, 4)})
+                         "io_frac_of_peak": round(io / wall / 1e9 / HBM_PEAK_GBS, 4),
+                         "semantics": "interp_array (fresh output, NDI_EVAL_FRESH_OUTPUT)",
+                         "interp_array_into_ms": round(walls[False] * 1e3, 4),
+                         "interp_array_into_Gqueries_s": round(Q / walls[False] / 1e9, 1)})
             it.strategy.release()
             del it, qx, qy, out, grid
         torch.cuda.empty_cache()

@@ -1313,18 +1313,20 @@ struct Interp1DImpl final : Interp1DBase {
     return b;
   }
 
-  // Query per lane with the whole table set in LDS (eval_scalar_kernel / eval_lanes_kernel): rows of up to 64 bytes
+  // Query per lane with the whole table set in LDS (eval_scalar_kernel / eval_lanes_kernel): rows of up to 56 bytes
   // (NDI_LANES_MAXB) whose records fit LDS beside the knots, an axis the branch-free search covers (dense bucket index
   // or exact O(1) guess), batches that give every workgroup several times its staging bytes to write.
   // NDI_LANES_KERNEL=0 leaves these shapes to the query-order kernel (A/B); =1 takes it whenever it fits.
   bool plan_lanes(hipStream_t s, Scratch& sc, Plan1& P, int path, int flags) {
     static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
-    static const int on_once = ShortKnobs::env("NDI_LANES_KERNEL", -1), maxb_once = ShortKnobs::env("NDI_LANES_MAXB", 64);
+    // rows of up to 56 bytes: at 64 bytes the query-order kernel is level (f64 x 8: 65 vs 61-65 Gqueries/s) or ahead
+    // (f32 x 16: 74 vs 57), profiles/r05_small_shapes_rates.txt
+    static const int on_once = ShortKnobs::env("NDI_LANES_KERNEL", -1), maxb_once = ShortKnobs::env("NDI_LANES_MAXB", 56);
     const int on = tune_live ? ShortKnobs::env("NDI_LANES_KERNEL", -1) : on_once;
-    const int maxb = tune_live ? ShortKnobs::env("NDI_LANES_MAXB", 64) : maxb_once;
+    const int maxb = tune_live ? ShortKnobs::env("NDI_LANES_MAXB", 56) : maxb_once;
     if (on == 0 || path == NDI_PATH_BUCKETED || n < 3 || n > 16384) return false;
     if (on < 0 && short_knobs().mode != 0) return false;   // a pinned short-row variant (NDI_SHORT_MODE) is what runs
-    if (lanes * sizeof(T) > (size_t)maxb) return false;
+    if (lanes * sizeof(T) > (size_t)(on > 0 ? std::max(maxb, 64) : maxb)) return false;   // (forced: up to 64 bytes, for the tests)
     const size_t tab = ((size_t)n * sizeof(T)) + (size_t)(n - 1) * (4 + lanes * 4) * sizeof(T);   // (before the index is known)
     if (tab > FUSED_LDS_LIMIT) return false;
     if (on < 0 && (P.nq < 65536 || (double)P.nq * (double)lanes * sizeof(T) < 4.0 * (double)cu_count() * (double)tab)) return false;
@@ -2423,7 +2425,7 @@ struct Interp2DImpl final : Interp2DBase {
       static const int on_once = ShortKnobs::env("NDI_LANES2D_KERNEL", -1);
       const int on = tune_live2 ? ShortKnobs::env("NDI_LANES2D_KERNEL", -1) : on_once;
       const size_t grid_b = (size_t)nx * ny * lanes * sizeof(T);
-      if (on != 0 && path != NDI_PATH_BUCKETED && !pair_packed && nx <= 16384 && ny <= 16384 && lanes * sizeof(T) <= 64 &&
+      if (on != 0 && path != NDI_PATH_BUCKETED && !pair_packed && nx <= 16384 && ny <= 16384 && lanes * sizeof(T) <= (on > 0 ? 64 : 56) &&
           grid_b + (nx + ny) * 5 * sizeof(T) <= FUSED_LDS_LIMIT && (uint64_t)nx * ny * lanes < (1ull << 31) &&
           (on > 0 || (nq >= 65536 && (double)nq * (double)lanes * sizeof(T) >= 4.0 * (double)cu_count() * (double)grid_b))) {
         px.ensure_dense_lut();

@@ -1916,7 +1916,8 @@ __global__ __launch_bounds__(BLOCK) void group_offsets_scan_kernel(uint32_t* his
   __threadfence();                 // every other workgroup's totals are visible to this one
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   uint32_t carry = 0;
-  constexpr int NT = 4;            // tiles of BLOCK * 4 bins whose loads are issued together
+  constexpr int NT = 16;           // tiles of BLOCK * 4 bins whose loads are issued together (16 384 bins: all at once)
+  const int chunk_shift = (chunk && (chunk & (chunk - 1u)) == 0u) ? (31 - __builtin_clz(chunk)) : -1;   // power of two: shifts
   for (uint32_t base = 0; base < nb; base += (uint32_t)BLOCK * 4u * NT) {
     uint4 v[NT];
 #pragma unroll
@@ -1955,8 +1956,9 @@ __global__ __launch_bounds__(BLOCK) void group_offsets_scan_kernel(uint32_t* his
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (st[k + 1] == st[k]) continue;
-          for (uint64_t c = ((uint64_t)st[k] + chunk - 1u) / chunk; c * chunk < (uint64_t)st[k + 1]; ++c)
-            chunk_bin[c] = i0 + (uint32_t)k;
+          const uint64_t c0 = chunk_shift >= 0 ? ((uint64_t)st[k] + chunk - 1u) >> chunk_shift
+                                               : ((uint64_t)st[k] + chunk - 1u) / chunk;
+          for (uint64_t c = c0; c * chunk < (uint64_t)st[k + 1]; ++c) chunk_bin[c] = i0 + (uint32_t)k;
         }
       }
       carry += tile_total;

@@ -630,13 +630,14 @@ static void reset_status(void* status, hipStream_t s) {
 
 constexpr uint32_t BUCKETED_RUN = 1;         // consecutive 128-query chunks per workgroup of eval_bucketed_kernel
                                              // (1 / 4 / 8 / 16 / 32 measured equal within 1 %: tools/sweep_target.py)
-constexpr uint32_t GROUP_MAX_BLOCKS = 256;   // query slices of the block-local counting sort
+constexpr uint32_t GROUP_MAX_BLOCKS = 256;   // query slices of the block-local counting sort (1-D; 2-D default)
+constexpr uint32_t GROUP_MAX_BLOCKS_2D = 1024;   // upper limit of NDI_GROUP_BLOCKS for the 2-D tile grouping
 // NDI_GROUP_BLOCKS (A/B, read once): fewer, longer slices -- longer runs per (slice, bin) in the record scatter
 static uint32_t group_blocks() {
   static const uint32_t v = [] {
     const char* e = std::getenv("NDI_GROUP_BLOCKS");
     const int k = e ? std::atoi(e) : 0;
-    return (uint32_t)(k >= 8 && k <= (int)GROUP_MAX_BLOCKS ? k : (int)GROUP_MAX_BLOCKS);
+    return (uint32_t)(k >= 8 && k <= (int)GROUP_MAX_BLOCKS_2D ? k : (int)GROUP_MAX_BLOCKS);
   }();
   return v;
 }
@@ -2603,14 +2604,15 @@ struct Interp2DImpl final : Interp2DBase {
       }
       size_t shmem = both_l;
       if (tiled) {
-        sc.hist.reserve((size_t)GROUP_MAX_BLOCKS * nb * sizeof(uint32_t));
+        sc.hist.reserve((size_t)std::max<uint32_t>(group_blocks(), GROUP_MAX_BLOCKS) * nb * sizeof(uint32_t));
         LA.hist = sc.hist.as<uint32_t>();
         LA.nb = nb; LA.sx = sx; LA.sy = sy; LA.nty = nty;
         shmem = ((both_l + 15) & ~(size_t)15) + (size_t)nb * 4;
       }
       const unsigned threads = beside_eval ? 256u : threads_for_lds(shmem);
       blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, tiled ? group_blocks() : 2048));
-      if (LA.bx.lut || LA.by.lut || tiled)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
+      if ((LA.bx.lut || LA.by.lut || tiled) && !(tiled && group_blocks() > GROUP_MAX_BLOCKS))   // staging is the fixed cost of a
+        // workgroup: no more workgroups than the chip holds at once (NDI_GROUP_BLOCKS > 256 lifts the cap: A/B)
         blocks = std::min<uint64_t>(blocks, (uint64_t)cu_count() * std::max<size_t>(1, (160 * 1024) / shmem));
       slice = (nq + blocks - 1) / blocks;
       slice = (slice + threads - 1) / threads * threads;

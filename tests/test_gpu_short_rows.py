@@ -370,7 +370,7 @@ def test_auto_picks_the_measured_form(pkg, capfd):
         (np.float64, 128, True, None),                      # 1 KiB rows, many queries per interval: grouped
         (np.float64, 8, False, "tables=lds{y,a,b}"), (np.float32, 32, False, "tables=memory"),
         (np.float64, 128, False, "tables=memory"),          # Linear: never grouped
-        (np.float64, 1, True, "tables=lds"),                # scalar data at 1e7 queries: the query-order kernel
+        (np.float64, 1, True, "[ndi plan] lanes L=1 qpl=2"),   # scalar data at 1e7 queries: query per lane, tables in LDS
     ]
     for dt, L, cubic, frag in expect:
         tdt = torch.float64 if dt == np.float64 else torch.float32

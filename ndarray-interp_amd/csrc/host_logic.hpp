@@ -157,6 +157,61 @@ std::vector<T> thomas_host(const std::vector<T>& up, const std::vector<T>& w,
   return k;
 }
 
+// The boundary-row scalars of the GENERAL plan alone (n >= 4, not periodic) -- what the device needs when it forms the
+// diagonals and the elimination factors itself (spline_eliminate_kernel): no O(n) vector is built.  up_first / mid_first /
+// low_last / mid_last are rows 0 and n-1 of the three diagonals (:597-670).
+template <class T>
+struct SplineEnds {
+  T up_first = T(0), mid_first = T(0), low_last = T(0), mid_last = T(0);
+};
+
+template <class T>
+SplinePlan<T> make_spline_plan_scalars(const T* x, uint64_t n, int lkind, double lval, int rkind, double rval,
+                                       SplineEnds<T>& E) {
+  SplinePlan<T> P;
+  P.n = n;
+  P.m = n;
+  P.mode = SPLINE_GENERAL;
+  const T one = T(1), two = T(2);
+  const T dx0 = x[1] - x[0];
+  const T dx1 = x[2] - x[1];
+  const T dxl = x[n - 1] - x[n - 2];
+  const T dxl2 = x[n - 2] - x[n - 3];
+  P.dx0_sq = dx0 * dx0;
+  P.dxl_sq = dxl * dxl;
+  int lk, rk;
+  double lv, rv;
+  specialize_end(lkind, lval, lk, lv);
+  specialize_end(rkind, rval, rk, rv);
+  P.left_kind = lk;
+  P.right_kind = rk;
+  P.left_val = T(lv);
+  P.right_val = T(rv);
+  if (lk == END_NOT_A_KNOT) {
+    E.mid_first = dx1;
+    const T d = x[2] - x[0];
+    E.up_first = d;
+    P.nkL_d = d;
+    P.nkL_tmp1 = (dx0 + two * d) * dx1;
+  } else if (lk == END_FIRST_DERIV) {
+    E.mid_first = one; E.up_first = T(0);
+  } else {
+    E.up_first = dx0; E.mid_first = two * dx0;
+  }
+  if (rk == END_NOT_A_KNOT) {
+    E.mid_last = dxl;  // sic: the reference uses dx_1 here (:635)
+    const T d = x[n - 1] - x[n - 3];
+    E.low_last = d;
+    P.nkR_d = d;
+    P.nkR_tmp1 = (two * d + dxl) * dxl2;
+  } else if (rk == END_FIRST_DERIV) {
+    E.mid_last = one; E.low_last = T(0);
+  } else {
+    E.mid_last = two * dxl; E.low_last = dxl;
+  }
+  return P;
+}
+
 template <class T>
 SplinePlan<T> make_spline_plan(const T* x, uint64_t n, bool periodic, int lkind, double lval,
                                int rkind, double rval) {

@@ -162,6 +162,15 @@ __device__ __forceinline__ T const_load(const T* p, uint64_t i) {
   return ((cptr)p)[i];
 }
 
+// const_load where the array really is read-only for the whole kernel (CL), a plain load where the same kernel wrote it
+// in an earlier phase: loads through the constant address space are invariant to the compiler -- it may move them above
+// a barrier, and the scalar cache they may be served from does not see the kernel's own vector stores.
+template <bool CL, class T>
+__device__ __forceinline__ T ro_load(const T* p, uint64_t i) {
+  if constexpr (CL) return const_load(p, i);
+  else return p[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // locate: knot pyramid  lv0 = knots[n], lv1[j] = knots[j * block]  (block = power of two with 64*block >= n,
 // so the top level never has more than 64 entries: one per lane)
@@ -3592,6 +3601,46 @@ __global__ __launch_bounds__(BLOCK) void spline_build_lds_kernel(BuildArgs<T> A)
   }
 }
 
+// The x-only elimination factors of the GENERAL system on the device, for axes of 1e5-1e6 knots where the host's division
+// chain of n steps was half of the build (8.7 of 18 ms at 1e6 knots): w[i] = low[i] / mid'[i-1], mid'[i] = mid[i] - w[i] up[i-1]
+// (thomas, cubic_spline.rs:690-692, on the diagonals alone) with low / mid / up formed from the knots (:440-451).  The map
+// mid'[i-1] -> mid'[i] is a contraction -- its derivative low[i] up[i-1] / mid'[i-1]^2 is below 0.15 for ANY strictly rising
+// axis because mid' >= 4/3 (dx[i] + dx[i-1]) -- so a chain started WARM = 32 rows early from the uneliminated diagonal has
+// forgotten its start (0.25 * 0.15^32 ~ 1e-27) by the time it reaches its own rows: every thread owns SE consecutive rows
+// and runs the reference's recurrence, in the reference's operation order, from 32 rows before them (the first thread from
+// row 0, exactly).  Used by the blocked build only, whose tables carry their own few-ulp tolerance.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void spline_eliminate_kernel(const T* x, uint64_t n, T up_first, T mid_first, T low_last,
+                                                                 T mid_last, T* w, T* midp, uint64_t SE) {
+  constexpr uint64_t WARM = 32;
+  const T two = T(2);
+  const uint64_t b = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const uint64_t i0 = b * SE;
+  if (i0 >= n) return;
+  const uint64_t i1 = (i0 + SE < n) ? i0 + SE : n;
+  auto up_of = [&](uint64_t i) -> T { return i == 0 ? up_first : x[i] - x[i - 1]; };          // (rows < n - 1)
+  auto mid_of = [&](uint64_t i) -> T {
+    if (i == 0) return mid_first;
+    if (i + 1 == n) return mid_last;
+    return two * ((x[i + 1] - x[i]) + (x[i] - x[i - 1]));
+  };
+  auto low_of = [&](uint64_t i) -> T { return i + 1 == n ? low_last : x[i + 1] - x[i]; };     // (rows >= 1)
+  uint64_t j = i0 > WARM ? i0 - WARM : 0;
+  T mp = mid_of(j);                       // row j: exact when j == 0 (mid'[0] = mid[0]), a starting guess otherwise
+  if (j >= i0) {
+    w[j] = T(0);
+    midp[j] = mp;
+  }
+  for (uint64_t i = j + 1; i < i1; ++i) {
+    const T wi = low_of(i) / mp;
+    mp = mid_of(i) - wi * up_of(i - 1);
+    if (i >= i0) {
+      w[i] = wi;
+      midp[i] = mp;
+    }
+  }
+}
+
 // BLOCKED Thomas sweeps for narrow trailing axes with many knots (scalar data on 1e5-1e6 knots; 8 lanes on 4096).
 // The per-lane serial kernel above gives such a build ONE wave with a handful of live lanes doing 2n dependent steps
 // (a division in every step of the back substitution): 10x-100x behind one CPU core.  Both sweeps are first-order
@@ -3607,11 +3656,21 @@ __global__ __launch_bounds__(BLOCK) void spline_build_lds_kernel(BuildArgs<T> A)
 //     fP[i] = prod_{j = block start .. i} (-w[j])      dco[i] = -up[i] / mid'[i]      bP[i] = prod_{j = i .. block end} dco[j]
 // (w, up, mid' are the x-only factors of the host plan, host_logic.hpp).
 template <class T>
+__device__ __forceinline__ void spline_blocked_coef_block(const T* w, const T* up, const T* midp, T* fP, T* dco, T* bP,
+                                                          uint64_t n, uint64_t S, uint64_t b);
+
+template <class T>
 __global__ __launch_bounds__(BLOCK) void spline_blocked_coef_kernel(const T* w, const T* up, const T* midp, T* fP,
                                                                     T* dco, T* bP, uint64_t n, uint64_t S,
                                                                     uint64_t nblocks) {
   const uint64_t b = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (b >= nblocks) return;
+  spline_blocked_coef_block<T>(w, up, midp, fP, dco, bP, n, S, b);
+}
+
+template <class T>
+__device__ __forceinline__ void spline_blocked_coef_block(const T* w, const T* up, const T* midp, T* fP, T* dco, T* bP,
+                                                          uint64_t n, uint64_t S, uint64_t b) {
   const uint64_t i0 = b * S, i1 = (i0 + S < n) ? i0 + S : n;
   T p = T(0);
   for (uint64_t i = i0; i < i1; ++i) {
@@ -3627,11 +3686,19 @@ __global__ __launch_bounds__(BLOCK) void spline_blocked_coef_kernel(const T* w, 
   }
 }
 
+template <class T, bool CL = true>
+__device__ __forceinline__ void spline_blocked_local_task(const BuildArgs<T>& A, int backward, uint64_t t);
+
 template <class T>
 __global__ __launch_bounds__(BLOCK) void spline_blocked_local_kernel(BuildArgs<T> A, int backward) {
-  const uint64_t L = A.lanes, n = A.rows;
   const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;   // = block * L + lane
-  if (t >= A.nblocks * L) return;
+  if (t >= A.nblocks * A.lanes) return;
+  spline_blocked_local_task<T>(A, backward, t);
+}
+
+template <class T, bool CL>
+__device__ __forceinline__ void spline_blocked_local_task(const BuildArgs<T>& A, int backward, uint64_t t) {
+  const uint64_t L = A.lanes, n = A.rows;
   const uint64_t b = t / L, l = t - b * L;
   const uint64_t i0 = b * A.S;
   const uint64_t i1 = (i0 + A.S < n) ? i0 + A.S : n;
@@ -3643,7 +3710,7 @@ __global__ __launch_bounds__(BLOCK) void spline_blocked_local_kernel(BuildArgs<T
       T rv[UB], wv[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if (i + u < i1) { rv[u] = r[(i + u) * L]; wv[u] = const_load(A.w, i + u); }
+        if (i + u < i1) { rv[u] = r[(i + u) * L]; wv[u] = const_load(A.w, i + u); }   // (w: the host plan's, in every form)
 #pragma unroll
       for (int u = 0; u < UB; ++u)
         if (i + u < i1) { prev = rv[u] - wv[u] * prev; r[(i + u) * L] = prev; }
@@ -3654,7 +3721,7 @@ __global__ __launch_bounds__(BLOCK) void spline_blocked_local_kernel(BuildArgs<T
       T cv[UB], dv[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if ((uint64_t)u < cnt) { cv[u] = r[(i - 1 - u) * L]; dv[u] = const_load(A.dco, i - 1 - u); }
+        if ((uint64_t)u < cnt) { cv[u] = r[(i - 1 - u) * L]; dv[u] = ro_load<CL>(A.dco, i - 1 - u); }
 #pragma unroll
       for (int u = 0; u < UB; ++u)
         if ((uint64_t)u < cnt) { prev = cv[u] + dv[u] * prev; r[(i - 1 - u) * L] = prev; }
@@ -3664,54 +3731,104 @@ __global__ __launch_bounds__(BLOCK) void spline_blocked_local_kernel(BuildArgs<T
   A.ends[b * L + l] = prev;
 }
 
+template <class T, bool CL = true>
+__device__ __forceinline__ void spline_blocked_carry_lane(const BuildArgs<T>& A, int backward, uint64_t l);
+
 template <class T>
 __global__ __launch_bounds__(64) void spline_blocked_carry_kernel(BuildArgs<T> A, int backward) {
   const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= A.lanes) return;
+  spline_blocked_carry_lane<T>(A, backward, l);
+}
+
+template <class T, bool CL>
+__device__ __forceinline__ void spline_blocked_carry_lane(const BuildArgs<T>& A, int backward, uint64_t l) {
   const uint64_t L = A.lanes, n = A.rows, nb = A.nblocks;
   T c = T(0);
   if (!backward) {
     for (uint64_t b = 0; b < nb; ++b) {
       A.carry[b * L + l] = c;
       const uint64_t last = ((b + 1) * A.S < n ? (b + 1) * A.S : n) - 1;
-      c = A.ends[b * L + l] + const_load(A.fP, last) * c;
+      c = A.ends[b * L + l] + ro_load<CL>(A.fP, last) * c;
     }
   } else {
     for (uint64_t b = nb; b-- > 0;) {
       A.carry[b * L + l] = c;
-      c = A.ends[b * L + l] + const_load(A.bP, b * A.S) * c;
+      c = A.ends[b * L + l] + ro_load<CL>(A.bP, b * A.S) * c;
     }
   }
 }
 
 // forward correction fused with the division of the back substitution: rfull[i] = (r'_local[i] + fP[i] carry) / mid'[i]
+template <class T, bool CL = true>
+__device__ __forceinline__ void spline_blocked_fix_forward_elem(const BuildArgs<T>& A, uint64_t e) {
+  const uint64_t L = A.lanes;
+  const uint64_t i = e / L, l = e - i * L;
+  const T rp = A.rfull[e] + ro_load<CL>(A.fP, i) * A.carry[(i / A.S) * L + l];
+  A.rfull[e] = rp / const_load(A.midp, i);
+}
 template <class T>
 __global__ __launch_bounds__(BLOCK) void spline_blocked_fix_forward_kernel(BuildArgs<T> A) {
-  const uint64_t L = A.lanes, total = A.rows * A.lanes;
-  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
-    const uint64_t i = e / L, l = e - i * L;
-    const T rp = A.rfull[e] + const_load(A.fP, i) * A.carry[(i / A.S) * L + l];
-    A.rfull[e] = rp / const_load(A.midp, i);
-  }
+  const uint64_t total = A.rows * A.lanes;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK)
+    spline_blocked_fix_forward_elem<T>(A, e);
 }
 
 // backward correction fused with a / b (cubic_spline.rs:354-365):  k[i] = k_local[i] + bP[i] carry
+template <class T, bool CL = true>
+__device__ __forceinline__ void spline_blocked_finish_elem(const BuildArgs<T>& A, uint64_t e) {
+  const uint64_t L = A.lanes;
+  const uint64_t i = e / L, l = e - i * L;
+  const T k0 = A.rfull[e] + ro_load<CL>(A.bP, i) * A.carry[(i / A.S) * L + l];
+  const T k1 = A.rfull[e + L] + ro_load<CL>(A.bP, i + 1) * A.carry[((i + 1) / A.S) * L + l];
+  const T dy = A.data[e + L] - A.data[e];
+  const T dxi = ro_load<CL>(A.dx, i);
+  A.ca[e] = k0 * dxi - dy;
+  A.cb[e] = dy - k1 * dxi;
+  if (A.kout) {
+    A.kout[e] = k0;
+    if (i + 2 == A.n) A.kout[e + L] = k1;
+  }
+}
 template <class T>
 __global__ __launch_bounds__(BLOCK) void spline_blocked_finish_kernel(BuildArgs<T> A) {
-  const uint64_t L = A.lanes, total = (A.n - 1) * A.lanes;
-  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
-    const uint64_t i = e / L, l = e - i * L;
-    const T k0 = A.rfull[e] + const_load(A.bP, i) * A.carry[(i / A.S) * L + l];
-    const T k1 = A.rfull[e + L] + const_load(A.bP, i + 1) * A.carry[((i + 1) / A.S) * L + l];
-    const T dy = A.data[e + L] - A.data[e];
-    const T dxi = const_load(A.dx, i);
-    A.ca[e] = k0 * dxi - dy;
-    A.cb[e] = dy - k1 * dxi;
-    if (A.kout) {
-      A.kout[e] = k0;
-      if (i + 2 == A.n) A.kout[e + L] = k1;
+  const uint64_t total = (A.n - 1) * A.lanes;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK)
+    spline_blocked_finish_elem<T>(A, e);
+}
+
+// The blocked sweeps of a SMALL system (n * lanes <= 2^17 values: 4096 knots x 8 lanes) in ONE launch: one 1024-thread
+// workgroup runs the phases of the multi-kernel form one after the other -- dx / up from the knots, the coefficient
+// products, every right-hand side, local forward sweeps, the carry chain, the forward correction with the division, the
+// same three steps backward, the a / b epilogue -- with a workgroup barrier (which orders its global-memory accesses too)
+// where the multi-kernel form has a launch boundary.  Nine dependent launches of a few microseconds of work each were
+// 0.13 of the 0.23 ms such a build took (profiles/r05_build_probe.jsonl).  Same operations: the tables are those of the
+// multi-kernel blocked build.
+template <class T>
+__global__ __launch_bounds__(1024) void spline_blocked_onewg_kernel(BuildArgs<T> A, T* dx, T* up, T up_first, T up_last_v,
+                                                                    uint64_t up_len) {
+  const uint64_t tid = threadIdx.x, nt = blockDim.x;
+  const uint64_t n = A.n, L = A.lanes;
+  for (uint64_t i = tid; i < n; i += nt) {          // spline_dx_up_kernel
+    if (i + 1 < n) dx[i] = A.x[i + 1] - A.x[i];
+    if (i < up_len) up[i] = (i == 0) ? up_first : ((i + 1 == up_len) ? up_last_v : A.x[i] - A.x[i - 1]);
+  }
+  __syncthreads();
+  for (uint64_t b = tid; b < A.nblocks; b += nt)
+    spline_blocked_coef_block<T>(A.w, A.up, A.midp, const_cast<T*>(A.fP), const_cast<T*>(A.dco), const_cast<T*>(A.bP), A.rows, A.S, b);
+  for (uint64_t e = tid; e < n * L; e += nt) A.rfull[e] = spline_rhs_at<T, false, true>(A, e / L, e % L);
+  __syncthreads();
+  for (int backward = 0; backward < 2; ++backward) {
+    for (uint64_t t = tid; t < A.nblocks * L; t += nt) spline_blocked_local_task<T, false>(A, backward, t);
+    __syncthreads();
+    for (uint64_t l = tid; l < L; l += nt) spline_blocked_carry_lane<T, false>(A, backward, l);
+    __syncthreads();
+    if (!backward) {
+      for (uint64_t e = tid; e < A.rows * L; e += nt) spline_blocked_fix_forward_elem<T, false>(A, e);
+      __syncthreads();
     }
   }
+  for (uint64_t e = tid; e < (n - 1) * L; e += nt) spline_blocked_finish_elem<T, false>(A, e);
 }
 
 // ---- periodic boundary (cubic_spline.rs:498-565) with the blocked sweeps: the condensed system of order m = n - 2

@@ -993,9 +993,6 @@ struct Interp1DImpl final : Interp1DBase {
     }
     const bool periodic = d.periodic != 0;
     BuildClock clk;
-    SplinePlan<T> P = make_spline_plan<T>(pyr.host_knots.data(), n, periodic, d.left.kind,
-                                          d.left.value, d.right.kind, d.right.value);
-    clk.mark("  host plan");
     const size_t tab = (size_t)(n - 1) * lanes * sizeof(T);
     ca.reserve(tab);
     cb.reserve(tab);
@@ -1020,9 +1017,19 @@ struct Interp1DImpl final : Interp1DBase {
         tame = a <= lim * b && b <= lim * a;
       }
     }
-    const bool blocked = (P.mode == SPLINE_GENERAL || P.mode == SPLINE_PERIODIC) && n >= 16 &&
-                         !(d.build_flags & NDI_BUILD_REFERENCE_ORDER) &&
+    // (n >= 16: the system is the GENERAL or the PERIODIC one -- the closed forms are n == 3)
+    const bool blocked = n >= 16 && !(d.build_flags & NDI_BUILD_REFERENCE_ORDER) &&
                          (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256 && tame));
+    // Long axes: the x-only elimination factors on the device as well (spline_eliminate_kernel); the host then forms only
+    // the boundary rows' scalars.  NDI_SPLINE_DEVICE_ELIM=0: A/B.
+    static const int elim_env = ShortKnobs::env("NDI_SPLINE_DEVICE_ELIM", 1);
+    const bool dev_elim = blocked && !periodic && n >= 32768 && elim_env != 0;
+    SplineEnds<T> ends;
+    SplinePlan<T> P = dev_elim ? make_spline_plan_scalars<T>(pyr.host_knots.data(), n, d.left.kind, d.left.value, d.right.kind,
+                                                             d.right.value, ends)
+                               : make_spline_plan<T>(pyr.host_knots.data(), n, periodic, d.left.kind, d.left.value,
+                                                     d.right.kind, d.right.value);
+    clk.mark("  host plan");
     // Small systems (the reference's (100, 5); 1024 x 8; ...): ONE launch -- right-hand sides, elimination, back
     // substitution and the a / b epilogue in spline_build_general_kernel<FUSED>, dx / up formed from the resident knots;
     // the x-only factors w, mid' travel through a kept pinned buffer into a kept device buffer: no allocation, no free,
@@ -1087,10 +1094,70 @@ struct Interp1DImpl final : Interp1DBase {
     // w, mid' and k2 -- the results of the host's division chain -- are uploaded straight from their vectors.
     const size_t plan_elems = 5 * (size_t)n;
     const size_t blk_elems = blocked ? 3 * (size_t)n + (size_t)n * lanes + 2 * (size_t)nblk * lanes : 0;
+    // Small blocked builds (4096 knots x 8 lanes): ONE launch -- one 1024-thread workgroup runs every phase
+    // (spline_blocked_onewg_kernel) -- on temporaries kept per host thread: nine dependent launches, an allocation, a
+    // free and the status read-back were 0.15 of the 0.23 ms of such a build.  NDI_SPLINE_ONEWG=0: A/B.
+    // (measured SLOWER than the nine launches it replaces -- 0.21 vs 0.13 ms at 4096 x 8: one workgroup pays every phase's
+    //  global-memory latency on one CU, the launches spread each phase over the chip -- so it is off: NDI_SPLINE_ONEWG=1: A/B)
+    static const int onewg_env = ShortKnobs::env("NDI_SPLINE_ONEWG", 0);
+    if (onewg_env && blocked && !per && (uint64_t)n * lanes <= (1u << 17)) {
+      BuildScratch& bs = build_scratch();
+      const size_t bytes = (plan_elems + blk_elems) * sizeof(T);
+      T* const plan = static_cast<T*>(bs.device_buf(device, bytes));
+      T* const hp = static_cast<T*>(bs.pinned(2 * (size_t)n * sizeof(T)));
+      std::memcpy(hp, P.w.data(), (size_t)n * sizeof(T));
+      std::memcpy(hp + n, P.midp.data(), (size_t)n * sizeof(T));
+      NDI_HIP(hipMemcpyAsync(plan + 2 * (size_t)n, hp, 2 * (size_t)n * sizeof(T), hipMemcpyHostToDevice, nullptr));   // [w | mid']
+      BuildArgs<T> A{};
+      A.data = data.as<T>();
+      A.ca = ca.as<T>();
+      A.cb = cb.as<T>();
+      A.x = pyr.view.lv0;
+      A.dx = plan;
+      A.up = plan + n;
+      A.w = plan + 2 * (size_t)n;
+      A.midp = plan + 3 * (size_t)n;
+      A.n = n;
+      A.lanes = lanes;
+      A.left_kind = P.left_kind;
+      A.right_kind = P.right_kind;
+      A.left_val = P.left_val;
+      A.right_val = P.right_val;
+      A.nkL_tmp1 = P.nkL_tmp1; A.nkL_d = P.nkL_d;
+      A.nkR_tmp1 = P.nkR_tmp1; A.nkR_d = P.nkR_d;
+      A.dx0_sq = P.dx0_sq; A.dxl_sq = P.dxl_sq;
+      A.kout = reserve_k();
+      T* sp = plan + plan_elems;
+      A.fP = sp;
+      A.dco = sp + n;
+      A.bP = sp + 2 * n;
+      A.rfull = sp + 3 * n;
+      A.ends = A.rfull + n * lanes;
+      A.carry = A.ends + nblk * lanes;
+      A.S = S;
+      A.nblocks = nblk;
+      A.rows = rows;
+      const uint64_t up_len = P.up.size();
+      hipLaunchKernelGGL(spline_blocked_onewg_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t) nullptr, A, plan, plan + n, P.up.front(),
+                         P.up.back(), up_len);
+      NDI_HIP(hipGetLastError());
+      NDI_HIP(hipStreamSynchronize(nullptr));
+      clk.mark("  blocked sweeps, one workgroup");
+      return NDI_OK;
+    }
+    // temporaries: kept per host thread up to 64 MiB (hipMalloc + hipFree of a 48 MB buffer cost 4 ms of a 1e6-knot build,
+    // and more than the kernels of a 4096 x 8 one); larger ones are allocated and freed here
     DevBuf tmp;
-    tmp.reserve(256 + (plan_elems + blk_elems) * sizeof(T));
-    NDI_HIP(hipMemsetAsync(tmp.p, 0, sizeof(StatusBlock), nullptr));
-    T* const plan = reinterpret_cast<T*>((char*)tmp.p + 256);
+    const size_t tmp_bytes = 256 + (plan_elems + blk_elems) * sizeof(T);
+    void* tmp_p = nullptr;
+    if (tmp_bytes <= ((size_t)64 << 20)) {
+      tmp_p = build_scratch().device_buf(device, tmp_bytes);
+    } else {
+      tmp.reserve(tmp_bytes);
+      tmp_p = tmp.p;
+    }
+    NDI_HIP(hipMemsetAsync(tmp_p, 0, sizeof(StatusBlock), nullptr));
+    T* const plan = reinterpret_cast<T*>((char*)tmp_p + 256);
     T* const d_dx = plan;
     T* const d_up = plan + n;
     T* const d_w = plan + 2 * (size_t)n;
@@ -1100,10 +1167,18 @@ struct Interp1DImpl final : Interp1DBase {
     if (!P.midp.empty()) NDI_HIP(hipMemcpyAsync(d_mid, P.midp.data(), P.midp.size() * sizeof(T), hipMemcpyHostToDevice, nullptr));
     if (!P.k2.empty()) NDI_HIP(hipMemcpyAsync(d_k2, P.k2.data(), P.k2.size() * sizeof(T), hipMemcpyHostToDevice, nullptr));
     {
-      const uint64_t up_len = P.up.size();
+      const uint64_t up_len = dev_elim ? n : P.up.size();
+      const T up_first = dev_elim ? ends.up_first : (up_len ? P.up[0] : T(0));
+      const T up_last = dev_elim ? T(0) : (up_len ? P.up[up_len - 1] : T(0));
       const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + BLOCK - 1) / BLOCK, 4096));
       hipLaunchKernelGGL(spline_dx_up_kernel<T>, dim3(g), dim3(BLOCK), 0, (hipStream_t) nullptr, (const T*)pyr.view.lv0, d_dx, d_up,
-                         n, up_len, up_len ? P.up[0] : T(0), up_len ? P.up[up_len - 1] : T(0));
+                         n, up_len, up_first, up_last);
+      if (dev_elim) {   // w, mid' where the host plan would have been uploaded
+        const uint64_t SE = 256;
+        const uint64_t tasks = (n + SE - 1) / SE;
+        hipLaunchKernelGGL(spline_eliminate_kernel<T>, dim3((unsigned)((tasks + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t) nullptr,
+                           (const T*)pyr.view.lv0, n, ends.up_first, ends.mid_first, ends.low_last, ends.mid_last, d_w, d_mid, SE);
+      }
       NDI_HIP(hipGetLastError());
     }
     clk.mark("  tables alloc + plan upload");
@@ -1127,7 +1202,7 @@ struct Interp1DImpl final : Interp1DBase {
     A.nkR_tmp1 = P.nkR_tmp1; A.nkR_d = P.nkR_d;
     A.dx0_sq = P.dx0_sq; A.dxl_sq = P.dxl_sq;
     A.per_den = P.per_den;
-    A.status = tmp.as<StatusBlock>();
+    A.status = static_cast<StatusBlock*>(tmp_p);
     A.kout = reserve_k();
     const unsigned grid = (unsigned)((lanes + 63) / 64);
     hipStream_t s = nullptr;
@@ -1161,7 +1236,8 @@ struct Interp1DImpl final : Interp1DBase {
       }
       NDI_HIP(hipGetLastError());
       StatusBlock hs{};
-      NDI_HIP(hipMemcpy(&hs, tmp.p, sizeof(hs), hipMemcpyDeviceToHost));   // synchronises; the scratch is freed on return
+      if (per) NDI_HIP(hipMemcpy(&hs, tmp_p, sizeof(hs), hipMemcpyDeviceToHost));   // (only the periodic build reports through it)
+      else NDI_HIP(hipStreamSynchronize(s));                                         // the tables are complete on return
       clk.mark("  blocked sweeps");
       if (hs.periodic_mismatch != 0)
         return fail(NDI_VALUE,
@@ -1190,7 +1266,7 @@ struct Interp1DImpl final : Interp1DBase {
     }
     NDI_HIP(hipGetLastError());
     StatusBlock hs{};
-    NDI_HIP(hipMemcpy(&hs, tmp.p, sizeof(hs), hipMemcpyDeviceToHost));  // synchronises
+    NDI_HIP(hipMemcpy(&hs, tmp_p, sizeof(hs), hipMemcpyDeviceToHost));  // synchronises
     if (hs.periodic_mismatch != 0)
       return fail(NDI_VALUE,
                   "for periodic boundary condition the first and last value must be equal "

@@ -525,6 +525,14 @@ struct Locate2Args {
   // 2^sx x 2^sy cells in hist[b][nb] (LDS atomics, as locate_kernel does for the 1-D intervals)
   uint32_t* hist;
   uint32_t nb, sx, sy, nty;
+  // two-level grouping (coarse_scatter2d_kernel): workgroup b also leaves the histogram of its slice over the ntx tile
+  // ROWS in chist[b][ntx] -- the row sums of its tile histogram
+  uint32_t* chist;
+  uint32_t ntx;
+  // hist_w != 0: the tile histograms are left in column-block-major order, hist[(bin / hist_w) * slices + b][bin % hist_w]
+  // -- the share of the columns one coarse_scatter2d_kernel workgroup sums is then ONE contiguous piece (row-major, its
+  // reads are `slices` pieces of hist_w words 4 * nb bytes apart: 65 536 page-crossing touches at C3, 0.26 ms)
+  uint32_t hist_w;
 };
 
 template <class T, int QB = LOCATE_QB>
@@ -627,8 +635,26 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
   }
   if (s_hist) {
     __syncthreads();
-    uint32_t* dst = A.hist + (uint64_t)blockIdx.x * A.nb;
-    for (uint32_t i = tid; i < A.nb; i += blockDim.x) dst[i] = s_hist[i];
+    if (A.hist_w) {
+      for (uint32_t i = tid; i < A.nb; i += blockDim.x) {
+        const uint32_t cb = i / A.hist_w, j = i - cb * A.hist_w;
+        A.hist[((uint64_t)cb * gridDim.x + blockIdx.x) * A.hist_w + j] = s_hist[i];
+      }
+    } else {
+      uint32_t* dst = A.hist + (uint64_t)blockIdx.x * A.nb;
+      for (uint32_t i = tid; i < A.nb; i += blockDim.x) dst[i] = s_hist[i];
+    }
+    if (A.chist) {   // one thread per tile row; the walk along the row starts at a rotated column (banks)
+      for (uint32_t c = tid; c < A.ntx; c += blockDim.x) {
+        const uint32_t* row = s_hist + c * A.nty;
+        uint32_t sum = 0, f = c % A.nty;
+        for (uint32_t k = 0; k < A.nty; ++k) {
+          sum += row[f];
+          f = (f + 1u == A.nty) ? 0u : f + 1u;
+        }
+        A.chist[(uint64_t)blockIdx.x * A.ntx + c] = sum;
+      }
+    }
   }
 }
 
@@ -1880,6 +1906,71 @@ __global__ __launch_bounds__(BLOCK) void group_offsets_kernel(uint32_t* hist, ui
   totals[bin] = run;
 }
 
+// Exclusive scan of the nb bin totals into cursor[] (= bin_start[]; cursor2: a second, consumable copy) by ONE workgroup
+// of TB threads with coalesced 16-byte pieces -- thread-local prefix of 4, wave scan by cross-lane shifts, the wave totals
+// through LDS -- and, while every bin's [start, end) is in registers, for every chunk of `chunk` grouped positions the
+// tile that holds the chunk's first position (what tile_chunk_bins_kernel found by bisection).  totals / cursor must be
+// allocated with nb rounded up to a multiple of 4 entries.
+template <int TB>
+__device__ __forceinline__ void scan_bin_totals(const uint32_t* totals, uint32_t nb, uint32_t* cursor, uint32_t* cursor2,
+                                                StatusBlock* status, uint32_t chunk, uint32_t* chunk_bin,
+                                                uint32_t* s_wave) {
+  static_assert(TB >= 64 && TB <= 1024 && 4096 % TB == 0, "one to sixteen waves");
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  uint32_t carry = 0;
+  constexpr int NT = 4096 / TB;    // tiles of TB * 4 bins whose loads are issued together (16 384 bins: all at once)
+  const int chunk_shift = (chunk && (chunk & (chunk - 1u)) == 0u) ? (31 - __builtin_clz(chunk)) : -1;   // power of two: shifts
+  for (uint32_t base = 0; base < nb; base += (uint32_t)TB * 4u * NT) {
+    uint4 v[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const uint32_t i0 = base + ((uint32_t)j * TB + tid) * 4u;
+      v[j] = i0 < nb ? reinterpret_cast<const uint4*>(totals)[i0 >> 2] : make_uint4(0u, 0u, 0u, 0u);
+      if (i0 + 1u >= nb) v[j].y = 0u;     // (the padding entries of the allocation hold nothing)
+      if (i0 + 2u >= nb) v[j].z = 0u;
+      if (i0 + 3u >= nb) v[j].w = 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const uint32_t i0 = base + ((uint32_t)j * TB + tid) * 4u;
+      const uint32_t local = v[j].x + v[j].y + v[j].z + v[j].w;
+      uint32_t incl = local;
+#pragma unroll
+      for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      __syncthreads();              // (s_wave of the previous tile has been read)
+      if (lane == 63u) s_wave[wave] = incl;
+      __syncthreads();
+      uint32_t wave_off = 0, tile_total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)TB / 64u; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) wave_off += t;
+        tile_total += t;
+      }
+      const uint32_t e0 = carry + wave_off + incl - local;
+      const uint32_t e1 = e0 + v[j].x, e2 = e1 + v[j].y, e3 = e2 + v[j].z, e4 = e3 + v[j].w;
+      if (i0 < nb) reinterpret_cast<uint4*>(cursor)[i0 >> 2] = make_uint4(e0, e1, e2, e3);
+      if (cursor2 && i0 < nb) reinterpret_cast<uint4*>(cursor2)[i0 >> 2] = make_uint4(e0, e1, e2, e3);
+      if (chunk_bin) {              // chunks whose first position p0 = c * chunk lies in [start, end) of a non-empty bin
+        const uint32_t st[5] = {e0, e1, e2, e3, e4};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (st[k + 1] == st[k]) continue;
+          const uint64_t c0 = chunk_shift >= 0 ? ((uint64_t)st[k] + chunk - 1u) >> chunk_shift
+                                               : ((uint64_t)st[k] + chunk - 1u) / chunk;
+          for (uint64_t c = c0; c * chunk < (uint64_t)st[k + 1]; ++c) chunk_bin[c] = i0 + (uint32_t)k;
+        }
+      }
+      carry += tile_total;
+    }
+  }
+  if (tid == 0) status->n_valid = carry;
+}
+
 // group_offsets_kernel, the exclusive scan of the bin totals and (2-D tile order) the chunk -> first-tile table in ONE
 // launch instead of three: every workgroup turns its 256 histogram columns into per-slice start offsets and publishes
 // their totals; the workgroup that draws the last ticket (an agent-scope atomic in the status block, release fence
@@ -1923,57 +2014,7 @@ __global__ __launch_bounds__(BLOCK) void group_offsets_scan_kernel(uint32_t* his
   __syncthreads();
   if (!s_last) return;             // (workgroup-uniform)
   __threadfence();                 // every other workgroup's totals are visible to this one
-  const uint32_t lane = tid & 63u, wave = tid >> 6;
-  uint32_t carry = 0;
-  constexpr int NT = 16;           // tiles of BLOCK * 4 bins whose loads are issued together (16 384 bins: all at once)
-  const int chunk_shift = (chunk && (chunk & (chunk - 1u)) == 0u) ? (31 - __builtin_clz(chunk)) : -1;   // power of two: shifts
-  for (uint32_t base = 0; base < nb; base += (uint32_t)BLOCK * 4u * NT) {
-    uint4 v[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const uint32_t i0 = base + ((uint32_t)j * BLOCK + tid) * 4u;
-      v[j] = i0 < nb ? reinterpret_cast<const uint4*>(totals)[i0 >> 2] : make_uint4(0u, 0u, 0u, 0u);
-      if (i0 + 1u >= nb) v[j].y = 0u;     // (the padding entries of the allocation hold nothing)
-      if (i0 + 2u >= nb) v[j].z = 0u;
-      if (i0 + 3u >= nb) v[j].w = 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const uint32_t i0 = base + ((uint32_t)j * BLOCK + tid) * 4u;
-      const uint32_t local = v[j].x + v[j].y + v[j].z + v[j].w;
-      uint32_t incl = local;
-#pragma unroll
-      for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-        if (lane >= d) incl += up;
-      }
-      __syncthreads();              // (s_wave of the previous tile has been read)
-      if (lane == 63u) s_wave[wave] = incl;
-      __syncthreads();
-      uint32_t wave_off = 0, tile_total = 0;
-#pragma unroll
-      for (uint32_t w = 0; w < (uint32_t)BLOCK / 64u; ++w) {
-        const uint32_t t = s_wave[w];
-        if (w < wave) wave_off += t;
-        tile_total += t;
-      }
-      const uint32_t e0 = carry + wave_off + incl - local;
-      const uint32_t e1 = e0 + v[j].x, e2 = e1 + v[j].y, e3 = e2 + v[j].z, e4 = e3 + v[j].w;
-      if (i0 < nb) reinterpret_cast<uint4*>(cursor)[i0 >> 2] = make_uint4(e0, e1, e2, e3);
-      if (chunk_bin) {              // chunks whose first position p0 = c * chunk lies in [start, end) of a non-empty bin
-        const uint32_t st[5] = {e0, e1, e2, e3, e4};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (st[k + 1] == st[k]) continue;
-          const uint64_t c0 = chunk_shift >= 0 ? ((uint64_t)st[k] + chunk - 1u) >> chunk_shift
-                                               : ((uint64_t)st[k] + chunk - 1u) / chunk;
-          for (uint64_t c = c0; c * chunk < (uint64_t)st[k + 1]; ++c) chunk_bin[c] = i0 + (uint32_t)k;
-        }
-      }
-      carry += tile_total;
-    }
-  }
-  if (tid == 0) status->n_valid = carry;
+  scan_bin_totals<BLOCK>(totals, nb, cursor, nullptr, status, chunk, chunk_bin, s_wave);
 }
 
 template <class T>
@@ -2235,6 +2276,228 @@ __global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* x
       rec_i[pos] = make_uint4((uint32_t)qi, ix, iy, 0u);
       rec_q[2 * (uint64_t)pos] = x;
       rec_q[2 * (uint64_t)pos + 1] = y;
+    }
+  }
+}
+
+// Two-level 2-D grouping.  The one-pass scatter above places 2.4 records per (slice, tile) at C3: every 16-byte record
+// is a partial line whose other records come from other slices -- other XCDs, other L2s -- so each reaches memory as
+// its own 32-byte sector (PMC: 304 MiB written for 153 MiB of records) at the rate of random memory transactions
+// (profiles/r05_tuning.md 2).  Two passes whose runs are whole lines instead:
+//   coarse_scatter2d_kernel  slice -> tile ROW (ntx bins): a slice leaves ~300 consecutive records per row, all written
+//                            by one workgroup -- the partial lines merge in that workgroup's L2;
+//   fine_scatter2d_kernel    tile row -> tile (nty bins), `round` records of a row at a time: LDS ranks, ONE global
+//                            atomic per (round, tile) claims the run's place behind the tile's cursor (the order of
+//                            the records inside a tile is free: every record writes its own output row), then the
+//                            records of a run are written next to each other by one workgroup.
+// No launch between locate2_kernel and the coarse pass: every coarse workgroup forms the start of its slice in every
+// tile row from locate2_kernel's row histograms chist[slice][ntx] (a 128 KiB table at C3, read from L2: the rows of
+// the slices before it, and all of them for the row totals), and -- its loads in flight beside the latency-bound
+// scatter -- the tile totals of ITS share of the tile columns of the per-slice tile histograms (column-block-major,
+// Locate2Args::hist_w); scan_bin_totals_kernel (one workgroup) then scans the nb totals into bin_start[] / cursor2[] /
+// chunk_bin[], which the fine pass and the evaluation read.  (The scan by the coarse workgroup that draws the last
+// ticket was measured: the agent-scope release fence in front of the ticket writes the XCD's L2 back -- an L2 full of
+// partly written record lines -- 256 times: 0.33 ms behind the scatter, 0.19 ms in front of it, against 0.08 + 0.01.)
+template <class T, bool COMPACT>
+__global__ __launch_bounds__(1024) void coarse_scatter2d_kernel(const uint32_t* xi, const uint32_t* yi, const T* qx,
+                                                                 const T* qy, uint64_t nq, uint64_t slice,
+                                                                 const uint32_t* chist, const uint32_t* hist, uint32_t nb,
+                                                                 uint32_t ntx, uint32_t sx, uint4* rec_i, T* rec_q,
+                                                                 uint32_t* totals) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ uint32_t s_wave[16];
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem_raw);   // [ntx]
+  uint32_t* part_b = cur + ntx;                            // [parts][ntx]: rows of the slices before this one
+  uint32_t* part_a = part_b + blockDim.x + ntx;            // [parts][ntx]: rows of all slices; later [blockDim.x] column sums
+  const uint32_t sl = blockIdx.x, tid = threadIdx.x, P = gridDim.x;
+  const uint32_t parts = blockDim.x >= ntx ? blockDim.x / ntx : 1u;
+  const uint32_t per = (P + parts - 1u) / parts;
+  for (uint32_t item = tid; item < parts * ntx; item += blockDim.x) {
+    const uint32_t p = item / ntx, c = item - p * ntx;
+    const uint32_t s0 = p * per, s1 = (s0 + per < P) ? s0 + per : P;
+    uint32_t before = 0, all = 0;
+    uint32_t s = s0;
+    for (; s + 8u <= s1; s += 8u) {
+      uint32_t h[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) h[u] = chist[(uint64_t)(s + u) * ntx + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        all += h[u];
+        if (s + (uint32_t)u < sl) before += h[u];
+      }
+    }
+    for (; s < s1; ++s) {
+      const uint32_t h = chist[(uint64_t)s * ntx + c];
+      all += h;
+      if (s < sl) before += h;
+    }
+    part_b[item] = before;
+    part_a[item] = all;
+  }
+  __syncthreads();
+  // exclusive scan of the row totals, blockDim.x rows at a time (wave scan by cross-lane shifts, wave totals through LDS)
+  {
+    const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = (blockDim.x + 63u) >> 6;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < ntx; c0 += blockDim.x) {
+      const uint32_t c = c0 + tid;
+      uint32_t before = 0, all = 0;
+      if (c < ntx)
+        for (uint32_t p = 0; p < parts; ++p) { before += part_b[p * ntx + c]; all += part_a[p * ntx + c]; }
+      uint32_t incl = all;
+#pragma unroll
+      for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      __syncthreads();
+      if (lane == 63u) s_wave[wave] = incl;
+      __syncthreads();
+      uint32_t wave_off = 0, total = 0;
+      for (uint32_t w = 0; w < nwaves; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) wave_off += t;
+        total += t;
+      }
+      if (c < ntx) cur[c] = carry + wave_off + incl - all + before;
+      carry += total;
+    }
+  }
+  __syncthreads();   // (part_a is free from here on)
+  // this workgroup's share of the tile totals: columns [col0, col0 + cpw) of hist[P][nb], `w` columns at a time by
+  // blockDim.x / w row groups, reduced through LDS
+  {
+    const uint32_t cpw = (nb + P - 1u) / P;
+    const uint32_t col0 = sl * cpw;
+    const uint32_t w = cpw < blockDim.x ? cpw : blockDim.x;
+    const uint32_t nrg = blockDim.x / w;
+    for (uint32_t cb = 0; cb < cpw; cb += w) {
+      const uint32_t col = tid % w, rg = tid / w;
+      const uint32_t bin = col0 + cb + col;
+      uint32_t sum = 0;
+      if (rg < nrg && cb + col < cpw && bin < nb) {
+        const uint32_t* h = hist + (uint64_t)sl * P * cpw + cb + col;   // column-block-major (Locate2Args::hist_w = cpw)
+        uint32_t r = rg;
+        for (; r + 3u * nrg < P; r += 4u * nrg) {
+          const uint32_t h0 = h[(uint64_t)r * cpw], h1 = h[(uint64_t)(r + nrg) * cpw];
+          const uint32_t h2 = h[(uint64_t)(r + 2u * nrg) * cpw], h3 = h[(uint64_t)(r + 3u * nrg) * cpw];
+          sum += h0 + h1 + h2 + h3;
+        }
+        for (; r < P; r += nrg) sum += h[(uint64_t)r * cpw];
+      }
+      __syncthreads();
+      part_a[tid] = sum;
+      __syncthreads();
+      if (tid < w && cb + tid < cpw && col0 + cb + tid < nb) {
+        uint32_t t = 0;
+        for (uint32_t g = 0; g < nrg; ++g) t += part_a[g * w + tid];
+        totals[col0 + cb + tid] = t;
+      }
+    }
+  }
+  const uint64_t q_begin = (uint64_t)sl * slice;
+  uint64_t q_end = q_begin + slice;
+  if (q_end > nq) q_end = nq;
+  constexpr int U = 4;   // queries per thread in flight: the chain load -> LDS atomic -> store is latency
+  for (uint64_t q0 = q_begin + tid; q0 < q_end; q0 += (uint64_t)U * blockDim.x) {
+    uint32_t ix[U], iy[U];
+    T x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t qi = q0 + (uint64_t)u * blockDim.x;
+      const uint64_t qc = qi < q_end ? qi : q_end - 1u;
+      ix[u] = xi[qc];
+      iy[u] = yi ? yi[qc] : 0u;
+      x[u] = qx[qc];
+      y[u] = qy[qc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t qi = q0 + (uint64_t)u * blockDim.x;
+      if (qi >= q_end) break;
+      uint32_t jx = ix[u], jy = iy[u];
+      if (!yi) { jy = jx >> 16; jx &= 0xffffu; }   // locate2_kernel's cell word
+      const uint32_t pos = NDI_CHK(atomicAdd(&cur[NDI_CHK(jx >> sx, ntx, BC_BIN)], 1u), nq, BC_POSITION);
+      if constexpr (COMPACT && sizeof(T) == 4) {
+        rec_i[pos] = make_uint4((uint32_t)qi, jx | (jy << 16), __builtin_bit_cast(uint32_t, x[u]),
+                                __builtin_bit_cast(uint32_t, y[u]));
+      } else {
+        rec_i[pos] = make_uint4((uint32_t)qi, jx, jy, 0u);
+        rec_q[2 * (uint64_t)pos] = x[u];
+        rec_q[2 * (uint64_t)pos + 1] = y[u];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void scan_bin_totals_kernel(const uint32_t* totals, uint32_t nb, uint32_t* cursor,
+                                                               uint32_t* cursor2, StatusBlock* status, uint32_t chunk,
+                                                               uint32_t* chunk_bin) {
+  __shared__ uint32_t s_wave[16];
+  scan_bin_totals<1024>(totals, nb, cursor, cursor2, status, chunk, chunk_bin, s_wave);
+}
+
+// Workgroup (row c, part g of G) takes the rounds g, g + G, ... of `R * blockDim.x` records of tile row c's run
+// [bin_start[c * nty], bin_start[(c + 1) * nty]) of the coarse order; any G is correct (the host sizes it for about
+// one round per workgroup on evenly spread queries).  When the grid is a multiple of 8 * G the parts of a row sit on
+// one XCD (blockIdx.x round-robins over the XCDs): the lines at the seams of neighbouring rounds' runs merge in one L2.
+template <class T, bool COMPACT, int R>
+__global__ __launch_bounds__(1024) void fine_scatter2d_kernel(const uint4* in_i, const T* in_q, uint4* out_i, T* out_q,
+                                                               const uint32_t* bin_start, uint32_t* cursor2,
+                                                               uint64_t nq, uint32_t ntx, uint32_t nty, uint32_t sy,
+                                                               uint32_t G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem_raw);   // [nty]
+  uint32_t* s_base = s_cnt + nty;                            // [nty]
+  const uint32_t tid = threadIdx.x;
+  uint32_t c, g;
+  if ((gridDim.x % (8u * G)) == 0u) {
+    const uint32_t x = blockIdx.x & 7u, r = blockIdx.x >> 3;
+    g = r % G;
+    c = (r / G) * 8u + x;
+  } else {
+    c = blockIdx.x / G;
+    g = blockIdx.x - c * G;
+  }
+  if (c >= ntx) return;
+  const uint64_t p_begin = bin_start[(uint64_t)c * nty];
+  const uint64_t p_end = (c + 1u < ntx) ? (uint64_t)bin_start[(uint64_t)(c + 1u) * nty] : nq;
+  for (uint32_t f = tid; f < nty; f += blockDim.x) s_cnt[f] = 0u;
+  __syncthreads();
+  const uint64_t round = (uint64_t)R * blockDim.x;
+  for (uint64_t r0 = p_begin + (uint64_t)g * round; r0 < p_end; r0 += (uint64_t)G * round) {
+    uint4 rec[R];
+    T rx[R], ry[R];
+    uint32_t f[R], rank[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint64_t p = r0 + (uint64_t)k * blockDim.x + tid;
+      const uint64_t pc = p < p_end ? p : p_end - 1u;
+      rec[k] = in_i[pc];
+      if constexpr (!(COMPACT && sizeof(T) == 4)) { rx[k] = in_q[2 * pc]; ry[k] = in_q[2 * pc + 1]; }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint64_t p = r0 + (uint64_t)k * blockDim.x + tid;
+      const uint32_t jy = (COMPACT && sizeof(T) == 4) ? rec[k].y >> 16 : rec[k].z;
+      f[k] = NDI_CHK(jy >> sy, nty, BC_BIN);
+      rank[k] = p < p_end ? atomicAdd(&s_cnt[f[k]], 1u) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < nty; b += blockDim.x) {
+      const uint32_t n = s_cnt[b];
+      s_base[b] = n ? atomicAdd(&cursor2[(uint64_t)c * nty + b], n) : 0u;
+      s_cnt[b] = 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint64_t p = r0 + (uint64_t)k * blockDim.x + tid;
+      if (p >= p_end) break;
+      const uint64_t pos = NDI_CHK(s_base[f[k]] + rank[k], nq, BC_POSITION);
+      out_i[pos] = rec[k];
+      if constexpr (!(COMPACT && sizeof(T) == 4)) { out_q[2 * pos] = rx[k]; out_q[2 * pos + 1] = ry[k]; }
     }
   }
 }

@@ -473,6 +473,7 @@ constexpr size_t FUSED_LDS_LIMIT = 160 * 1024;          // eval_fused_kernel wit
 // being evaluated (the set is handed back by the eval_done event).
 struct Scratch {
   DevBuf idx, idx2, t, perm, counts, cursor, hist, status, recq, chunkbin;
+  DevBuf perm2, recq2, chist, cursor2;   // two-level 2-D grouping: coarse-ordered records, row histograms, consumable cursors
   hipEvent_t prep_done = nullptr, eval_done = nullptr;
   Scratch() = default;
   Scratch(const Scratch&) = delete;
@@ -2663,6 +2664,13 @@ struct Interp2DImpl final : Interp2DBase {
     static const int cw_env = [] { const char* e = std::getenv("NDI_TILE_CELLWORDS"); return e ? std::atoi(e) : 1; }();   // A/B
     const bool cell_words = tiled && compact_records && both <= LDS_STAGE_LIMIT && cw_env;
     g_last_path.store(tiled ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
+    // Two-level grouping (tile row, then tile: coarse_scatter2d_kernel / fine_scatter2d_kernel) when the one-pass scatter
+    // would leave fewer than a line's worth of records per (slice, tile) and the batch is large enough to pay for the
+    // second pass.  NDI_GROUP_TWO_LEVEL=0 / 1: A/B.
+    static const int tl_env = [] { const char* e = std::getenv("NDI_GROUP_TWO_LEVEL"); return e ? std::atoi(e) : -1; }();
+    const uint32_t ntx = tiled ? nb / nty : 0;
+    const bool two_level = tiled && both <= LDS_STAGE_LIMIT && ntx >= 2 && ntx <= 4096 && nty <= 4096 &&
+                           (tl_env == 1 || (tl_env < 0 && nq >= (1u << 20) && (double)nq / group_blocks() / nb < 8.0));
     uint64_t slice = 0, blocks = 0;
     if (both <= LDS_STAGE_LIMIT) {   // both axes in one launch
       Locate2Args<T> LA{};
@@ -2684,6 +2692,11 @@ struct Interp2DImpl final : Interp2DBase {
         LA.hist = sc.hist.as<uint32_t>();
         LA.nb = nb; LA.sx = sx; LA.sy = sy; LA.nty = nty;
         shmem = ((both_l + 15) & ~(size_t)15) + (size_t)nb * 4;
+        if (two_level) {
+          sc.chist.reserve((size_t)std::max<uint32_t>(group_blocks(), GROUP_MAX_BLOCKS) * ntx * sizeof(uint32_t));
+          LA.chist = sc.chist.as<uint32_t>();
+          LA.ntx = ntx;
+        }
       }
       const unsigned threads = beside_eval ? 256u : threads_for_lds(shmem);
       blocks = std::max<uint64_t>(1, std::min<uint64_t>((nq + 1023) / 1024, tiled ? group_blocks() : 2048));
@@ -2694,6 +2707,11 @@ struct Interp2DImpl final : Interp2DBase {
       slice = (slice + threads - 1) / threads * threads;
       blocks = (nq + slice - 1) / slice;
       LA.slice = slice;
+      if (two_level) {   // column-block-major tile histograms: (blocks * hist_w) words per block, ceil(nb / hist_w) <= blocks blocks
+        LA.hist_w = (uint32_t)((nb + blocks - 1) / blocks);
+        sc.hist.reserve((size_t)blocks * LA.hist_w * blocks * sizeof(uint32_t));
+        LA.hist = sc.hist.as<uint32_t>();
+      }
       allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T, LOCATE_QB>), (int)LDS_STAGE_LIMIT);
       allow_dynamic_lds(reinterpret_cast<const void*>(&locate2_kernel<T, 1>), (int)LDS_STAGE_LIMIT);
       if (slice / threads >= 16) launch1<T>(s, PC_LOCATE, dim3((unsigned)blocks), dim3(threads), shmem, locate2_kernel<T, LOCATE_QB>, LA);
@@ -2715,18 +2733,54 @@ struct Interp2DImpl final : Interp2DBase {
       allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T, true>), (int)(GROUP_MAX_BINS * 4));
       allow_dynamic_lds(reinterpret_cast<const void*>(&group_scatter2d_kernel<T, false>), (int)(GROUP_MAX_BINS * 4));
       ProfScope ps(s, PC_GROUP);
-      {   // slice offsets, the scan of the tile totals and the tile each evaluation chunk starts in: one launch
-        const uint32_t chunk = tile_chunk();
-        const uint64_t nchunks = (nq + chunk - 1) / chunk;
-        sc.chunkbin.reserve(nchunks * sizeof(uint32_t));
+      const uint32_t chunk = tile_chunk();
+      sc.chunkbin.reserve(((nq + chunk - 1) / chunk) * sizeof(uint32_t));
+      if (!two_level)   // slice offsets, the scan of the tile totals and the tile each evaluation chunk starts in: one launch
         hipLaunchKernelGGL(group_offsets_scan_kernel, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
                            sc.hist.as<uint32_t>(), (uint32_t)blocks, nb, sc.counts.as<uint32_t>(),
                            sc.cursor.as<uint32_t>(), st, nq, chunk, sc.chunkbin.as<uint32_t>());
-      }
-      if (P.compact)
+      const uint32_t* yi_in = cell_words ? (const uint32_t*)nullptr : (const uint32_t*)sc.idx2.as<uint32_t>();
+      if (two_level) {
+        sc.perm2.reserve(nq * sizeof(uint4));
+        if (!P.compact) sc.recq2.reserve(nq * 2 * sizeof(T));
+        sc.cursor2.reserve(((size_t)nb + 4) * sizeof(uint32_t));
+        const size_t shm_c = ((size_t)3 * ntx + (size_t)2 * gthreads) * 4;
+        constexpr int FR = 4;                      // records per thread and round of the fine pass
+        static const int ft_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_THREADS"); return e ? std::atoi(e) : 0; }();
+        const unsigned fthreads = (ft_env == 256 || ft_env == 512 || ft_env == 1024) ? (unsigned)ft_env : 1024u;
+        const uint64_t per_row = (nq + ntx - 1) / ntx;
+        const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((per_row + (uint64_t)FR * fthreads - 1) / ((uint64_t)FR * fthreads), 4096));
+        const unsigned fgrid = (unsigned)(((ntx + 7u) / 8u) * 8u * G);
+        if (std::getenv("NDI_TRACE_PLAN"))
+          std::fprintf(stderr, "[ndi plan] two-level grouping ntx=%u nty=%u slices=%llu G=%u\n", ntx, nty,
+                       (unsigned long long)blocks, G);
+        if (P.compact) {
+          allow_dynamic_lds(reinterpret_cast<const void*>(&coarse_scatter2d_kernel<T, true>), (int)(64 * 1024));
+          hipLaunchKernelGGL((coarse_scatter2d_kernel<T, true>), dim3((unsigned)blocks), dim3(gthreads), shm_c, s,
+                             (const uint32_t*)sc.idx.as<uint32_t>(), yi_in, qx, qy, nq, slice,
+                             (const uint32_t*)sc.chist.as<uint32_t>(), (const uint32_t*)sc.hist.as<uint32_t>(), nb, ntx, sx,
+                             sc.perm2.as<uint4>(), (T*)nullptr, sc.counts.as<uint32_t>());
+          hipLaunchKernelGGL(scan_bin_totals_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.counts.as<uint32_t>(), nb,
+                             sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), st, chunk, sc.chunkbin.as<uint32_t>());
+          hipLaunchKernelGGL((fine_scatter2d_kernel<T, true, FR>), dim3(fgrid), dim3(fthreads), (size_t)nty * 8, s,
+                             (const uint4*)sc.perm2.as<uint4>(), (const T*)nullptr, sc.perm.as<uint4>(), (T*)nullptr,
+                             (const uint32_t*)sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), nq, ntx, nty, sy, G);
+        } else {
+          allow_dynamic_lds(reinterpret_cast<const void*>(&coarse_scatter2d_kernel<T, false>), (int)(64 * 1024));
+          hipLaunchKernelGGL((coarse_scatter2d_kernel<T, false>), dim3((unsigned)blocks), dim3(gthreads), shm_c, s,
+                             (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq, slice,
+                             (const uint32_t*)sc.chist.as<uint32_t>(), (const uint32_t*)sc.hist.as<uint32_t>(), nb, ntx, sx,
+                             sc.perm2.as<uint4>(), sc.recq2.as<T>(), sc.counts.as<uint32_t>());
+          hipLaunchKernelGGL(scan_bin_totals_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.counts.as<uint32_t>(), nb,
+                             sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), st, chunk, sc.chunkbin.as<uint32_t>());
+          hipLaunchKernelGGL((fine_scatter2d_kernel<T, false, FR>), dim3(fgrid), dim3(fthreads), (size_t)nty * 8, s,
+                             (const uint4*)sc.perm2.as<uint4>(), (const T*)sc.recq2.as<T>(), sc.perm.as<uint4>(),
+                             sc.recq.as<T>(), (const uint32_t*)sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), nq,
+                             ntx, nty, sy, G);
+        }
+      } else if (P.compact)
         hipLaunchKernelGGL((group_scatter2d_kernel<T, true>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
-                           (const uint32_t*)sc.idx.as<uint32_t>(),
-                           cell_words ? (const uint32_t*)nullptr : (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq,
+                           (const uint32_t*)sc.idx.as<uint32_t>(), yi_in, qx, qy, nq,
                            slice, (const uint32_t*)sc.hist.as<uint32_t>(), (const uint32_t*)sc.cursor.as<uint32_t>(),
                            nb, sx, sy, nty, sc.perm.as<uint4>(), (T*)nullptr);
       else

@@ -1,6 +1,6 @@
 """The A/B variants of the 2-D tile-grouped order (eval_bilinear_tiles_kernel, bilinear.rs:64-99) that the default launch
 never takes -- no staged x slopes (NDI_TILE_SLOPES=0: three divisions per channel), two 512-thread workgroups per CU
-(NDI_TILE_WG=512), other tile sizes (NDI_TILE_TS), other chunk sizes, plain (xi, yi) arrays instead of cell words -- must
+(NDI_TILE_WG=512), other tile sizes (NDI_TILE_TS), other chunk sizes, plain (xi, yi) arrays instead of cell words, the two-level grouping forced on or off -- must
 give the gather order's bits on the same batch.  The knobs are read once per process, so every variant is one child
 process (one at a time: the box allows few processes on the card)."""
 import os
@@ -48,6 +48,12 @@ VARIANTS = [
     {"NDI_TILE_TS": "2"},
     {"NDI_TILE_TS": "3", "NDI_TILE_CHUNK": "1000"},
     {"NDI_TILE_CELLWORDS": "0", "NDI_TILE_CHUNK": "100000"},
+    # two-level grouping (tile row, then tile: coarse_scatter2d_kernel + fine_scatter2d_kernel) forced on / off
+    {"NDI_GROUP_TWO_LEVEL": "1"},
+    {"NDI_GROUP_TWO_LEVEL": "0"},
+    {"NDI_GROUP_TWO_LEVEL": "1", "NDI_TILE_TS": "2", "NDI_GROUP_FINE_THREADS": "256"},
+    {"NDI_GROUP_TWO_LEVEL": "1", "NDI_TILE_CELLWORDS": "0", "NDI_TILE_TS": "3", "NDI_GROUP_BLOCKS": "32"},
+    {"NDI_GROUP_TWO_LEVEL": "1", "NDI_TILE_SPLIT": "0", "NDI_TILE_CHUNK": "1000"},
 ]
 
 

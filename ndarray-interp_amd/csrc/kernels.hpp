@@ -3176,6 +3176,9 @@ struct EvalLanes2Args {
   int mode;
   unsigned long long* first_fail;   // [2]: x, y (range_check_kernel, or this kernel when `check`)
   int check;                        // see EvalLanesArgs
+  // eval_staged2d_kernel: element offset of cell (xi, yi) = (xi * row_cells + yi) * cell_elems -- plain layout: (ny, lanes);
+  // pair-packed (pack_pairs_kernel): (ny - 1, 2 * lanes).  In both, z[xi][yi+1] follows z[xi][yi] at + lanes.
+  uint32_t row_cells, cell_elems;
 };
 
 // the failure conditions of a 2-D query (Interp2D::is_in_x_range / is_in_y_range, interp2d/mod.rs:374-379): x and y
@@ -3359,6 +3362,144 @@ __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
+    const uint32_t total = nq_here * L;
+    if (contig) {
+      T* const o = A.out + base * L;
+      for (uint32_t e0 = lane * VN; e0 < total; e0 += 64u * VN) {
+        if (e0 + VN <= total) {
+          store_stream<true>(reinterpret_cast<V*>(o + e0), *reinterpret_cast<const V*>(s_strip + e0));
+        } else {
+          for (uint32_t e = e0; e < total; ++e) o[e] = s_strip[e];
+        }
+      }
+    } else {
+      for (uint32_t it = lane; it < total; it += 64u) {
+        const uint32_t ql = it / L, l = it - ql * L;
+        A.out[(base + ql) * A.out_stride + l] = s_strip[it];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// 2-D QUERY PER LANE for short rows on grids that do NOT fit LDS (the reference's 100 x 100 x 5 bench grid,
+// benches/bench_interp2d.rs:87-92: 400 KB in f64) -- the corner values of a batch are STAGED through a wave-private LDS
+// strip by cooperative 16-byte loads.  The counters of the query-order kernel on that shape (profiles/r05_tuning.md 1) show
+// the L1 address path as its bound: an item per lane reads every query's 40-byte corner rows as 8-byte pieces, and the
+// texture path coalesces only inside a quad of lanes -- 11.9 L1 accesses per query, 0.39 of its 0.60 ms.  A query's two
+// corners of one grid row, z[xi][yi][*] and z[xi][yi+1][*], are 2 L consecutive values: here they are read whole, by
+// P = ceil(2 L sizeof(T) / 16) neighbouring lanes loading 16 bytes each (at the alignment of T: legal on gfx950), twelve
+// row segments per load instruction at L = 5 in f64, and written to the strip; then every lane evaluates ITS query --
+// searches and the two shared divisors stay in its registers from before the staging -- with all 4 L operands from LDS
+// (segment stride padded against bank conflicts), and the rows leave through a second strip as one sequential stream of
+// 16-byte vectors, as in eval_lanes2d_kernel.  Same operands, same operation order (bilinear.rs:88-97, div_shared).
+// The grid allocation carries 16 spare bytes: the last piece of the last cell's segment may read past the values.
+typedef double dbl2_u __attribute__((ext_vector_type(2), aligned(8)));
+typedef float flt4_u __attribute__((ext_vector_type(4), aligned(4)));
+template <class T>
+struct Piece16;
+template <>
+struct Piece16<double> { using type = dbl2_u; };
+template <>
+struct Piece16<float> { using type = flt4_u; };
+
+template <class T, int TB>
+__global__ __launch_bounds__(TB) void eval_staged2d_kernel(EvalLanes2Args<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int VN = Wide<T>::N;              // = elements per 16-byte piece
+  using V = typename VecT<T, VN>::type;
+  using PV = typename Piece16<T>::type;
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, L = A.lanes;
+  LaneAxis<T> SX, SY;
+  XRecs<T> XX, XY;
+  size_t off = 0;
+  SX = stage_lane_axis<T, TB>(smem_raw, off, A.xk, A.nx, A.dx);
+  SY = stage_lane_axis<T, TB>(smem_raw, off, A.yk, A.ny, A.dy);
+  XX = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), A.nx - 1u};
+  off += XRecs<T>::bytes(A.nx - 1u);
+  XY = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), A.ny - 1u};
+  off += XRecs<T>::bytes(A.ny - 1u);
+  stage_xrecs<T, TB>(XX, A.xk, A.nx);
+  stage_xrecs<T, TB>(XY, A.yk, A.ny);
+  const uint32_t P = (2u * L + (uint32_t)VN - 1u) / (uint32_t)VN;   // 16-byte pieces per row segment
+  const uint32_t seg_e = P * (uint32_t)VN;                         // elements per staged segment
+  const uint32_t qs_e = 2u * seg_e + 2u;                           // elements per query of the corner strip (padded: banks)
+  const uint32_t wave = tid >> 6;
+  constexpr uint32_t WAVES = TB / 64;
+  // per wave: [64] cell offsets | [64][qs_e] corner values | [64][L] results
+  uint32_t* s_o = reinterpret_cast<uint32_t*>(smem_raw + off) + wave * 64u;
+  off += (size_t)WAVES * 64u * sizeof(uint32_t);
+  T* s_c = reinterpret_cast<T*>(smem_raw + off) + (size_t)wave * 64u * qs_e;
+  off += (((size_t)WAVES * 64u * qs_e * sizeof(T)) + 15u) & ~(size_t)15u;
+  T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)wave * 64u * L;
+  __syncthreads();
+  unsigned long long limit = A.check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
+  if (limit > A.nq) limit = A.nq;
+  const uint32_t rowe = A.row_cells * A.cell_elems;
+  const bool contig = A.out_stride == (uint64_t)L;
+  const uint32_t rot = (L & 1u) ? 0u : lane % L;
+  // staging: lane -> (segment of the instruction, piece of the segment)
+  const uint32_t spi = 64u / P;                                    // segments per load instruction
+  const uint32_t seg_l = lane / P, pc = lane - seg_l * P;
+  const bool loader = seg_l < spi;
+  const uint64_t wstep = (uint64_t)gridDim.x * TB;
+  uint64_t base = ((uint64_t)blockIdx.x * WAVES + wave) * 64u;
+  // (Measured and dropped, profiles/r05_tuning.md: the staging loads of batch k + 1 held in registers while batch k is
+  //  evaluated -- 16 pieces per lane, 191 VGPRs -- is no faster in f64 and 1.7 x slower in f32: the kernel is bound by
+  //  instruction issue and LDS bank conflicts, not by the latency of the staging loads.)
+  T xq, yq;
+  {
+    const uint64_t pcq = (base + lane < A.nq) ? base + lane : A.nq - 1u;
+    xq = A.qx[pcq];
+    yq = A.qy[pcq];
+  }
+  for (; base < limit; base += wstep) {
+    const T x = xq, y = yq;
+    {
+      const uint64_t pn = base + wstep + lane;
+      const uint64_t pcq = pn < A.nq ? pn : A.nq - 1u;
+      xq = A.qx[pcq];
+      yq = A.qy[pcq];
+    }
+    if (A.check && base + lane < limit) lane_check2<T>(A.first_fail, base + lane, x, y, SX.k0, SX.kn, SY.k0, SY.kn, A.mode);
+    const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, A.row_cells, A.cell_elems, x, y);
+    s_o[lane] = c.o;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
+    const uint32_t nseg = 2u * nq_here;
+    constexpr int NI = 4;                      // load instructions in flight per wave
+    for (uint32_t s0 = 0; s0 < nseg; s0 += (uint32_t)NI * spi) {
+      PV v[NI];
+      uint32_t dst[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const uint32_t sg = s0 + (uint32_t)k * spi + seg_l;
+        const bool on = loader && sg < nseg;
+        const uint32_t sc = on ? sg : 0u;
+        const uint32_t q = NDI_CHK(sc >> 1, 64u, BC_STRIP), row = sc & 1u;
+        const uint32_t e = s_o[q] + row * rowe + pc * (uint32_t)VN;
+        v[k] = *reinterpret_cast<const PV*>(A.data + e);
+        dst[k] = on ? q * qs_e + row * seg_e + pc * (uint32_t)VN : 0xffffffffu;
+      }
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (dst[k] != 0xffffffffu) {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) s_c[dst[k] + (uint32_t)j] = v[k][j];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const T* g = s_c + lane * qs_e;
+      T* mine = s_strip + lane * L;
+      for (uint32_t k = 0; k < L; ++k) {      // (even L: rotated start, see eval_lanes_kernel)
+        uint32_t l = k + rot;
+        if (l >= L) l -= L;
+        mine[l] = lane_bilinear<T>(g + l, L, seg_e, c);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
     const uint32_t total = nq_here * L;
     if (contig) {
       T* const o = A.out + base * L;

@@ -2463,7 +2463,7 @@ struct Interp2DImpl final : Interp2DBase {
   // Two stages as in Interp1DImpl: prep() = both searches (+ the optional tile grouping) into a scratch set,
   // launch_eval() = the bilinear kernel reading that set.
   struct Plan2 {
-    enum Kind { SMALL, GATHER, TILED, FUSED2, LANES2 } kind = GATHER;
+    enum Kind { SMALL, GATHER, TILED, FUSED2, LANES2, STAGED2 } kind = GATHER;
     int l_qpl = 1;          // LANES2, scalar grids: queries per lane (1, or one 16-byte vector)
     bool l_check = false;   // LANES2: no range pre-pass (NDI_EVAL_FRESH_OUTPUT)
     // FUSED2 (eval_fused2d_kernel)
@@ -2523,6 +2523,56 @@ struct Interp2DImpl final : Interp2DBase {
           const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
           const uint64_t per_wg = (uint64_t)P.f_tb * (lanes == 1 ? (uint64_t)P.l_qpl : 1);
           P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + per_wg - 1) / per_wg, (uint64_t)cu_count() * wg_per_cu));
+          g_last_path.store(NDI_PATH_GATHER);
+          P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
+          if (P.l_check) return P;
+          const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+          ProfScope ps(s, PC_LOCATE);
+          hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
+                             px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode, &st->first_fail[0]);
+          NDI_HIP(hipGetLastError());
+          ps.done();
+          return P;
+        }
+      }
+    }
+    // Short rows on a grid too large for LDS but at home in L2 (the reference's 100 x 100 x 5 bench grid): query per lane
+    // with the batch's corner rows staged through LDS by cooperative 16-byte loads (eval_staged2d_kernel) -- the
+    // query-order kernel is bound by the L1 address path on these.  Measured (profiles/r05_tuning.md): 100 x 100 x 5 f32
+    // 53 vs 37 Gqueries/s; f64 26 vs 33 and every wider row slower (instruction issue + LDS bank conflicts) -- AUTO
+    // takes it for f32 rows of 16-24 bytes only.  NDI_STAGED2D_KERNEL=0 / 1: A/B.
+    {
+      static const bool tune_live3 = std::getenv("NDI_TUNE_LIVE") != nullptr;
+      static const int on_once3 = ShortKnobs::env("NDI_STAGED2D_KERNEL", -1);
+      const int on = tune_live3 ? ShortKnobs::env("NDI_STAGED2D_KERNEL", -1) : on_once3;
+      constexpr int VNg = Wide<T>::N;
+      const size_t cell_b = (size_t)lanes * sizeof(T);
+      const uint64_t cell_e = pair_packed ? 2 * lanes : lanes, row_c = pair_packed ? ny - 1 : ny;
+      const size_t grid_b = (size_t)nx * row_c * cell_e * sizeof(T);
+      if (on != 0 && path != NDI_PATH_BUCKETED && lanes >= 2 && cell_b >= 16 && cell_b <= 128 && nx <= 16384 && ny <= 16384 &&
+          (uint64_t)nx * row_c * cell_e < (1ull << 31) &&
+          (on > 0 || (std::is_same<T, float>::value && cell_b <= 24 && nq >= 65536 && grid_b <= ((size_t)32 << 20) &&
+                      (double)nq * (double)cell_b >= 4.0 * (double)grid_b))) {   // AUTO: where it was measured faster (f32 rows of 16-24 B)
+        px.ensure_dense_lut();
+        py.ensure_dense_lut();
+        const size_t fixed = (((size_t)(nx + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
+                             (((size_t)(ny + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
+                             px.dlut_bytes + py.dlut_bytes + (size_t)(nx - 1 + ny - 1) * 4 * sizeof(T);
+        const size_t pieces = (2 * lanes + VNg - 1) / VNg;
+        const size_t qs_e = 2 * pieces * VNg + 2;
+        auto need_of = [&](unsigned tb) {
+          const size_t w = tb / 64;
+          return fixed + w * 64 * 4 + ((w * 64 * qs_e * sizeof(T) + 15) & ~(size_t)15) + w * 64 * lanes * sizeof(T);
+        };
+        static const int tb_env = ShortKnobs::env("NDI_STAGED2D_TB", 0);
+        unsigned tb = (tb_env == 64 || tb_env == 128 || tb_env == 256) ? (unsigned)tb_env : 256u;
+        if (need_of(tb) > FUSED_LDS_LIMIT) tb = 128u;
+        if (px.dense_ok && py.dense_ok && need_of(tb) <= FUSED_LDS_LIMIT) {
+          P.kind = Plan2::STAGED2;
+          P.f_tb = tb;
+          P.f_lds = need_of(tb);
+          const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
+          P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + P.f_tb - 1) / P.f_tb, (uint64_t)cu_count() * wg_per_cu));
           g_last_path.store(NDI_PATH_GATHER);
           P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
           if (P.l_check) return P;
@@ -2850,7 +2900,7 @@ struct Interp2DImpl final : Interp2DBase {
       launch1<T>(s, PC_EVAL, dim3(gs), dim3(BLOCK), shm, eval_small2d_kernel<T>, S);
       return;
     }
-    if (P.kind == Plan2::LANES2) {
+    if (P.kind == Plan2::LANES2 || P.kind == Plan2::STAGED2) {
       EvalLanes2Args<T> F{};
       F.xk = px.view.lv0; F.yk = py.view.lv0;
       F.nx = (uint32_t)nx; F.ny = (uint32_t)ny;
@@ -2864,6 +2914,22 @@ struct Interp2DImpl final : Interp2DBase {
       F.mode = mode;
       F.first_fail = &st->first_fail[0];
       F.check = P.l_check ? 1 : 0;
+      F.row_cells = (uint32_t)(pair_packed ? ny - 1 : ny);
+      F.cell_elems = (uint32_t)(pair_packed ? 2 * lanes : lanes);
+      if (P.kind == Plan2::STAGED2) {
+        if (std::getenv("NDI_TRACE_PLAN"))
+          std::fprintf(stderr, "[ndi plan] staged2d L=%llu packed=%d tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes,
+                       (int)pair_packed, P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
+#define NDI_S2(TBS)                                                                       \
+  do {                                                                                    \
+    auto kern = eval_staged2d_kernel<T, TBS>;                                             \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);         \
+    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(TBS), P.f_lds, kern, F);                  \
+  } while (0)
+        if (P.f_tb == 256) NDI_S2(256); else if (P.f_tb == 64) NDI_S2(64); else NDI_S2(128);
+#undef NDI_S2
+        return;
+      }
       if (std::getenv("NDI_TRACE_PLAN"))
         std::fprintf(stderr, "[ndi plan] lanes2d L=%llu qpl=%d maxk=%u,%u tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes,
                      P.l_qpl, px.dlut.maxk, py.dlut.maxk, P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
@@ -3513,7 +3579,7 @@ static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
   h->pair_packed = d.lanes * sizeof(T) <= 64 && d.ny >= 2 && (pack_env > 0 || (pack_env < 0 && bytes > FUSED_LDS_LIMIT));
   if (h->pair_packed) {
     const size_t packed = (size_t)d.nx * (d.ny - 1) * 2 * d.lanes * sizeof(T);
-    h->data.reserve(packed);
+    h->data.reserve(packed + 16);   // (+16: eval_staged2d_kernel's last 16-byte piece may read past the values)
     const void* src = d.data;
     DevBuf tmp;
     if (d.memspace != NDI_MEM_DEVICE) {
@@ -3540,7 +3606,7 @@ static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
     NDI_HIP(hipGetLastError());
     NDI_HIP(hipDeviceSynchronize());
   } else {
-    h->data.reserve(bytes);
+    h->data.reserve(bytes + 16);    // (+16: see above)
     NDI_HIP(hipMemcpy(h->data.p, d.data, bytes, kind));
   }
   *out = h.release();

@@ -2399,19 +2399,29 @@ __global__ __launch_bounds__(1024) void coarse_scatter2d_kernel(const uint32_t* 
   const uint64_t q_begin = (uint64_t)sl * slice;
   uint64_t q_end = q_begin + slice;
   if (q_end > nq) q_end = nq;
-  constexpr int U = 4;   // queries per thread in flight: the chain load -> LDS atomic -> store is latency
-  for (uint64_t q0 = q_begin + tid; q0 < q_end; q0 += (uint64_t)U * blockDim.x) {
-    uint32_t ix[U], iy[U];
-    T x[U], y[U];
+  constexpr int U = 4;   // queries per thread and trip; the next trip's loads are in flight while this one's records are
+                         // placed (the chain load -> LDS atomic -> store is latency)
+  if (q_begin >= q_end) return;
+  uint32_t nix[U], niy[U];
+  T nx_[U], ny_[U];
+  auto fetch = [&](uint64_t q0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t qi = q0 + (uint64_t)u * blockDim.x;
       const uint64_t qc = qi < q_end ? qi : q_end - 1u;
-      ix[u] = xi[qc];
-      iy[u] = yi ? yi[qc] : 0u;
-      x[u] = qx[qc];
-      y[u] = qy[qc];
+      nix[u] = xi[qc];
+      niy[u] = yi ? yi[qc] : 0u;
+      nx_[u] = qx[qc];
+      ny_[u] = qy[qc];
     }
+  };
+  fetch(q_begin + tid);
+  for (uint64_t q0 = q_begin + tid; q0 < q_end; q0 += (uint64_t)U * blockDim.x) {
+    uint32_t ix[U], iy[U];
+    T x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { ix[u] = nix[u]; iy[u] = niy[u]; x[u] = nx_[u]; y[u] = ny_[u]; }
+    fetch(q0 + (uint64_t)U * blockDim.x);     // (clamped: past the slice it re-reads the slice's last query)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t qi = q0 + (uint64_t)u * blockDim.x;
@@ -2466,17 +2476,31 @@ __global__ __launch_bounds__(1024) void fine_scatter2d_kernel(const uint4* in_i,
   for (uint32_t f = tid; f < nty; f += blockDim.x) s_cnt[f] = 0u;
   __syncthreads();
   const uint64_t round = (uint64_t)R * blockDim.x;
-  for (uint64_t r0 = p_begin + (uint64_t)g * round; r0 < p_end; r0 += (uint64_t)G * round) {
+  uint64_t r0 = p_begin + (uint64_t)g * round;
+  if (r0 >= p_end) return;         // (workgroup-uniform)
+  // the records of the next round are in flight while this round's ranks are drawn, its runs claimed and written
+  uint4 nrec[R];
+  T nrx[R], nry[R];
+  auto fetch = [&](uint64_t rr) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint64_t p = rr + (uint64_t)k * blockDim.x + tid;
+      const uint64_t pc = p < p_end ? p : p_end - 1u;
+      nrec[k] = in_i[pc];
+      if constexpr (!(COMPACT && sizeof(T) == 4)) { nrx[k] = in_q[2 * pc]; nry[k] = in_q[2 * pc + 1]; }
+    }
+  };
+  fetch(r0);
+  for (; r0 < p_end; r0 += (uint64_t)G * round) {
     uint4 rec[R];
     T rx[R], ry[R];
     uint32_t f[R], rank[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      const uint64_t p = r0 + (uint64_t)k * blockDim.x + tid;
-      const uint64_t pc = p < p_end ? p : p_end - 1u;
-      rec[k] = in_i[pc];
-      if constexpr (!(COMPACT && sizeof(T) == 4)) { rx[k] = in_q[2 * pc]; ry[k] = in_q[2 * pc + 1]; }
+      rec[k] = nrec[k];
+      if constexpr (!(COMPACT && sizeof(T) == 4)) { rx[k] = nrx[k]; ry[k] = nry[k]; }
     }
+    if (r0 + (uint64_t)G * round < p_end) fetch(r0 + (uint64_t)G * round);   // (workgroup-uniform)
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const uint64_t p = r0 + (uint64_t)k * blockDim.x + tid;

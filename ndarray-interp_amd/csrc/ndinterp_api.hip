@@ -2795,39 +2795,44 @@ struct Interp2DImpl final : Interp2DBase {
         if (!P.compact) sc.recq2.reserve(nq * 2 * sizeof(T));
         sc.cursor2.reserve(((size_t)nb + 4) * sizeof(uint32_t));
         const size_t shm_c = ((size_t)3 * ntx + (size_t)2 * gthreads) * 4;
-        constexpr int FR = 4;                      // records per thread and round of the fine pass
+        static const int fr_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_R"); return e ? std::atoi(e) : 4; }();
         static const int ft_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_THREADS"); return e ? std::atoi(e) : 0; }();
+        static const int fg_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_PARTS"); return e ? std::atoi(e) : 0; }();
+        const int FR = (fr_env == 2 || fr_env == 8) ? fr_env : 4;   // records per thread and round of the fine pass
         const unsigned fthreads = (ft_env == 256 || ft_env == 512 || ft_env == 1024) ? (unsigned)ft_env : 1024u;
+        // parts per tile row: one round per workgroup on evenly spread queries (measured at C3, profiles/r05_tuning.md:
+        // 2560 one-round workgroups 78 us; 512 workgroups walking five rounds each with the next round's records in
+        // flight 115 us -- the pass wants its parallelism across workgroups)
         const uint64_t per_row = (nq + ntx - 1) / ntx;
-        const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((per_row + (uint64_t)FR * fthreads - 1) / ((uint64_t)FR * fthreads), 4096));
+        const uint64_t rounds_row = (per_row + (uint64_t)FR * fthreads - 1) / ((uint64_t)FR * fthreads);
+        uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(rounds_row, 4096));
+        if (fg_env > 0) G = (uint32_t)std::min<int>(fg_env, 4096);
         const unsigned fgrid = (unsigned)(((ntx + 7u) / 8u) * 8u * G);
         if (std::getenv("NDI_TRACE_PLAN"))
           std::fprintf(stderr, "[ndi plan] two-level grouping ntx=%u nty=%u slices=%llu G=%u\n", ntx, nty,
                        (unsigned long long)blocks, G);
-        if (P.compact) {
-          allow_dynamic_lds(reinterpret_cast<const void*>(&coarse_scatter2d_kernel<T, true>), (int)(64 * 1024));
-          hipLaunchKernelGGL((coarse_scatter2d_kernel<T, true>), dim3((unsigned)blocks), dim3(gthreads), shm_c, s,
-                             (const uint32_t*)sc.idx.as<uint32_t>(), yi_in, qx, qy, nq, slice,
-                             (const uint32_t*)sc.chist.as<uint32_t>(), (const uint32_t*)sc.hist.as<uint32_t>(), nb, ntx, sx,
-                             sc.perm2.as<uint4>(), (T*)nullptr, sc.counts.as<uint32_t>());
-          hipLaunchKernelGGL(scan_bin_totals_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.counts.as<uint32_t>(), nb,
-                             sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), st, chunk, sc.chunkbin.as<uint32_t>());
-          hipLaunchKernelGGL((fine_scatter2d_kernel<T, true, FR>), dim3(fgrid), dim3(fthreads), (size_t)nty * 8, s,
-                             (const uint4*)sc.perm2.as<uint4>(), (const T*)nullptr, sc.perm.as<uint4>(), (T*)nullptr,
-                             (const uint32_t*)sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), nq, ntx, nty, sy, G);
-        } else {
-          allow_dynamic_lds(reinterpret_cast<const void*>(&coarse_scatter2d_kernel<T, false>), (int)(64 * 1024));
-          hipLaunchKernelGGL((coarse_scatter2d_kernel<T, false>), dim3((unsigned)blocks), dim3(gthreads), shm_c, s,
-                             (const uint32_t*)sc.idx.as<uint32_t>(), (const uint32_t*)sc.idx2.as<uint32_t>(), qx, qy, nq, slice,
-                             (const uint32_t*)sc.chist.as<uint32_t>(), (const uint32_t*)sc.hist.as<uint32_t>(), nb, ntx, sx,
-                             sc.perm2.as<uint4>(), sc.recq2.as<T>(), sc.counts.as<uint32_t>());
-          hipLaunchKernelGGL(scan_bin_totals_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.counts.as<uint32_t>(), nb,
-                             sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), st, chunk, sc.chunkbin.as<uint32_t>());
-          hipLaunchKernelGGL((fine_scatter2d_kernel<T, false, FR>), dim3(fgrid), dim3(fthreads), (size_t)nty * 8, s,
-                             (const uint4*)sc.perm2.as<uint4>(), (const T*)sc.recq2.as<T>(), sc.perm.as<uint4>(),
-                             sc.recq.as<T>(), (const uint32_t*)sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), nq,
-                             ntx, nty, sy, G);
-        }
+        const uint32_t* yi_c = P.compact ? yi_in : (const uint32_t*)sc.idx2.as<uint32_t>();
+        T* rq2 = P.compact ? (T*)nullptr : sc.recq2.as<T>();
+        T* rq1 = P.compact ? (T*)nullptr : sc.recq.as<T>();
+#define NDI_COARSE(CP)                                                                                              \
+  do {                                                                                                              \
+    allow_dynamic_lds(reinterpret_cast<const void*>(&coarse_scatter2d_kernel<T, CP>), (int)(64 * 1024));            \
+    hipLaunchKernelGGL((coarse_scatter2d_kernel<T, CP>), dim3((unsigned)blocks), dim3(gthreads), shm_c, s,          \
+                       (const uint32_t*)sc.idx.as<uint32_t>(), yi_c, qx, qy, nq, slice,                             \
+                       (const uint32_t*)sc.chist.as<uint32_t>(), (const uint32_t*)sc.hist.as<uint32_t>(), nb, ntx,  \
+                       sx, sc.perm2.as<uint4>(), rq2, sc.counts.as<uint32_t>());                                    \
+  } while (0)
+#define NDI_FINE(CP, R)                                                                                             \
+  hipLaunchKernelGGL((fine_scatter2d_kernel<T, CP, R>), dim3(fgrid), dim3(fthreads), (size_t)nty * 8, s,            \
+                     (const uint4*)sc.perm2.as<uint4>(), (const T*)rq2, sc.perm.as<uint4>(), rq1,                   \
+                     (const uint32_t*)sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), nq, ntx, nty, sy, G)
+        if (P.compact) NDI_COARSE(true); else NDI_COARSE(false);
+        hipLaunchKernelGGL(scan_bin_totals_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.counts.as<uint32_t>(), nb,
+                           sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), st, chunk, sc.chunkbin.as<uint32_t>());
+        if (P.compact) { if (FR == 2) NDI_FINE(true, 2); else if (FR == 8) NDI_FINE(true, 8); else NDI_FINE(true, 4); }
+        else { if (FR == 2) NDI_FINE(false, 2); else if (FR == 8) NDI_FINE(false, 8); else NDI_FINE(false, 4); }
+#undef NDI_COARSE
+#undef NDI_FINE
       } else if (P.compact)
         hipLaunchKernelGGL((group_scatter2d_kernel<T, true>), dim3((unsigned)blocks), dim3(gthreads), (size_t)nb * 4, s,
                            (const uint32_t*)sc.idx.as<uint32_t>(), yi_in, qx, qy, nq,

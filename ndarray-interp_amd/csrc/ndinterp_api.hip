@@ -2717,7 +2717,9 @@ struct Interp2DImpl final : Interp2DBase {
     // Two-level grouping (tile row, then tile: coarse_scatter2d_kernel / fine_scatter2d_kernel) when the one-pass scatter
     // would leave fewer than a line's worth of records per (slice, tile) and the batch is large enough to pay for the
     // second pass.  NDI_GROUP_TWO_LEVEL=0 / 1: A/B.
-    static const int tl_env = [] { const char* e = std::getenv("NDI_GROUP_TWO_LEVEL"); return e ? std::atoi(e) : -1; }();
+    static const bool tl_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
+    static const int tl_once = ShortKnobs::env("NDI_GROUP_TWO_LEVEL", -1);
+    const int tl_env = tl_live ? ShortKnobs::env("NDI_GROUP_TWO_LEVEL", -1) : tl_once;
     const uint32_t ntx = tiled ? nb / nty : 0;
     const bool two_level = tiled && both <= LDS_STAGE_LIMIT && ntx >= 2 && ntx <= 4096 && nty <= 4096 &&
                            (tl_env == 1 || (tl_env < 0 && nq >= (1u << 20) && (double)nq / group_blocks() / nb < 8.0));
@@ -3030,7 +3032,12 @@ struct Interp2DImpl final : Interp2DBase {
       const bool split2 = split_env != 0 && slope_env0 != 0 && lv_full >= 2 && lv_full % 2 == 0 &&
                           s1 * s1 * (lv_full / 2) <= 5 * 512 && 512 % (lv_full / 2) == 0 &&
                           2 * (shm_half + static512s) <= 160 * 1024;
-      A.ch_split = split2 ? 2u : 1u;
+      // NDI_TILE_SPLIT=4 (A/B): four 256-thread workgroups per CU, a quarter of the trailing axis each
+      const size_t shm_quarter = (s1 * s1 + (s1 - 1) * s1) * (lanes / 4) * sizeof(T) + 5 * s1 * sizeof(T) + 16;
+      const bool split4 = split_env == 4 && slope_env0 != 0 && lv_full >= 4 && lv_full % 4 == 0 &&
+                          s1 * s1 * (lv_full / 4) <= 5 * 256 && 256 % (lv_full / 4) == 0 && ((lv_full / 4) & (lv_full / 4 - 1)) == 0 &&
+                          4 * (shm_quarter + static512s) <= 160 * 1024;
+      A.ch_split = split4 ? 4u : (split2 ? 2u : 1u);
       {   // item -> (grid row, vector) of the tile staging: ceil(2^32 / vectors per tile row), full and last-column tiles
         const uint64_t lvv = lv_full / A.ch_split;
         const uint64_t full = (((uint64_t)1 << P.ts) + 1) * lvv;
@@ -3071,6 +3078,20 @@ struct Interp2DImpl final : Interp2DBase {
   } while (0)
       if (std::getenv("NDI_TRACE_PLAN"))
         std::fprintf(stderr, "[ndi plan] tiles ts=%u split=%u compact=%d grid=%u\n", P.ts, A.ch_split, (int)P.compact, gx);
+      if (split4) {
+        if constexpr (std::is_same<T, float>::value) {
+          if (P.compact) {
+            auto kern = eval_bilinear_tiles_kernel<T, VNt, 256, 256, 5, true, true>;
+            allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(40 * 1024 - 256 * (16 + 2 * sizeof(T)) - 512));
+            launch1<T>(s, PC_EVAL, dim3(gx), dim3(256), shm_quarter, kern, A);
+            return;
+          }
+        }
+        auto kern = eval_bilinear_tiles_kernel<T, VNt, 256, 256, 5, false, true>;
+        allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(40 * 1024 - 256 * (16 + 2 * sizeof(T)) - 512));
+        launch1<T>(s, PC_EVAL, dim3(gx), dim3(256), shm_quarter, kern, A);
+        return;
+      }
       if (split2) {
         if constexpr (std::is_same<T, float>::value) {
           if (P.compact) {

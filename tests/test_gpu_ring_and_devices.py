@@ -2,6 +2,7 @@
 share at full size, the resident locator (ndi_locator_*), scratch-set reclaim, element-type checks, and several
 devices driven from one process.  All through the C ABI (via the host mirror), checked against the CPU oracle."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -538,3 +539,64 @@ def test_bucket_index_edge_axes(pkg, dt):
     for path in (pkg.PATH_BUCKETED, pkg.PATH_GATHER):
         sp.strategy.path = path
         assert np.array_equal(sp.interp_array(qq), ref), path
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_two_level_grouping_skewed_batches_and_ring(pkg, capfd, dt):
+    """The two-level 2-D grouping (tile row, then tile: coarse_scatter2d_kernel / fine_scatter2d_kernel, forced with
+    NDI_GROUP_TWO_LEVEL=1 -- AUTO takes it only for batches of a million queries) on batches that are anything but evenly
+    spread: every query in ONE tile, in one tile row, in one tile column, two far corners, a batch smaller than a
+    workgroup; tile rows without a single query; then chunk by chunk through the two-stream ring pipeline (256-thread
+    grouping workgroups beside the evaluation).  Bit-equal to the oracle (bilinear.rs:64-99) and to the gather order."""
+    import torch
+    rng = np.random.default_rng(77)
+    nx, ny, Cn = 150, 131, 32 if dt == np.float32 else 16
+    g = rng.uniform(-1, 1, (nx, ny, Cn)).astype(dt)
+    x = knots("rand", nx, rng, dt); y = knots("rand", ny, rng, dt)
+    interp = pkg.Interp2DBuilder.new(g).x(x).y(y).build()
+    dev = torch.device("cuda:0")
+
+    def batch(kind, Q):
+        if kind == "one_tile":
+            return rng.uniform(x[3], x[5], Q), rng.uniform(y[70], y[72], Q)
+        if kind == "one_row":
+            return rng.uniform(x[40], x[41], Q), rng.uniform(y[0], y[-1], Q)
+        if kind == "one_col":
+            return rng.uniform(x[0], x[-1], Q), rng.uniform(y[-3], y[-1], Q)
+        if kind == "corners":
+            s = rng.integers(0, 2, Q).astype(bool)
+            return np.where(s, rng.uniform(x[0], x[1], Q), rng.uniform(x[-2], x[-1], Q)), \
+                np.where(s, rng.uniform(y[0], y[1], Q), rng.uniform(y[-2], y[-1], Q))
+        return rng.uniform(x[0], x[-1], Q), rng.uniform(y[0], y[-1], Q)
+
+    os.environ["NDI_GROUP_TWO_LEVEL"] = "1"
+    os.environ["NDI_TRACE_PLAN"] = "1"
+    try:
+        for kind, Q in (("one_tile", 50_001), ("one_row", 33_333), ("one_col", 40_000), ("corners", 70_003), ("uniform", 100),
+                        ("uniform", 120_000)):
+            qx, qy = batch(kind, Q)
+            qx = qx.astype(dt); qy = qy.astype(dt)
+            ref = oracle.interp2d_bilinear(x, y, g, qx, qy)[3].reshape(Q, Cn)
+            interp.strategy.path = pkg.PATH_BUCKETED
+            out = torch.full((Q, Cn), -5.0, dtype=torch.float32 if dt == np.float32 else torch.float64, device=dev)
+            interp.interp_array_into(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), out)
+            assert pkg.profile_read(reset=False)["last_path"] == "bucketed", kind
+            assert np.array_equal(out.cpu().numpy(), ref), (kind, Q)
+            assert "two-level grouping" in capfd.readouterr().err, kind      # (the plan line: no silent one-pass scatter)
+        # the ring pipeline: search + two-level grouping of chunk k + 1 on the side stream while chunk k is evaluated
+        Q, chunk = 90_001, 11_000
+        qx, qy = batch("corners", Q)
+        qx = qx.astype(dt); qy = qy.astype(dt)
+        ref = oracle.interp2d_bilinear(x, y, g, qx, qy)[3].reshape(Q, Cn)
+        got = np.zeros_like(ref)
+        ring = pkg.striped_ring(chunk, Cn, 3, dt, 0)
+
+        def consumer(c, rows):
+            got[c.q_begin:c.q_begin + c.q_count] = rows.cpu().numpy()
+        interp.interp_array_ring(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), chunk, consumer, slots=ring)
+        assert np.array_equal(got, ref)
+        assert capfd.readouterr().err.count("two-level grouping") >= (Q + chunk - 1) // chunk
+    finally:
+        os.environ.pop("NDI_GROUP_TWO_LEVEL", None)
+        os.environ.pop("NDI_TRACE_PLAN", None)
+    interp.strategy.path = pkg.PATH_GATHER

@@ -2091,11 +2091,19 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
           s_s[j] = rec_value(r, T(0));
         }
         __syncthreads();
-        for (uint32_t j = 0; j < cnt; ++j) {
+        auto emit = [&](uint32_t i, uint32_t qi, T sj) {
+          const RowCoef<T, STRAT> c = row_coef<T, STRAT>(A.knots, i, sj, sj);
+          V* o = reinterpret_cast<V*>(A.out + (uint64_t)qi * A.out_stride);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint64_t v = v0 + (uint64_t)u * BLOCK;
+            if (FULL || v < LV) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
+          }
+        };
+        for (uint32_t j = 0; j < cnt;) {
           const uint32_t i = NDI_CHK((uint32_t)__builtin_amdgcn_readfirstlane((int)s_i[j]), A.n_int, BC_INTERVAL);
           const uint32_t qi = NDI_CHK((uint32_t)__builtin_amdgcn_readfirstlane((int)s_q[j]), A.nq, BC_QUERY);
-          if (qi >= limit) continue;
-          const T sj = s_s[j];
+          if (qi >= limit) { ++j; continue; }
           if (i != cur) {
             cur = i;
             const V* yl = reinterpret_cast<const V*>(A.data + (uint64_t)i * A.lanes);
@@ -2119,15 +2127,12 @@ __global__ __launch_bounds__(BLOCK) void eval_bucketed_kernel(Eval1Args<T> A) {
             // ahead without limit, is SLOWER (5.10-5.37 ms vs 4.93): the waits the compiler places below for the
             // reload path (vmcnt(28) ... vmcnt(7)) act on the wave's own stores on the common path -- vmcnt counts
             // stores on CDNA4 -- and keep about one query's stores in flight per wave, which is the pacing the
-            // memory system runs best at together with the polynomial's VALU work.
+            // memory system runs best at together with the polynomial's VALU work.  (Round 5, profiles/r05_tuning.md 6:
+            // the same-interval queries in a loop of their own with an EXPLICIT s_waitcnt vmcnt(N), N = 4 / 8 / 12 / 20
+            // stores in flight per wave -- every N within the run-to-run noise of the implicit pacing, f64 and f32.)
           }
-          const RowCoef<T, STRAT> c = row_coef<T, STRAT>(A.knots, i, sj, sj);
-          V* o = reinterpret_cast<V*>(A.out + (uint64_t)qi * A.out_stride);
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const uint64_t v = v0 + (uint64_t)u * BLOCK;
-            if (FULL || v < LV) store_stream<NT>(o + v, row_point<T, STRAT, V>(c, ryl[u], ryr[u], ra[u], rb[u]));
-          }
+          emit(i, qi, s_s[j]);
+          ++j;
         }
       }
     }

@@ -27,6 +27,11 @@
 //                          per direction and query in a wave-private LDS strip, row-major coalesced stores
 //   eval_bilinear_kernel   2-D gather order, two-kernel form (bilinear.rs:83-97), plain or pair-packed grid
 //                          (pack_pairs_kernel): axes too long for LDS, small batches
+//   coarse_scatter2d_kernel, scan_bin_totals_kernel, fine_scatter2d_kernel
+//                          2-D tile grouping in two levels (tile row, then tile) for large batches: whole-line record
+//                          runs instead of one 32-byte sector per record (group_scatter2d_kernel: the one-pass form)
+//   eval_staged2d_kernel   2-D query per lane on grids beyond LDS: the batch's corner rows staged through a wave-private
+//                          LDS strip by cooperative 16-byte loads (the reference's 100 x 100 x 5 grid in f32)
 //   eval_bilinear_tiles_kernel
 //                          2-D tile-grouped order (locate2_kernel's tile histogram + group_scatter2d_kernel): every
 //                          tile of grid points staged once in LDS (double-buffered through registers) together with

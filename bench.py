@@ -413,7 +413,8 @@ def short_rows_leg(pkg, torch, dev, out_bytes=4e9, steps=5):
     times, output TB/s, and the long-row bucketed kernel (32 KiB rows) on the SAME buffer as the yardstick."""
     rng = np.random.default_rng(0)
     res = {"what": "1D CubicSpline, 1024 random knots, 4 GB of output per call, device buffers; out_TBps = output bytes / "
-                   "wall time of a whole interp_array_into call (search [+ grouping] + evaluation)", "shapes": []}
+                   "wall time of a whole interp_array_into call (search [+ grouping] + evaluation); interp_array_* = the same "
+                   "with interp_array's semantics (fresh output: no range pre-pass)", "shapes": []}
     for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
         el = np.dtype(dt).itemsize
         x = np.unique(rng.uniform(0, 1, 2048).astype(dt))[:1024]
@@ -436,12 +437,25 @@ def short_rows_leg(pkg, torch, dev, out_bytes=4e9, steps=5):
             wall = (time.perf_counter() - t0) / steps
             interp.strategy.finish()
             prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
+            # interp_array semantics (the output is the call's own: NDI_EVAL_FRESH_OUTPUT -- the query-order kernels
+            # test the range themselves, no pre-pass; the grouped forms have none to drop)
+            fcall = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True, fresh=True)
+            fcall(); interp.strategy.finish()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fcall()
+            torch.cuda.synchronize()
+            fwall = (time.perf_counter() - t0) / steps
+            interp.strategy.finish()
             res["shapes"].append({"dtype": np.dtype(dt).name, "lanes": L, "queries": Q, "path": prof["last_path"],
                                   "ms": round(wall * 1e3, 4), "out_TBps": round(Q * L * el / wall / 1e12, 3),
                                   "Gpoints_s": round(Q * L / wall / 1e9, 1),
                                   "eval_ms": round(prof["eval_ms"] / steps, 4),
                                   "locate_ms": round(prof["locate_ms"] / steps, 4),
-                                  "group_ms": round(prof["group_ms"] / steps, 4)})
+                                  "group_ms": round(prof["group_ms"] / steps, 4),
+                                  "interp_array_ms": round(fwall * 1e3, 4),
+                                  "interp_array_out_TBps": round(Q * L * el / fwall / 1e12, 3)})
             interp.strategy.release()
             del interp, qd, yd, out
         del buf

@@ -1086,7 +1086,9 @@ struct EvalFusedArgs {
                          // (cubic) / 2 * lv (linear) for the interval-packed copy (pack_intervals_kernel), where data
                          // / ca / cb point at the y / a / b parts of interval 0's record
   int mode;              // ExtrapMode
-  const unsigned long long* first_fail;
+  unsigned long long* first_fail;
+  int check;             // 1: no range pre-pass ran (NDI_EVAL_FRESH_OUTPUT): the kernel tests every query itself, records
+                         // the lowest failing index and writes every row (the output is the call's own, dropped on Err)
   int debug;             // NDI_TUNING builds only (measurement aid, results meaningless): bit 0 no search, bit 1 every
                          // item reads interval (lane & 7), bit 2 no stores, bit 3 no operand loads at all
 };
@@ -1095,6 +1097,9 @@ template <class V, bool LDS>
 struct TabPtr { using type = const V*; };
 template <class V>
 struct TabPtr<V, true> { using type = const __attribute__((address_space(3))) V*; };
+
+template <class T>
+__device__ __forceinline__ bool lane_query_fails(T x, T k0, T kn, int mode);
 
 template <class T, int STRAT, int VEC, int UNR, int TB, int TLDS>
 __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
@@ -1176,7 +1181,7 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
   const T k0 = GK ? A.pyr.lv0[0] : (T)P.lv0[0], kn = GK ? A.pyr.lv0[n - 1] : (T)P.lv0[n - 1];
   const uint32_t lane = tid & 63u;
   const bool contig = A.out_stride == (uint64_t)A.lanes;
-  unsigned long long limit = *A.first_fail;
+  unsigned long long limit = A.check ? NO_FAIL : *A.first_fail;
   if (limit > A.nq) limit = A.nq;
   const uint64_t wave_step = (uint64_t)gridDim.x * TB;
   // The queries of QB batches are requested together, one round ahead.  The counter that orders a wave's memory
@@ -1210,6 +1215,8 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
     for (int j = 1; j < QB; ++j)
       if (jb == j) x = xc[j];
     const bool inr = (k0 <= x) && (x <= kn);
+    if (A.check && base + lane < limit && lane_query_fails<T>(x, k0, kn, A.mode))   // fresh output: the range test rides along
+      atomicMin(A.first_fail, (unsigned long long)(base + lane));
     T xs = x;
     if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;   // cubic_spline.rs:805-809
     // (queries at / after the first failing one never get here; an inactive lane searches k0)
@@ -3039,8 +3046,13 @@ struct EvalFused2Args {
   uint32_t cell_vecs;      // vectors between z[xi][yi] and z[xi][yi+1]'s slot: lv (plain grid) or 2 lv (pair-packed)
   uint32_t row_vecs;       // vectors between grid rows xi and xi + 1
   int mode;
-  const unsigned long long* first_fail;   // [2]: x, y (range_check_kernel)
+  unsigned long long* first_fail;   // [2]: x, y (range_check_kernel, or this kernel when `check`)
+  int check;                        // see EvalFusedArgs
 };
+
+template <class T>
+__device__ __forceinline__ void lane_check2(unsigned long long* first_fail, uint64_t qi, T x, T y, T x0, T xn, T y0, T yn,
+                                            int mode);
 
 template <class T, int VEC, int UNR, int TB>
 __global__ __launch_bounds__(TB) void eval_fused2d_kernel(EvalFused2Args<T> A) {
@@ -3086,7 +3098,7 @@ __global__ __launch_bounds__(TB) void eval_fused2d_kernel(EvalFused2Args<T> A) {
   const uint32_t lane = tid & 63u;
   const uint32_t LV = A.lv;
   const bool contig = A.out_stride == (uint64_t)A.lanes;
-  unsigned long long limit = A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1];
+  unsigned long long limit = A.check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
   if (limit > A.nq) limit = A.nq;
   const V* const G = reinterpret_cast<const V*>(A.data);
   const uint64_t wave_step = (uint64_t)gridDim.x * TB;
@@ -3124,6 +3136,7 @@ __global__ __launch_bounds__(TB) void eval_fused2d_kernel(EvalFused2Args<T> A) {
 #pragma unroll
     for (int j = 1; j < QB; ++j)
       if (jb == j) { x = xc[j]; y = yc[j]; }
+    if (A.check && base + lane < limit) lane_check2<T>(A.first_fail, base + lane, x, y, x0, xn, y0, yn, A.mode);   // fresh output
     const uint32_t xi = lutx ? locate_index_lut<T>(PX, lutx, A.bx.m, A.bx.scale, x0, xn, x)
                              : locate_index<T, lds_ptr<T>>(PX, x0, xn, x, lane);   // all 64 lanes take part
     const uint32_t yi = luty ? locate_index_lut<T>(PY, luty, A.by.m, A.by.scale, y0, yn, y)

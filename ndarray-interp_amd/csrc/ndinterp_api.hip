@@ -1506,7 +1506,7 @@ struct Interp1DImpl final : Interp1DBase {
 
   // Query-order fused search + evaluation (short rows): decides the variant and its launch shape, and enqueues the
   // range pre-pass the kernel relies on.  Returns false when the shape is not eligible.
-  bool plan_fused(hipStream_t s, Scratch& sc, Plan1& P, const ShortKnobs& K) {
+  bool plan_fused(hipStream_t s, Scratch& sc, Plan1& P, const ShortKnobs& K, int flags = 0) {
     static const int long_axes = ShortKnobs::env("NDI_FUSED_LONG_AXES", 1);   // A/B: 0 = axes up to half the LDS only
     static const int global_axes = ShortKnobs::env("NDI_FUSED_GLOBAL_AXES", 1);   // A/B: 0 = two-kernel form for axes beyond LDS
     const uint64_t LV = P.LV;
@@ -1527,6 +1527,8 @@ struct Interp1DImpl final : Interp1DBase {
       P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + 255) / 256, (uint64_t)cu_count() * 8 * 4));
       P.kind = Plan1::FUSED;
       g_last_path.store(NDI_PATH_GATHER);
+      P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
+      if (P.l_check) return true;
       StatusBlock* st = sc.status.as<StatusBlock>();
       const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
       const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + BLOCK - 1) / BLOCK, 4096));
@@ -1602,6 +1604,8 @@ struct Interp1DImpl final : Interp1DBase {
     P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + P.f_tb - 1) / P.f_tb, want));
     P.kind = Plan1::FUSED;
     g_last_path.store(NDI_PATH_GATHER);
+    P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;     // fresh output: the kernel's own range test, no pre-pass
+    if (P.l_check) return true;
     StatusBlock* st = sc.status.as<StatusBlock>();
     const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
     const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + BLOCK - 1) / BLOCK, 4096));
@@ -1635,7 +1639,7 @@ struct Interp1DImpl final : Interp1DBase {
       constexpr int VN0 = Wide<T>::N;
       P.vec_ok = (lanes % VN0 == 0) && (out_stride % VN0 == 0) && aligned16(out);
       P.LV = P.vec_ok ? lanes / VN0 : lanes;
-      if (K0.mode != 1 && K0.mode != 3 && plan_fused(s, sc, P, K0)) return P;
+      if (K0.mode != 1 && K0.mode != 3 && plan_fused(s, sc, P, K0, flags)) return P;
     }
     if (small_first) {
       // short trailing axes: range pre-check (so rows after the first failing query stay untouched in the
@@ -1682,7 +1686,7 @@ struct Interp1DImpl final : Interp1DBase {
                                         // (8192 knots x 128 f32 lanes, 12.6 MB: 3.94 vs 2.21 TB/s; tools/group_vs_fused_probe.py)
                                         (lanes * sizeof(T) >= 512 && (size_t)(3 * n - 2) * lanes * sizeof(T) >= ((size_t)8 << 20)))));
     }
-    if (short_rows && !grouped_short && !bucketed && K.mode != 1 && K.mode != 3 && plan_fused(s, sc, P, K)) return P;
+    if (short_rows && !grouped_short && !bucketed && K.mode != 1 && K.mode != 3 && plan_fused(s, sc, P, K, flags)) return P;
     g_last_path.store(bucketed || grouped_short ? NDI_PATH_BUCKETED : NDI_PATH_GATHER);
     sc.idx.reserve(nq * sizeof(uint32_t));   // the two-kernel forms: interval index (and t) per query
     if (strategy == NDI_CUBIC_SPLINE) sc.t.reserve(nq * sizeof(T));
@@ -1895,6 +1899,7 @@ struct Interp1DImpl final : Interp1DBase {
     F.lv_magic = F.lv >= 2 ? (uint32_t)(((1ull << 32) + F.lv - 1) / F.lv) : 0u;
     F.mode = mode;
     F.first_fail = &sc.status.as<StatusBlock>()->first_fail[0];
+    F.check = P.l_check ? 1 : 0;
     F.debug = 0;
 #ifdef NDI_TUNING
     F.debug = ShortKnobs::env("NDI_FUSED_DEBUG", 0);
@@ -1902,10 +1907,10 @@ struct Interp1DImpl final : Interp1DBase {
     constexpr int VN = Wide<T>::N;
     const dim3 grid(P.f_grid), block(P.f_tb);
     if (std::getenv("NDI_TRACE_PLAN"))   // which variant a batch took (tests assert on it; read per call)
-      std::fprintf(stderr, "[ndi plan] fused tables=%s lut=%d pack=%d unr=%d tb=%u grid=%u lds=%zu\n",
+      std::fprintf(stderr, "[ndi plan] fused tables=%s lut=%d pack=%d unr=%d tb=%u grid=%u lds=%zu prepass=%d\n",
                    P.f_tlds == 2 ? "lds{y,k}" : (P.f_tlds == 1 ? "lds{y,a,b}" : (P.f_tlds == 3 ? "memory,knots=global" : "memory")),
                    (int)P.f_lut, (int)P.f_pack,
-                   P.f_unr, P.f_tb, P.f_grid, P.f_lds);
+                   P.f_unr, P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
 #define NDI_FU(ST, VEC, UNR, TB, TL)                                                                   \
   do {                                                                                                 \
     auto kern = eval_fused_kernel<T, ST, VEC, UNR, TB, TL>;                                            \
@@ -2650,6 +2655,8 @@ struct Interp2DImpl final : Interp2DBase {
         const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 32 / (TBf / 64)));
         P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + TBf - 1) / TBf, (uint64_t)cu_count() * wg_per_cu * 4));
         g_last_path.store(NDI_PATH_GATHER);
+        P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
+        if (P.l_check) return P;
         const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
         ProfScope ps(s, PC_LOCATE);
         hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
@@ -2975,9 +2982,10 @@ struct Interp2DImpl final : Interp2DBase {
       F.row_vecs = (uint32_t)((pair_packed ? ny - 1 : ny) * (pair_packed ? 2 * lanes : lanes) / vec);
       F.mode = mode;
       F.first_fail = &st->first_fail[0];
+      F.check = P.l_check ? 1 : 0;
       if (std::getenv("NDI_TRACE_PLAN"))
-        std::fprintf(stderr, "[ndi plan] fused2d vec=%d lv=%u lut=%d tb=%u grid=%u lds=%zu\n", (int)P.f_vec, F.lv, (int)P.f_lut,
-                     P.f_tb, P.f_grid, P.f_lds);
+        std::fprintf(stderr, "[ndi plan] fused2d vec=%d lv=%u lut=%d tb=%u grid=%u lds=%zu prepass=%d\n", (int)P.f_vec, F.lv, (int)P.f_lut,
+                     P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
       constexpr int VNf = Wide<T>::N;
 #define NDI_F2(VEC, TB)                                                                      \
   do {                                                                                       \

@@ -2315,7 +2315,7 @@ __global__ __launch_bounds__(1024) void group_scatter2d_kernel(const uint32_t* x
 // chunk_bin[], which the fine pass and the evaluation read.  (The scan by the coarse workgroup that draws the last
 // ticket was measured: the agent-scope release fence in front of the ticket writes the XCD's L2 back -- an L2 full of
 // partly written record lines -- 256 times: 0.33 ms behind the scatter, 0.19 ms in front of it, against 0.08 + 0.01.)
-template <class T, bool COMPACT>
+template <class T, bool COMPACT, bool SORT = false>
 __global__ __launch_bounds__(1024) void coarse_scatter2d_kernel(const uint32_t* xi, const uint32_t* yi, const T* qx,
                                                                  const T* qy, uint64_t nq, uint64_t slice,
                                                                  const uint32_t* chist, const uint32_t* hist, uint32_t nb,
@@ -2421,6 +2421,94 @@ __global__ __launch_bounds__(1024) void coarse_scatter2d_kernel(const uint32_t* 
   if (q_begin >= q_end) return;
   uint32_t nix[U], niy[U];
   T nx_[U], ny_[U];
+  if constexpr (SORT && COMPACT && sizeof(T) == 4) {
+    // SORTED rounds (compact f32 records): the U * blockDim.x records of a trip are ordered by tile row in LDS -- ranks by
+    // LDS atomics, an exclusive scan of the trip's row counts, every row's run placed behind the slice's cursor -- and
+    // copied out by neighbouring lanes, four 16-byte records to a 64-byte request, instead of one request per record
+    // (1e7 of them at C3: a third of the pass, profiles/r05_tuning.md 2).
+    // LDS behind [cur | part_b | part_a]: [s_cnt | s_off | s_base : ntx each | records U * blockDim.x | destinations]
+    uint32_t* s_cnt = part_a + blockDim.x + ntx;
+    uint32_t* s_off = s_cnt + ntx;
+    uint32_t* s_base = s_off + ntx;
+    uint4* s_rec = reinterpret_cast<uint4*>(smem_raw + ((((size_t)(6u * ntx + 2u * blockDim.x)) * 4u + 15u) & ~(size_t)15u));
+    uint32_t* s_dst = reinterpret_cast<uint32_t*>(s_rec + (size_t)U * blockDim.x);
+    const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = (blockDim.x + 63u) >> 6;
+    for (uint32_t b = tid; b < ntx; b += blockDim.x) s_cnt[b] = 0u;
+    __syncthreads();
+    auto fetch2 = [&](uint64_t q0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t qi = q0 + (uint64_t)u * blockDim.x;
+        const uint64_t qc = qi < q_end ? qi : q_end - 1u;
+        nix[u] = xi[qc];
+        niy[u] = yi ? yi[qc] : 0u;
+        nx_[u] = qx[qc];
+        ny_[u] = qy[qc];
+      }
+    };
+    fetch2(q_begin + tid);
+    for (uint64_t qb = q_begin; qb < q_end; qb += (uint64_t)U * blockDim.x) {   // (workgroup-uniform)
+      uint4 rec[U];
+      uint32_t row[U], rank[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t qi = qb + (uint64_t)u * blockDim.x + tid;
+        uint32_t jx = nix[u], jy = niy[u];
+        if (!yi) { jy = jx >> 16; jx &= 0xffffu; }
+        rec[u] = make_uint4((uint32_t)qi, jx | (jy << 16), __builtin_bit_cast(uint32_t, nx_[u]), __builtin_bit_cast(uint32_t, ny_[u]));
+        row[u] = NDI_CHK(jx >> sx, ntx, BC_BIN);
+      }
+      fetch2(qb + (uint64_t)U * blockDim.x + tid);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t qi = qb + (uint64_t)u * blockDim.x + tid;
+        rank[u] = qi < q_end ? atomicAdd(&s_cnt[row[u]], 1u) : 0u;
+      }
+      __syncthreads();
+      uint32_t carry = 0;
+      for (uint32_t b0 = 0; b0 < ntx; b0 += blockDim.x) {
+        const uint32_t b = b0 + tid;
+        const uint32_t n = b < ntx ? s_cnt[b] : 0u;
+        uint32_t incl = n;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+          if (lane >= d) incl += up;
+        }
+        __syncthreads();
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+        for (uint32_t w = 0; w < nwaves; ++w) {
+          const uint32_t t = s_wave[w];
+          if (w < wave) wave_off += t;
+          total += t;
+        }
+        if (b < ntx) {
+          s_off[b] = carry + wave_off + incl - n;
+          s_base[b] = cur[b];
+          cur[b] += n;
+          s_cnt[b] = 0u;
+        }
+        carry += total;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t qi = qb + (uint64_t)u * blockDim.x + tid;
+        if (qi < q_end) {
+          const uint32_t i = NDI_CHK(s_off[row[u]] + rank[u], (uint32_t)U * blockDim.x, BC_POSITION);
+          s_rec[i] = rec[u];
+          s_dst[i] = s_base[row[u]] + rank[u];
+        }
+      }
+      __syncthreads();
+      const uint64_t left = q_end - qb;
+      const uint32_t n_here = left < (uint64_t)U * blockDim.x ? (uint32_t)left : (uint32_t)U * blockDim.x;
+      for (uint32_t i = tid; i < n_here; i += blockDim.x) rec_i[NDI_CHK(s_dst[i], nq, BC_POSITION)] = s_rec[i];
+    }
+    return;
+  }
   auto fetch = [&](uint64_t q0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2540,6 +2628,95 @@ __global__ __launch_bounds__(1024) void fine_scatter2d_kernel(const uint4* in_i,
       out_i[pos] = rec[k];
       if constexpr (!(COMPACT && sizeof(T) == 4)) { out_q[2 * pos] = rx[k]; out_q[2 * pos + 1] = ry[k]; }
     }
+  }
+}
+
+// fine_scatter2d_kernel with the round's records SORTED in LDS before they leave (compact f32 records): the direct form
+// writes every 16-byte record as a request of its own (64 per store instruction); here a run's records are copied out by
+// neighbouring lanes, four to a 64-byte request.  [s_cnt | s_base | s_off | wave totals | records | destinations]
+template <int R, int TB>
+__global__ __launch_bounds__(TB) void fine_scatter2d_sorted_kernel(const uint4* in_i, uint4* out_i, const uint32_t* bin_start,
+                                                                   uint32_t* cursor2, uint64_t nq, uint32_t ntx,
+                                                                   uint32_t nty, uint32_t sy, uint32_t G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem_raw);   // [nty]
+  uint32_t* s_base = s_cnt + nty;                            // [nty]
+  uint32_t* s_off = s_base + nty;                            // [nty]
+  uint32_t* s_wave = s_off + nty;                            // [16]
+  uint4* s_rec = reinterpret_cast<uint4*>(smem_raw + (((size_t)(3u * nty + 16u) * 4u + 15u) & ~(size_t)15u));   // [R * TB]
+  uint32_t* s_dst = reinterpret_cast<uint32_t*>(s_rec + (size_t)R * TB);                                         // [R * TB]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  uint32_t c, g;
+  if ((gridDim.x % (8u * G)) == 0u) {
+    const uint32_t x = blockIdx.x & 7u, r = blockIdx.x >> 3;
+    g = r % G;
+    c = (r / G) * 8u + x;
+  } else {
+    c = blockIdx.x / G;
+    g = blockIdx.x - c * G;
+  }
+  if (c >= ntx) return;
+  const uint64_t p_begin = bin_start[(uint64_t)c * nty];
+  const uint64_t p_end = (c + 1u < ntx) ? (uint64_t)bin_start[(uint64_t)(c + 1u) * nty] : nq;
+  for (uint32_t f = tid; f < nty; f += TB) s_cnt[f] = 0u;
+  __syncthreads();
+  const uint64_t round = (uint64_t)R * TB;
+  for (uint64_t r0 = p_begin + (uint64_t)g * round; r0 < p_end; r0 += (uint64_t)G * round) {
+    uint4 rec[R];
+    uint32_t f[R], rank[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint64_t p = r0 + (uint64_t)k * TB + tid;
+      rec[k] = in_i[p < p_end ? p : p_end - 1u];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint64_t p = r0 + (uint64_t)k * TB + tid;
+      f[k] = NDI_CHK((rec[k].y >> 16) >> sy, nty, BC_BIN);
+      rank[k] = p < p_end ? atomicAdd(&s_cnt[f[k]], 1u) : 0u;
+    }
+    __syncthreads();
+    // exclusive scan of the round's tile counts (TB bins at a time), the runs' places claimed on the way
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nty; b0 += TB) {
+      const uint32_t b = b0 + tid;
+      const uint32_t n = b < nty ? s_cnt[b] : 0u;
+      uint32_t incl = n;
+#pragma unroll
+      for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      __syncthreads();
+      if (lane == 63u) s_wave[wave] = incl;
+      __syncthreads();
+      uint32_t wave_off = 0, total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)TB / 64u; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) wave_off += t;
+        total += t;
+      }
+      if (b < nty) {
+        s_off[b] = carry + wave_off + incl - n;
+        s_base[b] = n ? atomicAdd(&cursor2[(uint64_t)c * nty + b], n) : 0u;
+        s_cnt[b] = 0u;
+      }
+      carry += total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint64_t p = r0 + (uint64_t)k * TB + tid;
+      if (p < p_end) {
+        const uint32_t i = NDI_CHK(s_off[f[k]] + rank[k], (uint32_t)round, BC_POSITION);
+        s_rec[i] = rec[k];
+        s_dst[i] = s_base[f[k]] + rank[k];
+      }
+    }
+    __syncthreads();
+    const uint32_t n_here = (p_end - r0 < round) ? (uint32_t)(p_end - r0) : (uint32_t)round;
+    for (uint32_t i = tid; i < n_here; i += TB) out_i[NDI_CHK(s_dst[i], nq, BC_POSITION)] = s_rec[i];
   }
 }
 

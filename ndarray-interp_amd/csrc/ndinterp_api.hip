@@ -2835,10 +2835,35 @@ struct Interp2DImpl final : Interp2DBase {
   hipLaunchKernelGGL((fine_scatter2d_kernel<T, CP, R>), dim3(fgrid), dim3(fthreads), (size_t)nty * 8, s,            \
                      (const uint4*)sc.perm2.as<uint4>(), (const T*)rq2, sc.perm.as<uint4>(), rq1,                   \
                      (const uint32_t*)sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), nq, ntx, nty, sy, G)
-        if (P.compact) NDI_COARSE(true); else NDI_COARSE(false);
+        static const int csort_env = [] { const char* e = std::getenv("NDI_GROUP_COARSE_SORT"); return e ? std::atoi(e) : 1; }();
+        const size_t shm_cs = ((((size_t)6 * ntx + 2 * gthreads) * 4 + 15) & ~(size_t)15) + (size_t)4 * gthreads * 20;
+        if (P.compact && std::is_same<T, float>::value && csort_env && shm_cs <= 150 * 1024) {   // trips sorted in LDS (NDI_GROUP_COARSE_SORT=0: direct, A/B)
+          auto kern = coarse_scatter2d_kernel<T, true, true>;
+          allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(150 * 1024));
+          hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gthreads), shm_cs, s,
+                             (const uint32_t*)sc.idx.as<uint32_t>(), yi_c, qx, qy, nq, slice,
+                             (const uint32_t*)sc.chist.as<uint32_t>(), (const uint32_t*)sc.hist.as<uint32_t>(), nb, ntx,
+                             sx, sc.perm2.as<uint4>(), rq2, sc.counts.as<uint32_t>());
+        } else if (P.compact) NDI_COARSE(true); else NDI_COARSE(false);
         hipLaunchKernelGGL(scan_bin_totals_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.counts.as<uint32_t>(), nb,
                            sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), st, chunk, sc.chunkbin.as<uint32_t>());
-        if (P.compact) { if (FR == 2) NDI_FINE(true, 2); else if (FR == 8) NDI_FINE(true, 8); else NDI_FINE(true, 4); }
+        static const int fsort_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_SORT"); return e ? std::atoi(e) : 1; }();
+        if (P.compact && std::is_same<T, float>::value && fsort_env) {   // the round's records sorted in LDS, coalesced copy-out (NDI_GROUP_FINE_SORT=0: the direct form, A/B)
+#define NDI_FSORT(SR, STB)                                                                                          \
+  do {                                                                                                              \
+    const uint64_t rr = (per_row + (uint64_t)SR * STB - 1) / ((uint64_t)SR * STB);                                  \
+    const uint32_t Gs = fg_env > 0 ? G : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(rr, 4096));             \
+    const unsigned sgrid = (unsigned)(((ntx + 7u) / 8u) * 8u * Gs);                                                 \
+    const size_t shm_s = ((((size_t)3 * nty + 16) * 4 + 15) & ~(size_t)15) + (size_t)SR * STB * 20;                 \
+    auto kern = fine_scatter2d_sorted_kernel<SR, STB>;                                                              \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(128 * 1024));                                      \
+    hipLaunchKernelGGL(kern, dim3(sgrid), dim3(STB), shm_s, s, (const uint4*)sc.perm2.as<uint4>(), sc.perm.as<uint4>(), \
+                       (const uint32_t*)sc.cursor.as<uint32_t>(), sc.cursor2.as<uint32_t>(), nq, ntx, nty, sy, Gs); \
+  } while (0)
+          if (fsort_env == 2) NDI_FSORT(8, 512); else if (fsort_env == 3) NDI_FSORT(4, 1024); else if (fsort_env == 4) NDI_FSORT(2, 512);
+          else if (fsort_env == 5) NDI_FSORT(4, 256); else NDI_FSORT(4, 512);
+#undef NDI_FSORT
+        } else if (P.compact) { if (FR == 2) NDI_FINE(true, 2); else if (FR == 8) NDI_FINE(true, 8); else NDI_FINE(true, 4); }
         else { if (FR == 2) NDI_FINE(false, 2); else if (FR == 8) NDI_FINE(false, 8); else NDI_FINE(false, 4); }
 #undef NDI_COARSE
 #undef NDI_FINE

@@ -55,6 +55,10 @@ VARIANTS = [
     {"NDI_GROUP_TWO_LEVEL": "1", "NDI_TILE_TS": "2", "NDI_GROUP_FINE_THREADS": "256"},
     {"NDI_GROUP_TWO_LEVEL": "1", "NDI_TILE_CELLWORDS": "0", "NDI_TILE_TS": "3", "NDI_GROUP_BLOCKS": "32"},
     {"NDI_GROUP_TWO_LEVEL": "1", "NDI_TILE_SPLIT": "0", "NDI_TILE_CHUNK": "1000"},
+    # both passes write their runs DIRECTLY from registers (one request per record) instead of sorting a round in LDS
+    {"NDI_GROUP_TWO_LEVEL": "1", "NDI_GROUP_FINE_SORT": "0", "NDI_GROUP_COARSE_SORT": "0"},
+    {"NDI_GROUP_TWO_LEVEL": "1", "NDI_GROUP_FINE_SORT": "0", "NDI_GROUP_COARSE_SORT": "1", "NDI_GROUP_BLOCKS": "32", "NDI_TILE_TS": "3"},
+    {"NDI_GROUP_TWO_LEVEL": "1", "NDI_GROUP_FINE_SORT": "5", "NDI_GROUP_COARSE_SORT": "0"},
 ]
 
 

@@ -679,15 +679,25 @@ __global__ __launch_bounds__(1024) void locate2_kernel(Locate2Args<T> A) {
       uint32_t* dst = A.hist + (uint64_t)blockIdx.x * A.nb;
       for (uint32_t i = tid; i < A.nb; i += blockDim.x) dst[i] = s_hist[i];
     }
-    if (A.chist) {   // one thread per tile row; the walk along the row starts at a rotated column (banks)
-      for (uint32_t c = tid; c < A.ntx; c += blockDim.x) {
-        const uint32_t* row = s_hist + c * A.nty;
-        uint32_t sum = 0, f = c % A.nty;
-        for (uint32_t k = 0; k < A.nty; ++k) {
-          sum += row[f];
-          f = (f + 1u == A.nty) ? 0u : f + 1u;
+    if (A.chist) {   // `parts` neighbouring lanes per tile row (one lane alone walked 128 LDS reads while 7/8 of the workgroup
+      // idled: 5 us of the kernel's tail at C3), each a share of the row from a rotated start (banks), combined by shuffles
+      const uint32_t parts = A.ntx * 8u <= blockDim.x ? 8u : (A.ntx * 4u <= blockDim.x ? 4u : (A.ntx * 2u <= blockDim.x ? 2u : 1u));
+      const uint32_t share = (A.nty + parts - 1u) / parts;
+      for (uint32_t c0 = 0; c0 < A.ntx; c0 += blockDim.x / parts) {
+        const uint32_t c = c0 + tid / parts, p = tid % parts;
+        uint32_t sum = 0;
+        if (c < A.ntx) {
+          const uint32_t* row = s_hist + c * A.nty;
+          const uint32_t f0 = p * share, f1 = (f0 + share < A.nty) ? f0 + share : A.nty;
+          const uint32_t len = f1 > f0 ? f1 - f0 : 0u;
+          uint32_t f = len ? f0 + c % len : 0u;
+          for (uint32_t k = 0; k < len; ++k) {
+            sum += row[f];
+            f = (f + 1u == f1) ? f0 : f + 1u;
+          }
         }
-        A.chist[(uint64_t)blockIdx.x * A.ntx + c] = sum;
+        for (uint32_t d = 1; d < parts; d <<= 1) sum += (uint32_t)__shfl_xor((int)sum, (int)d, 64);
+        if (c < A.ntx && p == 0u) A.chist[(uint64_t)blockIdx.x * A.ntx + c] = sum;
       }
     }
   }

@@ -31,7 +31,10 @@
 //                          2-D tile grouping in two levels (tile row, then tile) for large batches: whole-line record
 //                          runs instead of one 32-byte sector per record (group_scatter2d_kernel: the one-pass form)
 //   eval_staged2d_kernel   2-D query per lane on grids beyond LDS: the batch's corner rows staged through a wave-private
-//                          LDS strip by cooperative 16-byte loads (the reference's 100 x 100 x 5 grid in f32)
+//                          LDS strip by cooperative 16-byte loads (A/B variant: the quad kernel covers its shapes)
+//   quad_pack_kernel, eval_quads2d_kernel
+//                          short 2-D rows on grids up to 16 MiB: a cell-quad copy of the grid (four corners of a cell and
+//                          channel adjacent), one contiguous record per query read by neighbouring lanes
 //   eval_bilinear_tiles_kernel
 //                          2-D tile-grouped order (locate2_kernel's tile histogram + group_scatter2d_kernel): every
 //                          tile of grid points staged once in LDS (double-buffered through registers) together with
@@ -3781,6 +3784,148 @@ __global__ __launch_bounds__(TB) void eval_staged2d_kernel(EvalLanes2Args<T> A) 
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// CELL-QUAD layout for short rows on small / medium grids (the reference's 100 x 100 x 5 bench grid,
+// benches/bench_interp2d.rs:87-92): QD[xi][yi][c] = { z[xi][yi][c], z[xi+1][yi][c], z[xi][yi+1][c], z[xi+1][yi+1][c] } for
+// every CELL (xi < nx-1, yi < ny-1) and channel -- the four corners a query needs of one channel next to each other, the
+// 4 L values of a cell contiguous and 16-byte aligned (4 x the grid: 1.6 MB for that grid in f64, at home in L2).  A query
+// then reads ONE contiguous record; its lanes -- L of them in f32 (one 16-byte piece per channel: all four corners, the
+// whole bilinear form lane-local), 2 L in f64 (piece 2c = {z11, z21}[c], piece 2c+1 = {z12, z22}[c]: the x direction
+// lane-local, the y direction after one exchange with the neighbouring lane) -- load neighbouring 16-byte pieces, so the
+// texture path sees about three 64-byte accesses per query where the item-per-lane kernel on the row layout needs 11.9
+// (profiles/r05_tuning.md 1: its bound).  Values are copied, never recomputed; operands and operation order are the
+// reference's (bilinear.rs:88-97: x first, then y; div_shared = the bits of the IEEE divisions).
+template <class T>
+__global__ __launch_bounds__(BLOCK) void quad_pack_kernel(const T* data, T* out, uint64_t nx, uint64_t ny, uint64_t lanes,
+                                                          uint64_t row_cells, uint64_t cell_elems) {
+  // element (xi, yi, c) of the source: data[(xi * row_cells + yi) * cell_elems + c] in either layout (pair-packed: the
+  // last grid column is reached as the second half of pair ny - 2)
+  auto src = [&](uint64_t xi, uint64_t yi, uint64_t c) -> T {
+    if (cell_elems == lanes) return data[(xi * row_cells + yi) * cell_elems + c];
+    return yi < row_cells ? data[(xi * row_cells + yi) * cell_elems + c] : data[(xi * row_cells + yi - 1) * cell_elems + lanes + c];
+  };
+  const uint64_t cells = (nx - 1) * (ny - 1), total = cells * lanes;
+  for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t cell = e / lanes, c = e - cell * lanes;
+    const uint64_t xi = cell / (ny - 1), yi = cell - xi * (ny - 1);
+    T* o = out + e * 4;
+    o[0] = src(xi, yi, c);
+    o[1] = src(xi + 1, yi, c);
+    o[2] = src(xi, yi + 1, c);
+    o[3] = src(xi + 1, yi + 1, c);
+  }
+}
+
+template <class T>
+struct EvalQuads2Args {
+  const T* xk;             // [nx]
+  const T* yk;             // [ny]
+  uint32_t nx, ny;
+  DenseLut<T> dx, dy;
+  const T* quads;          // [(nx-1)(ny-1)][lanes][4]
+  const T* qx;
+  const T* qy;
+  T* out;
+  uint64_t nq, out_stride;
+  uint32_t lanes;
+  int mode;
+  unsigned long long* first_fail;   // [2]: x, y
+  int check;                        // see EvalLanesArgs
+};
+
+template <class T, int TB>
+__global__ __launch_bounds__(TB) void eval_quads2d_kernel(EvalQuads2Args<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  constexpr bool F32 = sizeof(T) == 4;
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, L = A.lanes;
+  constexpr uint32_t WAVES = TB / 64;
+  LaneAxis<T> SX, SY;
+  XRecs<T> XX, XY;
+  size_t off = 0;
+  SX = stage_lane_axis<T, TB>(smem_raw, off, A.xk, A.nx, A.dx);
+  SY = stage_lane_axis<T, TB>(smem_raw, off, A.yk, A.ny, A.dy);
+  XX = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), A.nx - 1u};
+  off += XRecs<T>::bytes(A.nx - 1u);
+  XY = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), A.ny - 1u};
+  off += XRecs<T>::bytes(A.ny - 1u);
+  stage_xrecs<T, TB>(XX, A.xk, A.nx);
+  stage_xrecs<T, TB>(XY, A.yk, A.ny);
+  // per wave: [64] record offsets | [6][64] fx, fy, dx, 1/dx, dy, 1/dy
+  uint32_t* w_o = reinterpret_cast<uint32_t*>(smem_raw + off) + wave * 64u;
+  off += (size_t)WAVES * 64u * sizeof(uint32_t);
+  T* w_s = reinterpret_cast<T*>(smem_raw + off) + (size_t)wave * 64u * 6u;
+  __syncthreads();
+  unsigned long long limit = A.check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
+  if (limit > A.nq) limit = A.nq;
+  const uint32_t PL = F32 ? L : 2u * L;              // lanes (16-byte pieces) per query
+  const uint32_t QT = 64u / PL;                      // queries per trip
+  const uint32_t ql = lane / PL, pc = lane - ql * PL;
+  const bool worker = ql < QT;
+  const uint32_t ch = F32 ? pc : pc >> 1;            // the channel this lane serves
+  const bool writer = worker && (F32 || (pc & 1u) == 0u);
+  const uint64_t wstep = (uint64_t)gridDim.x * TB;
+  uint64_t base = ((uint64_t)blockIdx.x * WAVES + wave) * 64u;
+  const T* __restrict__ const quads = A.quads;
+  T* __restrict__ const out = A.out;
+  T xq, yq;
+  {
+    const uint64_t pcq = (base + lane < A.nq) ? base + lane : A.nq - 1u;
+    xq = A.qx[pcq];
+    yq = A.qy[pcq];
+  }
+  for (; base < limit; base += wstep) {
+    const T x = xq, y = yq;
+    {
+      const uint64_t pn = base + wstep + lane;
+      const uint64_t pcq = pn < A.nq ? pn : A.nq - 1u;
+      xq = A.qx[pcq];
+      yq = A.qy[pcq];
+    }
+    if (A.check && base + lane < limit) lane_check2<T>(A.first_fail, base + lane, x, y, SX.k0, SX.kn, SY.k0, SY.kn, A.mode);
+    {
+      const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, A.ny - 1u, 4u * L, x, y);
+      w_o[lane] = c.o;
+      w_s[0 * 64 + lane] = c.fx;
+      w_s[1 * 64 + lane] = c.fy;
+      w_s[2 * 64 + lane] = c.dx.d;
+      w_s[3 * 64 + lane] = c.dx.ok ? c.dx.r : T(0);
+      w_s[4 * 64 + lane] = c.dy.d;
+      w_s[5 * 64 + lane] = c.dy.ok ? c.dy.r : T(0);
+    }
+    __builtin_amdgcn_wave_barrier();        // LDS operations of one wave execute in order: no s_barrier needed
+    const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
+    // (Requesting the pieces of six trips before the first is used -- 24 more VGPRs -- was measured SLOWER, 0.75 vs 0.66 ms
+    //  at L = 5 in f64, 0.35 vs 0.33 in f32: the kernel is bound by instruction issue, not by the latency of its loads.)
+    for (uint32_t q0 = 0; q0 < nq_here; q0 += QT) {
+      const uint32_t q = q0 + ql;
+      const bool act = worker && q < nq_here;
+      const uint32_t qc = NDI_CHK(act ? q : 0u, 64u, BC_STRIP);
+      const V piece = *reinterpret_cast<const V*>(quads + w_o[qc] + (worker ? pc * (uint32_t)VN : 0u));
+      SharedDivisor<T> dx, dy;
+      const T fx = w_s[0 * 64 + qc], fy = w_s[1 * 64 + qc];
+      dx.d = w_s[2 * 64 + qc]; dx.r = w_s[3 * 64 + qc]; dx.ok = dx.r > T(0);
+      dy.d = w_s[4 * 64 + qc]; dy.r = w_s[5 * 64 + qc]; dy.ok = dy.r > T(0);
+      T z1, z2;
+      if constexpr (F32) {                  // piece = {z11, z21, z12, z22} of this lane's channel
+        z1 = div_shared<T, T>(piece[1] - piece[0], dx) * fx + piece[0];
+        z2 = div_shared<T, T>(piece[3] - piece[2], dx) * fx + piece[2];
+      } else {                              // piece = {z11, z21} (even lane) or {z12, z22} (odd lane)
+        const T zx = div_shared<T, T>(piece[1] - piece[0], dx) * fx + piece[0];
+        const T other = __shfl_xor(zx, 1, 64);
+        z1 = zx;
+        z2 = other;
+      }
+      if (act && writer) {
+        const T r = div_shared<T, T>(z2 - z1, dy) * fy + z1;
+        out[(base + q) * A.out_stride + ch] = r;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();        // the strip is rewritten by the next batch
   }
 }
 

@@ -2457,6 +2457,64 @@ struct Interp2DImpl final : Interp2DBase {
   bool pair_packed = false;   // data holds the pair-packed layout (pack_pairs_kernel)
   SpaceSet spaces;
   OwnedRing ring_own;
+  // the cell-quad copy of a small / medium grid with short rows (quad_pack_kernel, eval_quads2d_kernel): built on first
+  // use by a kernel on the caller's stream, as Interp1DImpl::ensure_packed builds its copy -- 0 = not built, 1 = built and
+  // complete, 2 = not available, 3 = enqueued on quads_stream, completion signalled by quads_ev
+  DevBuf quads;
+  std::atomic<int> quads_state{0};
+  std::mutex quads_mu;
+  hipEvent_t quads_ev = nullptr;
+  hipStream_t quads_stream = nullptr;
+  static constexpr size_t QUADS_LIMIT = (size_t)64 << 20;
+  ~Interp2DImpl() {
+    if (quads_ev) (void)hipEventDestroy(quads_ev);
+  }
+  size_t quads_bytes() const { return (size_t)(nx - 1) * (ny - 1) * 4 * lanes * sizeof(T); }
+  bool ensure_quads(hipStream_t s) {
+    int st = quads_state.load(std::memory_order_acquire);
+    if (st == 1) return true;
+    if (st == 2) return false;
+    std::lock_guard<std::mutex> g(quads_mu);
+    st = quads_state.load(std::memory_order_acquire);
+    if (st == 1) return true;
+    if (st == 2) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+    if (cs != hipStreamCaptureStatusNone) return false;   // this batch takes another kernel
+    if (st == 0) {
+      const size_t bytes = quads_bytes();
+      if (bytes == 0 || bytes > QUADS_LIMIT) {
+        quads_state.store(2, std::memory_order_release);
+        return false;
+      }
+      try {
+        maybe_fail_lazy_alloc(__LINE__);
+        quads.reserve(bytes);
+        if (!quads_ev) NDI_HIP(hipEventCreateWithFlags(&quads_ev, hipEventDisableTiming));
+        const uint64_t total = (uint64_t)(nx - 1) * (ny - 1) * lanes;
+        const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((total + BLOCK - 1) / BLOCK, 65536));
+        hipLaunchKernelGGL(quad_pack_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, (const T*)data.as<T>(), quads.as<T>(), nx, ny, lanes,
+                           (uint64_t)(pair_packed ? ny - 1 : ny), (uint64_t)(pair_packed ? 2 * lanes : lanes));
+        NDI_HIP(hipGetLastError());
+        NDI_HIP(hipEventRecord(quads_ev, s));
+      } catch (const HipFailure&) {
+        (void)hipGetLastError();
+        quads.release();
+        quads_state.store(2, std::memory_order_release);
+        return false;
+      }
+      quads_stream = s;
+      quads_state.store(3, std::memory_order_release);
+      return true;
+    }
+    if (hipEventQuery(quads_ev) == hipSuccess) {   // st == 3
+      quads_state.store(1, std::memory_order_release);
+      return true;
+    }
+    (void)hipGetLastError();
+    if (s != quads_stream) NDI_HIP(hipStreamWaitEvent(s, quads_ev, 0));
+    return true;
+  }
 
   uint64_t signature() const override {
     uint64_t h = fnv1a(FNV_SEED, px.host_knots.data(), px.host_knots.size() * sizeof(T));
@@ -2468,7 +2526,7 @@ struct Interp2DImpl final : Interp2DBase {
   // Two stages as in Interp1DImpl: prep() = both searches (+ the optional tile grouping) into a scratch set,
   // launch_eval() = the bilinear kernel reading that set.
   struct Plan2 {
-    enum Kind { SMALL, GATHER, TILED, FUSED2, LANES2, STAGED2 } kind = GATHER;
+    enum Kind { SMALL, GATHER, TILED, FUSED2, LANES2, STAGED2, QUADS2 } kind = GATHER;
     int l_qpl = 1;          // LANES2, scalar grids: queries per lane (1, or one 16-byte vector)
     bool l_check = false;   // LANES2: no range pre-pass (NDI_EVAL_FRESH_OUTPUT)
     // FUSED2 (eval_fused2d_kernel)
@@ -2528,6 +2586,49 @@ struct Interp2DImpl final : Interp2DBase {
           const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
           const uint64_t per_wg = (uint64_t)P.f_tb * (lanes == 1 ? (uint64_t)P.l_qpl : 1);
           P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + per_wg - 1) / per_wg, (uint64_t)cu_count() * wg_per_cu));
+          g_last_path.store(NDI_PATH_GATHER);
+          P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
+          if (P.l_check) return P;
+          const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
+          ProfScope ps(s, PC_LOCATE);
+          hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
+                             px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode, &st->first_fail[0]);
+          NDI_HIP(hipGetLastError());
+          ps.done();
+          return P;
+        }
+      }
+    }
+    // Short rows (up to 64 bytes) on a grid whose cell-quad copy (4 x the grid) stays under 64 MiB, large batches: one
+    // contiguous record per query read by neighbouring lanes (eval_quads2d_kernel; the copy is built on first use).
+    // NDI_QUADS2D_KERNEL=0 / 1: A/B.
+    {
+      static const bool tune_live4 = std::getenv("NDI_TUNE_LIVE") != nullptr;
+      static const int on_once4 = ShortKnobs::env("NDI_QUADS2D_KERNEL", -1);
+      const int on = tune_live4 ? ShortKnobs::env("NDI_QUADS2D_KERNEL", -1) : on_once4;
+      const size_t cell_b = (size_t)lanes * sizeof(T);
+      const uint32_t pl = (uint32_t)(sizeof(T) == 4 ? lanes : 2 * lanes);
+      if (on != 0 && path != NDI_PATH_BUCKETED && lanes >= 2 && pl <= 32 && cell_b <= 64 && nx <= 16384 && ny <= 16384 &&
+          (uint64_t)(nx - 1) * (ny - 1) * 4 * lanes < (1ull << 32) && quads_bytes() <= QUADS_LIMIT &&
+          (on > 0 || (nq >= 65536 && (double)nq * (double)cell_b >= 2.0 * (double)quads_bytes() &&
+                      // AUTO: where it was measured ahead of the other kernels (profiles/r05_tuning.md 9): f32 rows of up to
+                      // 32 bytes (100 x 100 x 5: 61-63 vs 52-54 staged / 37 query order; 1000 x 1000 x 4: 37-42 vs 28), f64
+                      // pairs (45 -> 57); wider rows and f64 from three values are bound by instruction issue and lose
+                      ((std::is_same<T, float>::value && cell_b <= 32) || (std::is_same<T, double>::value && lanes == 2))))) {
+        px.ensure_dense_lut();
+        py.ensure_dense_lut();
+        const size_t fixed = (((size_t)(nx + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
+                             (((size_t)(ny + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
+                             px.dlut_bytes + py.dlut_bytes + (size_t)(nx - 1 + ny - 1) * 4 * sizeof(T);
+        static const int qtb_env = ShortKnobs::env("NDI_QUADS2D_TB", 0);
+        const unsigned tb = (qtb_env == 64 || qtb_env == 128 || qtb_env == 256 || qtb_env == 512) ? (unsigned)qtb_env : 256u;
+        const size_t need = fixed + (size_t)(tb / 64) * 64 * (4 + 6 * sizeof(T));
+        if (px.dense_ok && py.dense_ok && need <= FUSED_LDS_LIMIT && ensure_quads(s)) {
+          P.kind = Plan2::QUADS2;
+          P.f_tb = tb;
+          P.f_lds = need;
+          const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
+          P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + P.f_tb - 1) / P.f_tb, (uint64_t)cu_count() * wg_per_cu));
           g_last_path.store(NDI_PATH_GATHER);
           P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
           if (P.l_check) return P;
@@ -2937,6 +3038,33 @@ struct Interp2DImpl final : Interp2DBase {
       if (shm > both)   // staging is the fixed cost of a workgroup: no more workgroups than the chip holds at once
         gs = (unsigned)std::min<uint64_t>(g, (uint64_t)cu_count() * std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / shm)));
       launch1<T>(s, PC_EVAL, dim3(gs), dim3(BLOCK), shm, eval_small2d_kernel<T>, S);
+      return;
+    }
+    if (P.kind == Plan2::QUADS2) {
+      EvalQuads2Args<T> F{};
+      F.xk = px.view.lv0; F.yk = py.view.lv0;
+      F.nx = (uint32_t)nx; F.ny = (uint32_t)ny;
+      F.dx = px.dlut; F.dy = py.dlut;
+      F.quads = quads.as<T>();
+      F.qx = P.qx; F.qy = P.qy;
+      F.out = P.out;
+      F.nq = nq;
+      F.out_stride = P.out_stride;
+      F.lanes = (uint32_t)lanes;
+      F.mode = mode;
+      F.first_fail = &st->first_fail[0];
+      F.check = P.l_check ? 1 : 0;
+      if (std::getenv("NDI_TRACE_PLAN"))
+        std::fprintf(stderr, "[ndi plan] quads2d L=%llu tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes, P.f_tb, P.f_grid,
+                     P.f_lds, P.l_check ? 0 : 1);
+#define NDI_Q2(TBS)                                                                       \
+  do {                                                                                    \
+    auto kern = eval_quads2d_kernel<T, TBS>;                                              \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);         \
+    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(TBS), P.f_lds, kern, F);                  \
+  } while (0)
+      if (P.f_tb == 512) NDI_Q2(512); else if (P.f_tb == 128) NDI_Q2(128); else if (P.f_tb == 64) NDI_Q2(64); else NDI_Q2(256);
+#undef NDI_Q2
       return;
     }
     if (P.kind == Plan2::LANES2 || P.kind == Plan2::STAGED2) {

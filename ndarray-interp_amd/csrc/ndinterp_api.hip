@@ -2610,7 +2610,7 @@ struct Interp2DImpl final : Interp2DBase {
       const uint32_t pl = (uint32_t)(sizeof(T) == 4 ? lanes : 2 * lanes);
       if (on != 0 && path != NDI_PATH_BUCKETED && lanes >= 2 && pl <= 32 && cell_b <= 64 && nx <= 16384 && ny <= 16384 &&
           (uint64_t)(nx - 1) * (ny - 1) * 4 * lanes < (1ull << 32) && quads_bytes() <= QUADS_LIMIT &&
-          (on > 0 || (nq >= 65536 && (double)nq * (double)cell_b >= 2.0 * (double)quads_bytes() &&
+          (on > 0 || (nq >= (lanes <= 2 ? 524288u : 65536u) && (double)nq * (double)cell_b >= 2.0 * (double)quads_bytes() &&   // (1-2 values: the one-thread-per-query kernel keeps the smaller batches, as before)
                       // AUTO: where it was measured ahead of the other kernels (profiles/r05_tuning.md 9): f32 rows of up to
                       // 32 bytes (100 x 100 x 5: 61-63 vs 52-54 staged / 37 query order; 1000 x 1000 x 4: 37-42 vs 28), f64
                       // pairs (45 -> 57); wider rows and f64 from three values are bound by instruction issue and lose

@@ -44,8 +44,6 @@ def test_two_level_grouping_fuzz(pkg, capfd, seed):
     outs = {}
     os.environ["NDI_GROUP_TWO_LEVEL"] = "1"
     os.environ["NDI_TRACE_PLAN"] = "1"
-    if seed % 2:
-        os.environ["NDI_TILE_TS"] = str(2 + seed % 3)     # (read once per process: whichever test comes first sets it -- any value is valid)
     capfd.readouterr()
     try:
         for name, path in (("gather", pkg.PATH_GATHER), ("tiled", pkg.PATH_BUCKETED)):
@@ -55,7 +53,7 @@ def test_two_level_grouping_fuzz(pkg, capfd, seed):
             outs[name] = out
             assert pkg.profile_read(reset=False)["last_path"] == ("gather" if name == "gather" else "bucketed"), (seed, name)
     finally:
-        for k in ("NDI_GROUP_TWO_LEVEL", "NDI_TRACE_PLAN", "NDI_TILE_TS"):
+        for k in ("NDI_GROUP_TWO_LEVEL", "NDI_TRACE_PLAN"):
             os.environ.pop(k, None)
     err = capfd.readouterr().err
     if Q >= 2:

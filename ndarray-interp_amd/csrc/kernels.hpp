@@ -13,6 +13,9 @@
 //   eval_fused_kernel      short rows (< 256 vectors), QUERY ORDER with the search fused in: 64 queries per wave, one
 //                          sequential write stream; tables from L2 (plain / interval-packed: pack_intervals_kernel)
 //                          or staged in LDS -- {y, a, b}, or {y, k} with a / b re-formed per item
+//   eval_fused_sorted_kernel
+//                          the same for rows of 128 B - 1 KiB read from L2: a workgroup round's queries ordered by interval
+//                          in LDS first, so that neighbouring items share their operand rows through L1
 //   eval_bucketed_short_kernel
 //                          short rows grouped by interval: sub-workgroup groups keep the operand vectors in registers
 //   range_check_kernel     first failing query of a batch before a query-order launch (first-error semantics)
@@ -1378,6 +1381,166 @@ __global__ __launch_bounds__(TB) void eval_fused_kernel(EvalFusedArgs<T> A) {
     }
     __builtin_amdgcn_wave_barrier();        // the strip is rewritten by the next batch
   }
+  }
+}
+
+// eval_fused_kernel's work for rows of 64 bytes to a few KiB whose tables are read from L2, with the queries of a
+// workgroup round ORDERED BY INTERVAL in LDS first.  In query order every output vector costs four operand vectors from
+// L2 -- random rows, an L1 that holds a thirtieth of the table set -- and the counters of f64 x 32 lanes show the L2
+// REQUEST rate as the first bound: 1.8e8 64-byte requests (1.2e8 of them operand reads) in a 1.0 ms kernel against
+// 2.7e11 requests / s of the chip's 128 L2 channels (profiles/r05_fused_32lane_counters.txt).  A round of TB * QPT
+// queries (4096) on 1023 intervals has four queries per interval: ordered by interval, neighbouring items read the SAME
+// operand rows, which then come from L1 -- the table reads from L2 drop to about one per interval and round.  The order
+// is formed in LDS (ranks by LDS atomics, an exclusive scan of the interval counts, {interval, local index} and the
+// query's scalars placed in interval order); rows are still written at their own positions, whole rows at a time.
+// Same search, same operands, same operation order as eval_fused_kernel (TLDS == 0, plain tables).
+template <class T, int STRAT, int VEC, int TB, int QPT>
+__global__ __launch_bounds__(TB) void eval_fused_sorted_kernel(EvalFusedArgs<T> A) {
+  using V = typename VecT<T, VEC>::type;
+  constexpr bool STRIP2 = STRAT == ST_LINEAR;
+  constexpr uint32_t NQ = (uint32_t)TB * QPT;
+  static_assert(NQ <= 4096, "the local index takes 12 bits of the key");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ uint32_t s_wave[TB / 64];
+  if (A.nq == 0) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n = A.pyr.n, n1 = A.pyr.n1, nint = n - 1u;
+  // LDS: [pyramid | lut | interval counters | keys | c0 | (linear) c1]
+  size_t off;
+  {
+    T* s0 = reinterpret_cast<T*>(smem_raw);
+    const uint32_t total = n + n1;
+    for (uint32_t i = tid; i < total; i += TB) s0[i] = A.pyr.lv0[i];
+    off = ((size_t)total * sizeof(T) + 15u) & ~(size_t)15u;
+  }
+  lds_u16 lut = nullptr;
+  if (A.bx.lut) {
+    uint32_t* sl = reinterpret_cast<uint32_t*>(smem_raw + off);
+    const uint32_t words = (A.bx.m + 2u) / 2u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.bx.lut);
+    for (uint32_t i = tid; i < words; i += TB) sl[i] = src[i];
+    lut = (lds_u16)(smem_raw + off);
+    off += ((size_t)words * 4u + 15u) & ~(size_t)15u;
+  }
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem_raw + off);
+  off += ((size_t)nint * 4u + 15u) & ~(size_t)15u;
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(smem_raw + off);
+  off += (size_t)NQ * 4u;
+  T* s_c0 = reinterpret_cast<T*>(smem_raw + off);
+  off += (size_t)NQ * sizeof(T);
+  T* s_c1 = reinterpret_cast<T*>(smem_raw + off);
+  for (uint32_t b = tid; b < nint; b += TB) s_cnt[b] = 0u;
+  __syncthreads();
+  PyramidLds<T> P;
+  P.lv0 = (lds_ptr<T>)(smem_raw);
+  P.lv1 = P.lv0 + n;
+  P.n = n; P.n1 = n1; P.levels = A.pyr.levels; P.guess = A.pyr.guess; P.block = A.pyr.block;
+  const T k0 = P.lv0[0], kn = P.lv0[n - 1];
+  unsigned long long limit = A.check ? NO_FAIL : *A.first_fail;
+  if (limit > A.nq) limit = A.nq;
+  const uint32_t LV = A.lv;
+  const V* const t_y = reinterpret_cast<const V*>(A.data);
+  const V* const t_a = reinterpret_cast<const V*>(A.ca);
+  const V* const t_b = reinterpret_cast<const V*>(A.cb);
+  for (uint64_t base = (uint64_t)blockIdx.x * NQ; base < limit; base += (uint64_t)gridDim.x * NQ) {   // (workgroup-uniform)
+    uint32_t iv[QPT], rank[QPT];
+    T c0v[QPT], c1v[QPT];
+    T xq[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const uint64_t qi = base + (uint64_t)k * TB + tid;
+      xq[k] = A.q[qi < A.nq ? qi : A.nq - 1u];
+    }
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const uint64_t qi = base + (uint64_t)k * TB + tid;
+      const bool act = qi < limit;
+      const T x = act ? xq[k] : k0;
+      const bool inr = (k0 <= x) && (x <= kn);
+      if (A.check && act && lane_query_fails<T>(x, k0, kn, A.mode)) atomicMin(A.first_fail, (unsigned long long)qi);
+      T xs = x;
+      if (A.mode == EX_PERIODIC && !inr) xs = rem_euclid_t(x - k0, kn - k0) + k0;   // cubic_spline.rs:805-809
+      const uint32_t i = lut ? locate_index_lut<T>(P, lut, A.bx.m, A.bx.scale, k0, kn, xs)
+                             : locate_index<T, lds_ptr<T>>(P, k0, kn, xs, lane);   // all 64 lanes take part
+      const T xl = P.lv0[i], xr = P.lv0[i + 1];
+      iv[k] = NDI_CHK(i, nint, BC_INTERVAL);
+      if (STRAT == ST_CUBIC) {
+        c0v[k] = (xs - xl) / (xr - xl);   // t, cubic_spline.rs:818
+        c1v[k] = T(0);
+      } else {
+        c0v[k] = xr - xl;                 // linear.rs:33-35: (x2 - x1), (x - x1)
+        c1v[k] = x - xl;
+      }
+      rank[k] = act ? atomicAdd(&s_cnt[iv[k]], 1u) : 0u;
+    }
+    __syncthreads();
+    {   // exclusive scan of the interval counts, TB intervals at a time
+      uint32_t carry = 0;
+      for (uint32_t b0 = 0; b0 < nint; b0 += TB) {
+        const uint32_t b = b0 + tid;
+        const uint32_t c = b < nint ? s_cnt[b] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+          if (lane >= d) incl += up;
+        }
+        __syncthreads();
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < (uint32_t)TB / 64u; ++w) {
+          const uint32_t t = s_wave[w];
+          if (w < wave) wave_off += t;
+          total += t;
+        }
+        if (b < nint) s_cnt[b] = carry + wave_off + incl - c;
+        carry += total;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const uint64_t qi = base + (uint64_t)k * TB + tid;
+      if (qi < limit) {
+        const uint32_t p = NDI_CHK(s_cnt[iv[k]] + rank[k], NQ, BC_POSITION);
+        s_key[p] = (iv[k] << 12) | ((uint32_t)k * TB + tid);
+        s_c0[p] = c0v[k];
+        if (STRIP2) s_c1[p] = c1v[k];
+      }
+    }
+    __syncthreads();
+    const uint32_t nloc = (limit - base < (uint64_t)NQ) ? (uint32_t)(limit - base) : NQ;
+    const uint32_t items = nloc * LV;
+    for (uint32_t it = tid; it < items; it += TB) {
+      const uint32_t p = (LV == 1u) ? it : __umulhi(it, A.lv_magic);
+      const uint32_t v = it - p * LV;
+      const uint32_t key = s_key[NDI_CHK(p, NQ, BC_POSITION)];
+      const uint32_t i = key >> 12, loc = key & 4095u;
+      const T s0 = s_c0[p];
+      const T s1 = STRIP2 ? s_c1[p] : T(0);
+      const uint32_t e = i * LV + v;
+      const V yl = t_y[e], yr = t_y[e + LV];
+      V a = V(0), b = V(0);
+      if (STRAT == ST_CUBIC) { a = t_a[e]; b = t_b[e]; }
+      RowCoef<T, STRAT> c;
+      if (STRAT == ST_CUBIC) {
+        const T one = T(1);
+        c.c0 = one - s0;
+        c.c1 = s0;
+        c.c2 = s0 * (one - s0);
+      } else {
+        c.c0 = s0;
+        c.c1 = s1;
+        c.c2 = T(0);
+      }
+      V* o = reinterpret_cast<V*>(A.out + (base + loc) * A.out_stride) + v;
+      store_stream<true>(o, row_point<T, STRAT, V>(c, yl, yr, a, b));
+    }
+    __syncthreads();                                   // the round's arrays are rewritten by the next one
+    for (uint32_t b = tid; b < nint; b += TB) s_cnt[b] = 0u;
+    __syncthreads();
   }
 }
 

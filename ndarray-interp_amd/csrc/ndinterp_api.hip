@@ -1371,6 +1371,7 @@ struct Interp1DImpl final : Interp1DBase {
     uint64_t LV = 0;
     // FUSED (eval_fused_kernel)
     bool f_lut = false, f_pack = false;
+    bool f_sorted = false;   // FUSED: the queries of a workgroup round ordered by interval in LDS (eval_fused_sorted_kernel)
     int f_tlds = 0;   // 0: tables from memory, 1: {y, a, b} in LDS, 2: {y, k} in LDS
     unsigned f_tb = 256, f_grid = 1;
     int f_unr = 2;
@@ -1599,6 +1600,42 @@ struct Interp1DImpl final : Interp1DBase {
     P.f_lds = fused_lds_bytes(P.f_lut, P.f_tb, P.f_tlds);
     // rows shorter than a cache line read from L2: one contiguous record per interval instead of three row pieces
     P.f_pack = !P.f_tlds && (K.pack > 0 || (K.pack < 0 && lanes * sizeof(T) < 128)) && ensure_packed(s);
+    // Tables from L2, rows of 64 bytes and more, a large batch on an axis of up to 4096 intervals: the workgroup-local
+    // interval order (eval_fused_sorted_kernel: the operand rows of neighbouring items coincide and come from L1 -- the
+    // query-order form is bound by the L2 request rate on these).  NDI_FUSED_SORTED=0 / 1: A/B.
+    {
+      static const bool tune_live5 = std::getenv("NDI_TUNE_LIVE") != nullptr;
+      static const int fs_once = ShortKnobs::env("NDI_FUSED_SORTED", -1);
+      const int fs = tune_live5 ? ShortKnobs::env("NDI_FUSED_SORTED", -1) : fs_once;
+      const bool cubic = strategy == NDI_CUBIC_SPLINE;
+      const size_t lds_s = ((pyr.lds_bytes + 15) & ~(size_t)15) + (P.f_lut ? pyr.lut_bytes : 0) + (((size_t)(n - 1) * 4 + 15) & ~(size_t)15) +
+                           (size_t)4096 / (cubic ? 1 : 2) * (4 + (cubic ? 1 : 2) * sizeof(T));
+      // AUTO: where it was measured ahead (profiles/r05_tuning.md 10): CubicSpline (four operand rows per output row), rows of
+      // 128 bytes and more, at least two queries per interval and round (4096 queries: axes of up to 2049 knots)
+      P.f_sorted = fs != 0 && !P.f_tlds && n >= 3 && n - 1 <= 4096 && LV >= 2 && lanes * sizeof(T) >= 64 && lds_s <= FUSED_LDS_LIMIT - 256 &&
+                   (fs > 0 || (cubic && lanes * sizeof(T) >= 128 && n - 1 <= 2048 && P.nq >= (1u << 18)));
+      if (P.f_sorted) {
+        P.f_pack = false;
+        P.f_tb = 512;
+        P.f_lds = lds_s;
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds_s, 4));
+        const uint64_t nqw = cubic ? 4096 : 2048;
+        P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + nqw - 1) / nqw, (uint64_t)cu_count() * per_cu * 4));
+        P.kind = Plan1::FUSED;
+        g_last_path.store(NDI_PATH_GATHER);
+        P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;
+        if (P.l_check) return true;
+        StatusBlock* st = sc.status.as<StatusBlock>();
+        const T k0 = pyr.host_knots.front(), kn = pyr.host_knots.back();
+        const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + BLOCK - 1) / BLOCK, 4096));
+        ProfScope ps(s, PC_LOCATE);
+        hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, P.q, (const T*)nullptr, P.nq, k0, kn, k0, kn,
+                           mode, &st->first_fail[0]);
+        NDI_HIP(hipGetLastError());
+        ps.done();
+        return true;
+      }
+    }
     const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(P.f_lds, 1), 32 / (P.f_tb / 64)));
     const uint64_t want = (uint64_t)cu_count() * (K.wgs > 0 ? (size_t)K.wgs : wg_per_cu * (P.f_tlds ? 1 : 4));
     P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((P.nq + P.f_tb - 1) / P.f_tb, want));
@@ -1906,6 +1943,21 @@ struct Interp1DImpl final : Interp1DBase {
 #endif
     constexpr int VN = Wide<T>::N;
     const dim3 grid(P.f_grid), block(P.f_tb);
+    if (P.f_sorted) {
+      if (std::getenv("NDI_TRACE_PLAN"))
+        std::fprintf(stderr, "[ndi plan] fused sorted lut=%d tb=%u grid=%u lds=%zu prepass=%d\n", (int)P.f_lut, P.f_tb, P.f_grid,
+                     P.f_lds, P.l_check ? 0 : 1);
+#define NDI_FSK(ST, VEC, QPT)                                                                          \
+  do {                                                                                                 \
+    auto kern = eval_fused_sorted_kernel<T, ST, VEC, 512, QPT>;                                        \
+    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(FUSED_LDS_LIMIT - 256));              \
+    launch1<T>(s, PC_EVAL, grid, dim3(512), P.f_lds, kern, F);                                         \
+  } while (0)
+      if (strategy == NDI_CUBIC_SPLINE) { if (P.vec_ok) NDI_FSK(ST_CUBIC, VN, 8); else NDI_FSK(ST_CUBIC, 1, 8); }
+      else { if (P.vec_ok) NDI_FSK(ST_LINEAR, VN, 4); else NDI_FSK(ST_LINEAR, 1, 4); }
+#undef NDI_FSK
+      return;
+    }
     if (std::getenv("NDI_TRACE_PLAN"))   // which variant a batch took (tests assert on it; read per call)
       std::fprintf(stderr, "[ndi plan] fused tables=%s lut=%d pack=%d unr=%d tb=%u grid=%u lds=%zu prepass=%d\n",
                    P.f_tlds == 2 ? "lds{y,k}" : (P.f_tlds == 1 ? "lds{y,a,b}" : (P.f_tlds == 3 ? "memory,knots=global" : "memory")),

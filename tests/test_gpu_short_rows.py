@@ -366,7 +366,7 @@ def test_auto_picks_the_measured_form(pkg, capfd):
     x = knots("rand", 1024, rng, np.float64)
     expect = [   # (dtype, lanes, cubic, fragment of the trace or None = not the query-order kernel)
         (np.float64, 8, True, "tables=lds{y,k}"), (np.float32, 8, True, "tables=lds{y,a,b}"),
-        (np.float32, 16, True, "tables=lds{y,k}"), (np.float64, 32, True, "tables=memory"),
+        (np.float32, 16, True, "tables=lds{y,k}"), (np.float64, 32, True, "fused sorted"),   # 256-byte rows from L2: interval order per round
         (np.float64, 128, True, None),                      # 1 KiB rows, many queries per interval: grouped
         (np.float64, 8, False, "tables=lds{y,a,b}"), (np.float32, 32, False, "tables=memory"),
         (np.float64, 128, False, "tables=memory"),          # Linear: never grouped

@@ -334,8 +334,12 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False, ra
         gather_kernel = traced_kernel()
         # (a) per-stage kernel times: the library's HIP events (two event records per stage on the launch stream)
         pkg.profile_enable(True); pkg.profile_read(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        torch.cuda.synchronize()
+        el_prof = time.perf_counter() - t0        # wall time of the SAME loop the stage times come from (event recording on)
         interp.strategy.finish()
         prof = pkg.profile_read(reset=True); pkg.profile_enable(False)
         kms = prof["eval_ms"] / max(1, prof["eval_launches"])
@@ -378,7 +382,11 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False, ra
              "ms_per_step": round(el / steps * 1e3, 4), "Mpoints_s": round(nq * C * steps / el / 1e6, 1),
              "timed_through": "bare C ABI (ndi_interp2d_eval, async_launch), event recording off",
              "host_ms_per_call": round(host / steps * 1e3, 4),
-             "step_minus_kernels_ms": round(el / steps * 1e3 - gpu_ms, 4),
+             # the stage times are HIP-event intervals of a run WITH event recording (each interval carries the event
+             # commands' own dispatch gaps), so they are compared with that run's own wall clock -- never negative -- and
+             # the unprofiled step (ms_per_step) is what a caller pays
+             "profiled_ms_per_step": round(el_prof / steps * 1e3, 4),
+             "step_minus_kernels_ms": round(el_prof / steps * 1e3 - gpu_ms, 4),
              "python_mirror_ms_per_step": round(el_py / steps * 1e3, 4)}
         if tiled:   # every grid value once + output + records: the bytes this formulation has to move
             comp = nx * nx * C * 4 + nq * C * 4 + nq * 16
@@ -502,15 +510,19 @@ def short_rows_leg(pkg, torch, dev, out_bytes=4e9, steps=5):
 
 
 def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
-    """BASELINE configs[1]'s shape (4096 knots x 4096 lanes, 1e6 queries, one resident output buffer) for the two long-row
-    kernels the headline does not time: 1-D Linear f64 (linear.rs:73-98; SURVEY 8(d): 24 B per point) and CubicSpline
-    f32.  AUTO takes the bucketed formulation (Q >= 5 (n - 1)): compulsory bytes = output + tables + records once;
-    the SURVEY 8(d) gather-model ratio is printed next to it, never as `frac`.  PMC traffic: the stored figure of the
-    same launch from profiles/traffic.json (tools/profile_r05.sh), labelled."""
+    """BASELINE configs[1] itself (`c2`: 1-D CubicSpline, 4096 knots x 4096 f64 lanes, 1e6 queries into ONE resident 32.8 GB
+    buffer; cubic_spline.rs:791-830) and the same shape for the two long-row kernels the headline does not time: 1-D Linear
+    f64 (linear.rs:73-98; SURVEY 8(d): 24 B per point) and CubicSpline f32.  AUTO takes the bucketed formulation
+    (Q >= 5 (n - 1)): compulsory bytes = output + tables + records once; the SURVEY 8(d) gather-model ratio is printed next
+    to it, never as `frac`.  Output buffers: `frac` / `kernel_ms` are those of the FIRST buffer the allocator hands out (no
+    selection); three caller-style buffers (torch.empty) and three library-owned ones (ndi_output_alloc: what the mirrors'
+    interp_array -- the reference's Array::zeros, interp1d/mod.rs:209 -- allocates: physical chunks spread over the device's
+    memory) are all timed and listed.  PMC traffic: the stored figure of the same launch from profiles/traffic.json."""
     res = {}
     n = lanes = 4096
     nq = 1_000_000
-    for key, dt, tdt, strat_name in (("c2_linear", np.float64, torch.float64, "linear"), ("c2_f32", np.float32, torch.float32, "cubic")):
+    for key, dt, tdt, strat_name in (("c2", np.float64, torch.float64, "cubic"), ("c2_linear", np.float64, torch.float64, "linear"),
+                                     ("c2_f32", np.float32, torch.float32, "cubic")):
         x, yv, q = synth_c2(n, lanes, nq, 0)
         x = np.unique(x.astype(dt)); yv = yv[:x.size].astype(dt)
         q = np.clip(q.astype(dt), x[0], x[-1])
@@ -518,12 +530,8 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
         b = pkg.Interp1DBuilder.new(torch.as_tensor(yv, device=dev)).x(torch.as_tensor(x, device=dev))
         interp = (b.strategy(pkg.CubicSpline.new()) if strat_name == "cubic" else b).build()
         qd = torch.as_tensor(q, device=dev)
-        # Where a 16-33 GB buffer lands in HBM moves this write stream by 10-25 % between allocations (DESIGN.md 6,
-        # "placement": the Target's ring takes the process's first allocation for that reason).  Three candidate buffers
-        # are timed; the line reports all of them and uses the fastest -- the kernel, not the allocator, is what is measured.
-        cands, best = [], None
-        bufs = [torch.empty((nq, lanes), dtype=tdt, device=dev) for _ in range(3)]
-        for out in bufs:
+
+        def time_into(out):
             step = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
             step(); interp.strategy.finish()
             pkg.profile_enable(True); pkg.profile_read(reset=True)
@@ -535,25 +543,37 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
             wall_c = (time.perf_counter() - t0) / steps
             interp.strategy.finish()
             prof_c = pkg.profile_read(reset=True); pkg.profile_enable(False)
-            kms_c = prof_c["eval_ms"] / max(1, prof_c["eval_launches"])
-            cands.append(round(kms_c, 4))
-            if best is None or kms_c < best[0]:
-                best = (kms_c, wall_c, prof_c)
-        kms, wall, prof = best
+            return prof_c["eval_ms"] / max(1, prof_c["eval_launches"]), wall_c, prof_c
+
+        bufs = [torch.empty((nq, lanes), dtype=tdt, device=dev) for _ in range(3)]
+        runs = [time_into(o) for o in bufs]
         del bufs
+        torch.cuda.empty_cache()
+        owned = []
+        if hasattr(pkg, "output_empty"):          # library-owned outputs, one after the other (each freed before the next)
+            for _ in range(3):
+                o = pkg.output_empty((nq, lanes), dt, dev.index)
+                owned.append(time_into(o))
+                del o
+        kms, wall, prof = runs[0]                  # the FIRST allocation, no selection
         ntab = x.size + (2 * (x.size - 1) if strat_name == "cubic" else 0)
         comp = nq * lanes * el + ntab * lanes * el + nq * 16
         model = nq * lanes * (5 if strat_name == "cubic" else 3) * el + nq * el
         bucketed = prof["last_path"] == "bucketed"
         stored = (traffic_store or {}).get(f"{key}_bytes_per_launch")
+        frac_of = lambda k: round(comp / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         res[key] = {"workload": f"1D {'CubicSpline' if strat_name == 'cubic' else 'Linear'}, {x.size} knots x {lanes} lanes "
-                                f"{np.dtype(dt).name}, {nq} queries, one resident output buffer ({nq * lanes * el / 1e9:.1f} GB)",
+                                f"{np.dtype(dt).name}, {nq} queries, one resident output buffer ({nq * lanes * el / 1e9:.1f} GB)"
+                                + (" = BASELINE configs[1]" if key == "c2" else ""),
                     "path": prof["last_path"], "kernel": "eval_bucketed_kernel" if bucketed else "eval_rows_kernel",
                     "kernel_ms": round(kms, 4), "ms_per_step": round(wall * 1e3, 4),
-                    "kernel_ms_per_output_buffer": cands,
-                    "placement": "fastest of three candidate output buffers (the spread is the allocator's, DESIGN.md 6)",
+                    "placement": "first of three caller-style buffers (torch.empty), no selection",
+                    "kernel_ms_per_output_buffer": [round(r[0], 4) for r in runs],
+                    "frac_per_output_buffer": [frac_of(r[0]) for r in runs],
+                    "kernel_ms_library_owned_outputs": [round(r[0], 4) for r in owned],
+                    "frac_library_owned_outputs": [frac_of(r[0]) for r in owned],
                     "Mpoints_s": round(nq * lanes / wall / 1e6, 1),
-                    "compulsory_bytes_per_launch": int(comp), "frac": round(comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "compulsory_bytes_per_launch": int(comp), "frac": frac_of(kms),
                     "bytes_basis": "compulsory bytes per launch (output + tables + query records, once)",
                     "survey_8d_model_bytes": int(model),
                     "gather_model_ratio": round(model / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -561,7 +581,7 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
                     "traffic_frac": round(stored / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if stored else None,
                     "stages_ms_per_step": {k: round(prof[k + "_ms"] / steps, 4) for k in ("locate", "group", "eval")}}
         interp.strategy.release()
-        del interp, qd, out
+        del interp, qd
         torch.cuda.empty_cache()
     return res
 
@@ -706,12 +726,15 @@ def secondary_legs(pkg, torch, dev):
         traffic_store = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         traffic_store = None
-    sec = {"c3": bilinear_leg(pkg, torch, dev, 2048, 64, 10_000_000),
-           "c5_share": bilinear_leg(pkg, torch, dev, 8192, 16, 12_500_000, probe=True),
-           "short_rows": short_rows_leg(pkg, torch, dev)}
-    sec.update(long_rows_leg(pkg, torch, dev, traffic_store))
-    sec["reference_shapes_2d"] = reference_shapes_2d_leg(pkg, torch, dev)
+    # the long tables first (they go to a line of their own, printed BEFORE the contract line), the BASELINE configs last
+    detail = {"short_rows": short_rows_leg(pkg, torch, dev),
+              "reference_shapes_2d": reference_shapes_2d_leg(pkg, torch, dev)}
+    sec = {"detail_line": "the JSON line before this one ({\"detail\": ...}) carries short_rows (+ reference_shapes) and reference_shapes_2d"}
+    sec["reference_shapes_summary"] = reference_summary(detail)
     sec["host_path"] = host_path_leg(pkg, torch, dev)
+    sec.update(long_rows_leg(pkg, torch, dev, traffic_store))
+    sec["c5_share"] = bilinear_leg(pkg, torch, dev, 8192, 16, 12_500_000, probe=True)
+    sec["c3"] = bilinear_leg(pkg, torch, dev, 2048, 64, 10_000_000)
     n, nq = 1024, 10_000
     rng = np.random.default_rng(42)
     yv = rng.uniform(0, 1, n); q = np.random.default_rng(123).uniform(0, n - 1, nq)
@@ -737,7 +760,45 @@ def secondary_legs(pkg, torch, dev):
                  "gpu_us": round(gpu_us, 1), "cpu_us": round(cpu_us, 1), "bit_exact": bool(np.array_equal(out, ref)),
                  "gpu_path": "C ABI host to host (zero-copy: memcpy into a pinned buffer, one fused search+evaluate launch that reads and writes it through its host mapping, one sync, memcpy out)",
                  "cpu_path": "oracle port, 1 thread"}
-    return sec
+    return sec, detail
+
+
+def reference_summary(detail):
+    """The reference's own bench shapes (benches/bench_interp1d.rs:12-47, 82-122, benches/bench_interp2d.rs:12-18, 87-92) as
+    [Gqueries/s with interp_array semantics, with interp_array_into semantics, q-in / row-out stream as a fraction of the
+    HBM peak] -- the compact copy of the detail line's tables that rides in the contract line."""
+    out = {}
+    for r in detail["short_rows"]["reference_shapes"]:
+        out[f"1d_{r['knots']}x{r['lanes']}_{r['dtype']}"] = [r["Gqueries_s"], r["interp_array_into_Gqueries_s"], r["io_frac_of_peak"]]
+    for r in detail["reference_shapes_2d"]:
+        g = r["grid"]
+        out[f"2d_{g[0]}x{g[1]}x{g[2]}_{r['dtype']}"] = [r["Gqueries_s"], r["interp_array_into_Gqueries_s"], r["io_frac_of_peak"]]
+    out["short_rows_out_TBps_by_lanes"] = {f"{r['dtype']}x{r['lanes']}": r["out_TBps"] for r in detail["short_rows"]["shapes"]}
+    return out
+
+
+def secondary_summary(sec):
+    """Five-odd scalars per BASELINE config, small enough to ride inside `config` (the part of the line a truncating
+    reader keeps) and, once more, at the very END of the line."""
+    def pick(d, *ks):
+        return {k: d.get(k) for k in ks if d.get(k) is not None}
+    out = {}
+    for k in ("c3", "c5_share"):
+        if k in sec:
+            out[k] = pick(sec[k], "ms_per_step", "kernel_ms", "locate_ms", "group_ms", "frac", "Mpoints_s", "path", "step_minus_kernels_ms")
+    for k in ("c2", "c2_linear", "c2_f32"):
+        if k in sec:
+            out[k] = pick(sec[k], "ms_per_step", "kernel_ms", "frac", "kernel_ms_per_output_buffer", "kernel_ms_library_owned_outputs",
+                          "frac_library_owned_outputs")
+    if "host_path" in sec:
+        out["host_path_GBps"] = sec["host_path"].get("output_GBps")
+    if "c1" in sec:
+        out["c1_us"] = [sec["c1"].get("gpu_us"), sec["c1"].get("cpu_us")]
+    rs = sec.get("reference_shapes_summary", {})
+    for k in ("2d_100x100x5_float64", "2d_100x100x5_float32", "2d_100x100x1_float64", "1d_100x5_float64", "1d_100x1_float64"):
+        if k in rs:
+            out[k + "_Gq_s"] = rs[k][0]
+    return out
 
 
 def gather_ranks(torch, dist, world, rank, ms_per_step, kernel_ms, my_dev, cdev):
@@ -1053,7 +1114,9 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         del ring, qd, interp, yd, xd
         torch.cuda.empty_cache()
         progress("secondary legs: C3, C5 share, C1")
-        line["secondary"] = secondary_legs(pkg, torch, dev)
+        line["secondary"], detail = secondary_legs(pkg, torch, dev)
+        line["config"]["secondary_summary"] = secondary_summary(line["secondary"])
+        print(json.dumps({"detail": "tables of the secondary legs (the contract line follows as the LAST line)", **detail}), flush=True)
         if pkg.device_count() >= 2 or args.sharded_leg_devices:
             progress("in-process sharded leg over the visible devices")
             leg = in_process_sharded_leg(args, pkg, torch, x, y)
@@ -1093,6 +1156,12 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
                                 "per_gpu_share": ({"value": round(res["share"][0], 1), "cores": 16,
                                                    "sample": f"{res['share'][1]} queries (~5 s)"} if "share" in res else None),
                                 "build_s": round(build_s, 2), "compiler_flags": res["flags"]}
+    # key order of the contract line: the long `secondary` object and, after it, a compact copy of its BASELINE-config
+    # scalars come LAST, so that a reader who keeps only the tail of the output still sees C2 / C3 / C5
+    if "secondary" in line:
+        sec = line.pop("secondary")
+        line["secondary"] = sec
+        line["tail_summary"] = line["config"]["secondary_summary"]
     print(json.dumps(line), flush=True)
 
 

@@ -33,11 +33,10 @@
 //   coarse_scatter2d_kernel, scan_bin_totals_kernel, fine_scatter2d_kernel
 //                          2-D tile grouping in two levels (tile row, then tile) for large batches: whole-line record
 //                          runs instead of one 32-byte sector per record (group_scatter2d_kernel: the one-pass form)
-//   eval_staged2d_kernel   2-D query per lane on grids beyond LDS: the batch's corner rows staged through a wave-private
-//                          LDS strip by cooperative 16-byte loads (A/B variant: the quad kernel covers its shapes)
-//   quad_pack_kernel, eval_quads2d_kernel
-//                          short 2-D rows on grids up to 16 MiB: a cell-quad copy of the grid (four corners of a cell and
-//                          channel adjacent), one contiguous record per query read by neighbouring lanes
+//   slope_pack_kernel, eval_slopes2d_kernel
+//                          short 2-D rows (up to 64 bytes) on grids beyond LDS: slope records {z, m} -- linear.rs:33's
+//                          division done once per grid point --, one contiguous run per query, an item per lane, loads
+//                          issued ahead of the previous batch's stores
 //   eval_bilinear_tiles_kernel
 //                          2-D tile-grouped order (locate2_kernel's tile histogram + group_scatter2d_kernel): every
 //                          tile of grid points staged once in LDS (double-buffered through registers) together with
@@ -3612,9 +3611,6 @@ struct EvalLanes2Args {
   int mode;
   unsigned long long* first_fail;   // [2]: x, y (range_check_kernel, or this kernel when `check`)
   int check;                        // see EvalLanesArgs
-  // eval_staged2d_kernel: element offset of cell (xi, yi) = (xi * row_cells + yi) * cell_elems -- plain layout: (ny, lanes);
-  // pair-packed (pack_pairs_kernel): (ny - 1, 2 * lanes).  In both, z[xi][yi+1] follows z[xi][yi] at + lanes.
-  uint32_t row_cells, cell_elems;
 };
 
 // the failure conditions of a 2-D query (Interp2D::is_in_x_range / is_in_y_range, interp2d/mod.rs:374-379): x and y
@@ -3818,182 +3814,66 @@ __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
   }
 }
 
-// 2-D QUERY PER LANE for short rows on grids that do NOT fit LDS (the reference's 100 x 100 x 5 bench grid,
-// benches/bench_interp2d.rs:87-92: 400 KB in f64) -- the corner values of a batch are STAGED through a wave-private LDS
-// strip by cooperative 16-byte loads.  The counters of the query-order kernel on that shape (profiles/r05_tuning.md 1) show
-// the L1 address path as its bound: an item per lane reads every query's 40-byte corner rows as 8-byte pieces, and the
-// texture path coalesces only inside a quad of lanes -- 11.9 L1 accesses per query, 0.39 of its 0.60 ms.  A query's two
-// corners of one grid row, z[xi][yi][*] and z[xi][yi+1][*], are 2 L consecutive values: here they are read whole, by
-// P = ceil(2 L sizeof(T) / 16) neighbouring lanes loading 16 bytes each (at the alignment of T: legal on gfx950), twelve
-// row segments per load instruction at L = 5 in f64, and written to the strip; then every lane evaluates ITS query --
-// searches and the two shared divisors stay in its registers from before the staging -- with all 4 L operands from LDS
-// (segment stride padded against bank conflicts), and the rows leave through a second strip as one sequential stream of
-// 16-byte vectors, as in eval_lanes2d_kernel.  Same operands, same operation order (bilinear.rs:88-97, div_shared).
-// The grid allocation carries 16 spare bytes: the last piece of the last cell's segment may read past the values.
-typedef double dbl2_u __attribute__((ext_vector_type(2), aligned(8)));
-typedef float flt4_u __attribute__((ext_vector_type(4), aligned(4)));
+// SLOPE RECORDS for short rows on grids that do not fit LDS (round 6; the reference's 100 x 100 x 5 bench grid,
+// benches/bench_interp2d.rs:87-92).  Bilinear::interp_into (bilinear.rs:88-97) forms, per channel,
+//     z1 = calc_frac((x1, z11), (x2, z21), x) = m1 (x - x1) + z11,   m1 = (z21 - z11) / (x2 - x1)      (linear.rs:33-35)
+//     z2 = calc_frac((x1, z12), (x2, z22), x) = m2 (x - x1) + z12,   m2 = (z22 - z12) / (x2 - x1)
+//     z  = calc_frac((y1, z1), (y2, z2), y).
+// m1 and m2 have no query in them: they are formed ONCE per grid point by the IEEE division of the same operands (the same
+// bits) and kept next to the value, SR[xi][yi][c] = { z[xi][yi][c], m[xi][yi][c] } for xi < nx - 1 (slope_pack_kernel; 2 x
+// the grid, built on first use).  A query then needs ONE contiguous run of 4 L values -- the records of (xi, yi) and
+// (xi, yi + 1) -- two of its three divisions per channel are gone, and nothing has to cross lanes: a lane owns one
+// (query, channel) item, loads its two 2-value records (16 bytes each in f64) next to its neighbours' and evaluates the
+// whole bilinear form.  The 64 L items of a wave's 64 queries are walked in row-major order, 64 per trip, exactly L
+// full trips, so every trip's loads of one query are neighbouring lanes on neighbouring addresses (about 2-3 L1 accesses
+// per query instead of 11.9) and every trip's stores are 64 consecutive output values: one sequential write stream.
+// The per-query scalars {cell offset, x - x1, y - y1, dy, RN(1 / dy)} are parked in a wave-private LDS strip as
+// 16-byte units (three reads per trip, no bank conflicts: neighbouring queries, neighbouring units).
 template <class T>
-struct Piece16;
-template <>
-struct Piece16<double> { using type = dbl2_u; };
-template <>
-struct Piece16<float> { using type = flt4_u; };
-
-template <class T, int TB>
-__global__ __launch_bounds__(TB) void eval_staged2d_kernel(EvalLanes2Args<T> A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int VN = Wide<T>::N;              // = elements per 16-byte piece
-  using V = typename VecT<T, VN>::type;
-  using PV = typename Piece16<T>::type;
-  if (A.nq == 0) return;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, L = A.lanes;
-  LaneAxis<T> SX, SY;
-  XRecs<T> XX, XY;
-  size_t off = 0;
-  SX = stage_lane_axis<T, TB>(smem_raw, off, A.xk, A.nx, A.dx);
-  SY = stage_lane_axis<T, TB>(smem_raw, off, A.yk, A.ny, A.dy);
-  XX = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), A.nx - 1u};
-  off += XRecs<T>::bytes(A.nx - 1u);
-  XY = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), A.ny - 1u};
-  off += XRecs<T>::bytes(A.ny - 1u);
-  stage_xrecs<T, TB>(XX, A.xk, A.nx);
-  stage_xrecs<T, TB>(XY, A.yk, A.ny);
-  const uint32_t P = (2u * L + (uint32_t)VN - 1u) / (uint32_t)VN;   // 16-byte pieces per row segment
-  const uint32_t seg_e = P * (uint32_t)VN;                         // elements per staged segment
-  const uint32_t qs_e = 2u * seg_e + 2u;                           // elements per query of the corner strip (padded: banks)
-  const uint32_t wave = tid >> 6;
-  constexpr uint32_t WAVES = TB / 64;
-  // per wave: [64] cell offsets | [64][qs_e] corner values | [64][L] results
-  uint32_t* s_o = reinterpret_cast<uint32_t*>(smem_raw + off) + wave * 64u;
-  off += (size_t)WAVES * 64u * sizeof(uint32_t);
-  T* s_c = reinterpret_cast<T*>(smem_raw + off) + (size_t)wave * 64u * qs_e;
-  off += (((size_t)WAVES * 64u * qs_e * sizeof(T)) + 15u) & ~(size_t)15u;
-  T* s_strip = reinterpret_cast<T*>(smem_raw + off) + (size_t)wave * 64u * L;
-  __syncthreads();
-  unsigned long long limit = A.check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
-  if (limit > A.nq) limit = A.nq;
-  const uint32_t rowe = A.row_cells * A.cell_elems;
-  const bool contig = A.out_stride == (uint64_t)L;
-  const uint32_t rot = (L & 1u) ? 0u : lane % L;
-  // staging: lane -> (segment of the instruction, piece of the segment)
-  const uint32_t spi = 64u / P;                                    // segments per load instruction
-  const uint32_t seg_l = lane / P, pc = lane - seg_l * P;
-  const bool loader = seg_l < spi;
-  const uint64_t wstep = (uint64_t)gridDim.x * TB;
-  uint64_t base = ((uint64_t)blockIdx.x * WAVES + wave) * 64u;
-  // (Measured and dropped, profiles/r05_tuning.md: the staging loads of batch k + 1 held in registers while batch k is
-  //  evaluated -- 16 pieces per lane, 191 VGPRs -- is no faster in f64 and 1.7 x slower in f32: the kernel is bound by
-  //  instruction issue and LDS bank conflicts, not by the latency of the staging loads.)
-  T xq, yq;
-  {
-    const uint64_t pcq = (base + lane < A.nq) ? base + lane : A.nq - 1u;
-    xq = A.qx[pcq];
-    yq = A.qy[pcq];
-  }
-  for (; base < limit; base += wstep) {
-    const T x = xq, y = yq;
-    {
-      const uint64_t pn = base + wstep + lane;
-      const uint64_t pcq = pn < A.nq ? pn : A.nq - 1u;
-      xq = A.qx[pcq];
-      yq = A.qy[pcq];
-    }
-    if (A.check && base + lane < limit) lane_check2<T>(A.first_fail, base + lane, x, y, SX.k0, SX.kn, SY.k0, SY.kn, A.mode);
-    const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, A.row_cells, A.cell_elems, x, y);
-    s_o[lane] = c.o;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
-    const uint32_t nseg = 2u * nq_here;
-    constexpr int NI = 4;                      // load instructions in flight per wave
-    for (uint32_t s0 = 0; s0 < nseg; s0 += (uint32_t)NI * spi) {
-      PV v[NI];
-      uint32_t dst[NI];
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const uint32_t sg = s0 + (uint32_t)k * spi + seg_l;
-        const bool on = loader && sg < nseg;
-        const uint32_t sc = on ? sg : 0u;
-        const uint32_t q = NDI_CHK(sc >> 1, 64u, BC_STRIP), row = sc & 1u;
-        const uint32_t e = s_o[q] + row * rowe + pc * (uint32_t)VN;
-        v[k] = *reinterpret_cast<const PV*>(A.data + e);
-        dst[k] = on ? q * qs_e + row * seg_e + pc * (uint32_t)VN : 0xffffffffu;
-      }
-#pragma unroll
-      for (int k = 0; k < NI; ++k)
-        if (dst[k] != 0xffffffffu) {
-#pragma unroll
-          for (int j = 0; j < VN; ++j) s_c[dst[k] + (uint32_t)j] = v[k][j];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    {
-      const T* g = s_c + lane * qs_e;
-      T* mine = s_strip + lane * L;
-      for (uint32_t k = 0; k < L; ++k) {      // (even L: rotated start, see eval_lanes_kernel)
-        uint32_t l = k + rot;
-        if (l >= L) l -= L;
-        mine[l] = lane_bilinear<T>(g + l, L, seg_e, c);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t total = nq_here * L;
-    if (contig) {
-      T* const o = A.out + base * L;
-      for (uint32_t e0 = lane * VN; e0 < total; e0 += 64u * VN) {
-        if (e0 + VN <= total) {
-          store_stream<true>(reinterpret_cast<V*>(o + e0), *reinterpret_cast<const V*>(s_strip + e0));
-        } else {
-          for (uint32_t e = e0; e < total; ++e) o[e] = s_strip[e];
-        }
-      }
-    } else {
-      for (uint32_t it = lane; it < total; it += 64u) {
-        const uint32_t ql = it / L, l = it - ql * L;
-        A.out[(base + ql) * A.out_stride + l] = s_strip[it];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// CELL-QUAD layout for short rows on small / medium grids (the reference's 100 x 100 x 5 bench grid,
-// benches/bench_interp2d.rs:87-92): QD[xi][yi][c] = { z[xi][yi][c], z[xi+1][yi][c], z[xi][yi+1][c], z[xi+1][yi+1][c] } for
-// every CELL (xi < nx-1, yi < ny-1) and channel -- the four corners a query needs of one channel next to each other, the
-// 4 L values of a cell contiguous and 16-byte aligned (4 x the grid: 1.6 MB for that grid in f64, at home in L2).  A query
-// then reads ONE contiguous record; its lanes -- L of them in f32 (one 16-byte piece per channel: all four corners, the
-// whole bilinear form lane-local), 2 L in f64 (piece 2c = {z11, z21}[c], piece 2c+1 = {z12, z22}[c]: the x direction
-// lane-local, the y direction after one exchange with the neighbouring lane) -- load neighbouring 16-byte pieces, so the
-// texture path sees about three 64-byte accesses per query where the item-per-lane kernel on the row layout needs 11.9
-// (profiles/r05_tuning.md 1: its bound).  Values are copied, never recomputed; operands and operation order are the
-// reference's (bilinear.rs:88-97: x first, then y; div_shared = the bits of the IEEE divisions).
-template <class T>
-__global__ __launch_bounds__(BLOCK) void quad_pack_kernel(const T* data, T* out, uint64_t nx, uint64_t ny, uint64_t lanes,
-                                                          uint64_t row_cells, uint64_t cell_elems) {
-  // element (xi, yi, c) of the source: data[(xi * row_cells + yi) * cell_elems + c] in either layout (pair-packed: the
-  // last grid column is reached as the second half of pair ny - 2)
+__global__ __launch_bounds__(BLOCK) void slope_pack_kernel(const T* data, const T* xk, T* out, uint64_t nx, uint64_t ny,
+                                                           uint64_t lanes, uint64_t row_cells, uint64_t cell_elems,
+                                                           uint64_t cell_stride) {
+  // element (xi, yi, c) of the source: data[(xi * row_cells + yi) * cell_elems + c] in either layout (pair-packed,
+  // pack_pairs_kernel: the last grid column is reached as the second half of pair ny - 2)
   auto src = [&](uint64_t xi, uint64_t yi, uint64_t c) -> T {
     if (cell_elems == lanes) return data[(xi * row_cells + yi) * cell_elems + c];
     return yi < row_cells ? data[(xi * row_cells + yi) * cell_elems + c] : data[(xi * row_cells + yi - 1) * cell_elems + lanes + c];
   };
-  const uint64_t cells = (nx - 1) * (ny - 1), total = cells * lanes;
+  if (cell_stride == 0) {       // POINT records: SR[xi][yi][c] = {z, m}, a query's two records are neighbours
+    const uint64_t per_row = ny * lanes, total = (nx - 1) * per_row;
+    for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
+      const uint64_t xi = e / per_row, r = e - xi * per_row;
+      const uint64_t yi = r / lanes, c = r - yi * lanes;
+      const T z = src(xi, yi, c), zn = src(xi + 1, yi, c);
+      out[2 * e] = z;
+      out[2 * e + 1] = (zn - z) / (xk[xi + 1] - xk[xi]);       // linear.rs:33, once per grid point
+    }
+    return;
+  }
+  // CELL records: every cell (xi, yi) owns {z, m}[yi][0 .. L) ++ {z, m}[yi + 1][0 .. L) at (xi (ny - 1) + yi) cell_stride
+  // elements -- the stride padded so that a record never straddles more 128-byte lines than it has to
+  const uint64_t per_cell = 2 * lanes, per_row = (ny - 1) * per_cell, total = (nx - 1) * per_row;
   for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (uint64_t)gridDim.x * BLOCK) {
-    const uint64_t cell = e / lanes, c = e - cell * lanes;
-    const uint64_t xi = cell / (ny - 1), yi = cell - xi * (ny - 1);
-    T* o = out + e * 4;
-    o[0] = src(xi, yi, c);
-    o[1] = src(xi + 1, yi, c);
-    o[2] = src(xi, yi + 1, c);
-    o[3] = src(xi + 1, yi + 1, c);
+    const uint64_t xi = e / per_row, r = e - xi * per_row;
+    const uint64_t yc = r / per_cell, k = r - yc * per_cell;
+    const uint64_t yi = yc + (k >= lanes ? 1 : 0), c = k >= lanes ? k - lanes : k;
+    const T z = src(xi, yi, c), zn = src(xi + 1, yi, c);
+    T* o = out + (xi * (ny - 1) + yc) * cell_stride + 2 * k;
+    o[0] = z;
+    o[1] = (zn - z) / (xk[xi + 1] - xk[xi]);
   }
 }
 
 template <class T>
-struct EvalQuads2Args {
+struct EvalSlopes2Args {
   const T* xk;             // [nx]
   const T* yk;             // [ny]
   uint32_t nx, ny;
   DenseLut<T> dx, dy;
-  const T* quads;          // [(nx-1)(ny-1)][lanes][4]
+  const T* recs;           // point records [(nx-1)][ny][lanes][2] = {z, m}, or cell records (slope_pack_kernel)
+  uint32_t row_bytes, col_bytes;    // byte offset of a query's first record = xi * row_bytes + yi * col_bytes
+  int debug;               // NDI_TUNING builds only (measurement aid, results meaningless): bit 0 no record loads, bit 1 no
+                           // stores, bit 2 no searches, bit 3 no division
   const T* qx;
   const T* qy;
   T* out;
@@ -4004,97 +3884,221 @@ struct EvalQuads2Args {
   int check;                        // see EvalLanesArgs
 };
 
-template <class T, int TB>
-__global__ __launch_bounds__(TB) void eval_quads2d_kernel(EvalQuads2Args<T> A) {
+template <class T>
+struct Pair2;
+template <>
+struct Pair2<double> { using type = dbl2; };
+template <>
+struct Pair2<float> { typedef float type __attribute__((ext_vector_type(2))); };
+
+// the branch-free search with a compile-time number of knot reads per bucket (MK >= the index's maxk: knots behind the
+// bucket's own -- and the +inf sentinels -- are > x and count nothing)
+template <class T, int MK>
+__device__ __forceinline__ uint32_t lane_axis_index_mk(const LaneAxis<T>& S, T x) {
+  if (S.lut) {                                            // (workgroup-uniform)
+    T f = (x - S.k0) * S.scale;
+    f = fmax(f, T(0));                                    // below the axis, NaN -> bucket 0
+    f = fmin(f, T(S.m - 1u));
+    const uint32_t lo = S.lut[(uint32_t)f];
+    const uint32_t cnt = lo + knots_le<T, MK>(S.k, lo, x);
+    const uint32_t i = cnt ? cnt - 1u : 0u;
+    return i < S.n - 2u ? i : S.n - 2u;
+  }
+  const T mm = S.gfac * (x - S.k0) + T(0);
+  return (mm >= T(0)) ? (uint32_t)(mm < T(S.n - 2u) ? mm : T(S.n - 2u)) : 0u;
+}
+
+// Software pipeline of a wave (one batch = 64 consecutive queries, LC trips of 64 items).  The counter that orders a
+// wave's memory operations (vmcnt) is in-order and counts stores: a load issued BEHIND a batch's stores can only be waited
+// for by draining those stores -- microseconds per batch.  So every load is issued AHEAD of the stores it must not wait for:
+//     iteration k:   evaluate batch k (its records were requested an iteration ago, its scalars are in strip k & 1)
+//                    request the records of batch k + 1 (strip (k + 1) & 1 is complete) and the queries of batch k + 3
+//                    store batch k                                  <- nothing later waits for these
+//                    search batch k + 2 (queries requested an iteration ago) into strip k & 1
+// The loop body is straight-line for full batches (unconditional stores: the compiler can count, `s_waitcnt vmcnt(N)` with
+// N > 0); the one partial batch a wave may have is its last and is handled behind the loop.  The kernel's own range test
+// (`check`) keeps the lowest failing index per lane in registers and publishes it once, at the end.
+template <class T, int LC, int MK, int CONTIG, int TB>      // CONTIG: 0 strided rows, 1 contiguous, 2 contiguous through a
+                                                           // wave-private LDS strip as 16-byte vectors (needs out 16-byte aligned)
+__global__ __launch_bounds__(TB) void eval_slopes2d_kernel(EvalSlopes2Args<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int VN = Wide<T>::N;
-  using V = typename VecT<T, VN>::type;
-  constexpr bool F32 = sizeof(T) == 4;
+  using P2 = typename Pair2<T>::type;                // one {z, m} record / one pair of per-query scalars
   if (A.nq == 0) return;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, L = A.lanes;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr uint32_t WAVES = TB / 64;
   LaneAxis<T> SX, SY;
-  XRecs<T> XX, XY;
+  XRecs<T> XY;
   size_t off = 0;
   SX = stage_lane_axis<T, TB>(smem_raw, off, A.xk, A.nx, A.dx);
   SY = stage_lane_axis<T, TB>(smem_raw, off, A.yk, A.ny, A.dy);
-  XX = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), A.nx - 1u};
-  off += XRecs<T>::bytes(A.nx - 1u);
   XY = XRecs<T>{reinterpret_cast<typename XRecs<T>::U*>(smem_raw + off), A.ny - 1u};
   off += XRecs<T>::bytes(A.ny - 1u);
-  stage_xrecs<T, TB>(XX, A.xk, A.nx);
   stage_xrecs<T, TB>(XY, A.yk, A.ny);
-  // per wave: [64] record offsets | [6][64] fx, fy, dx, 1/dx, dy, 1/dy
-  uint32_t* w_o = reinterpret_cast<uint32_t*>(smem_raw + off) + wave * 64u;
-  off += (size_t)WAVES * 64u * sizeof(uint32_t);
-  T* w_s = reinterpret_cast<T*>(smem_raw + off) + (size_t)wave * 64u * 6u;
+  // per wave, twice: [64] {x - x1, y - y1} | [64] {dy, RN(1 / dy) or 0} | [64] record byte offsets
+  constexpr uint32_t STRIP = 64u * (2u * (uint32_t)sizeof(P2) + 4u);
+  unsigned char* const w_base = smem_raw + off + (size_t)wave * 2u * STRIP;
+  auto strip_f = [&](uint32_t b) { return reinterpret_cast<P2*>(w_base + b * STRIP); };
+  auto strip_d = [&](uint32_t b) { return reinterpret_cast<P2*>(w_base + b * STRIP + 64u * sizeof(P2)); };
+  auto strip_o = [&](uint32_t b) { return reinterpret_cast<uint32_t*>(w_base + b * STRIP + 128u * sizeof(P2)); };
+  constexpr int VN = Wide<T>::N;
+  using V = typename VecT<T, VN>::type;
+  T* const w_res = reinterpret_cast<T*>(smem_raw + off + (size_t)WAVES * 2u * STRIP) + (size_t)wave * 64u * LC;   // CONTIG == 2
   __syncthreads();
-  unsigned long long limit = A.check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
+  const int check = A.check, mode = A.mode;
+  unsigned long long limit = check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
   if (limit > A.nq) limit = A.nq;
-  const uint32_t PL = F32 ? L : 2u * L;              // lanes (16-byte pieces) per query
-  const uint32_t QT = 64u / PL;                      // queries per trip
-  const uint32_t ql = lane / PL, pc = lane - ql * PL;
-  const bool worker = ql < QT;
-  const uint32_t ch = F32 ? pc : pc >> 1;            // the channel this lane serves
-  const bool writer = worker && (F32 || (pc & 1u) == 0u);
+  // trip t serves items t * 64 + lane of the batch's 64 * LC: query and channel of this lane in every trip
+  uint32_t tq[LC], tc[LC];
+#pragma unroll
+  for (int t = 0; t < LC; ++t) {
+    const uint32_t it = (uint32_t)t * 64u + lane;
+    tq[t] = it / (uint32_t)LC;
+    tc[t] = (it - tq[t] * (uint32_t)LC) * (uint32_t)sizeof(P2);
+  }
   const uint64_t wstep = (uint64_t)gridDim.x * TB;
   uint64_t base = ((uint64_t)blockIdx.x * WAVES + wave) * 64u;
-  const T* __restrict__ const quads = A.quads;
+  if (base >= limit) return;
+  const char* __restrict__ const recs = reinterpret_cast<const char*>(A.recs);
   T* __restrict__ const out = A.out;
-  T xq, yq;
-  {
-    const uint64_t pcq = (base + lane < A.nq) ? base + lane : A.nq - 1u;
-    xq = A.qx[pcq];
-    yq = A.qy[pcq];
+  const uint32_t row_bytes = A.row_bytes, col_bytes = A.col_bytes;
+  unsigned long long failx = NO_FAIL, faily = NO_FAIL;   // (check) lowest failing query of this lane, per axis
+  // one batch's searches: cell, (x - x1), (y - y1), the y spacing with its reciprocal -> strip b
+  auto phase1 = [&](uint32_t b, uint64_t bbase, T x, T y) {
+    if (check) {                                     // Interp2D::is_in_x_range / is_in_y_range, see lane_check2
+      const bool badx = (mode == EX_NO) ? !((SX.k0 <= x) && (x <= SX.kn)) : !(x == x);
+      const bool bady = (mode == EX_NO) ? !((SY.k0 <= y) && (y <= SY.kn)) : !(y == y);
+      const unsigned long long qi = bbase + lane;
+      if (badx && qi < limit && qi < failx) failx = qi;
+      if (bady && qi < limit && qi < faily) faily = qi;
+    }
+    uint32_t xi = NDI_CHK((lane_axis_index_mk<T, MK>(SX, x)), SX.n - 1u, BC_CELL_X);
+    uint32_t yi = NDI_CHK((lane_axis_index_mk<T, MK>(SY, y)), SY.n - 1u, BC_CELL_Y);
+#ifdef NDI_TUNING
+    if (A.debug & 4) { xi = ((uint32_t)(x * T(977)) * 7u + lane) % (SX.n - 1u); yi = ((uint32_t)(y * T(1013)) * 13u + lane) % (SY.n - 1u); }
+#endif
+    T ry[4];
+    XY.get(yi, ry);
+    P2 f, d;
+    f[0] = x - SX.k[xi];                   // linear.rs:35's (x - x1) of both directions
+    f[1] = y - ry[0];
+    d[0] = ry[1];
+    d[1] = ry[2];                          // 0: the divisor is outside the shared-divisor window
+    strip_f(b)[lane] = f;
+    strip_d(b)[lane] = d;
+    strip_o(b)[lane] = xi * row_bytes + yi * col_bytes;
+  };
+  auto load_q = [&](uint64_t bbase, T& x, T& y) {
+    const uint64_t pn = bbase + lane;
+    const uint64_t pcq = pn < A.nq ? pn : A.nq - 1u;
+#ifdef NDI_TUNING
+    if (A.debug & 64) { x = SX.k0 + T(lane); y = SY.k0 + T(pcq & 63u); return; }
+#endif
+    x = A.qx[pcq];
+    y = A.qy[pcq];
+  };
+  P2 r1[LC], r2[LC];
+  auto request = [&](uint32_t b) {                   // the records of strip b's batch: all trips
+    const uint32_t* const co = strip_o(b);
+#pragma unroll
+    for (int t = 0; t < LC; ++t) {
+      const uint32_t o = co[NDI_CHK(tq[t], 64u, BC_STRIP)] + tc[t];
+#ifdef NDI_TUNING
+      if (A.debug & 1) { r1[t] = P2(T(o)); r2[t] = P2(T(o + 1u)); continue; }
+#endif
+      r1[t] = *reinterpret_cast<const P2*>(recs + o);
+      r2[t] = *reinterpret_cast<const P2*>(recs + o + (uint32_t)LC * (uint32_t)sizeof(P2));
+    }
+  };
+  T res[LC];
+  auto evaluate = [&](uint32_t b) {                  // bilinear.rs:88-97 with the records' slopes
+    const P2* const cf = strip_f(b);
+    const P2* const cd = strip_d(b);
+#pragma unroll
+    for (int t = 0; t < LC; ++t) {
+      P2 f = cf[tq[t]], d = cd[tq[t]];
+#ifdef NDI_TUNING
+      if (A.debug & 32) { f = P2(T(1.5)); d = P2(T(0.5)); }
+#endif
+      SharedDivisor<T> dy;
+      dy.d = d[0]; dy.r = d[1]; dy.ok = d[1] > T(0);
+      const T z1 = r1[t][1] * f[0] + r1[t][0];
+      const T z2 = r2[t][1] * f[0] + r2[t][0];
+      bool okg;
+#ifdef NDI_TUNING
+      if (A.debug & 8) { res[t] = (z2 - z1) * d[1] * f[1] + z1; continue; }
+#endif
+      T m = div_shared_fast<T>(z2 - z1, dy, okg);
+      if (__builtin_expect(!okg, 0)) m = (z2 - z1) / d[0];       // outside the window: the IEEE division
+      res[t] = m * f[1] + z1;
+      if (CONTIG == 2) w_res[(uint32_t)t * 64u + lane] = res[t];
+    }
+  };
+  T xa, ya, xb, yb;                                  // queries of the next two batches to be searched
+  load_q(base, xa, ya);
+  load_q(base + wstep, xb, yb);
+  phase1(0u, base, xa, ya);
+  __builtin_amdgcn_wave_barrier();
+  request(0u);
+  load_q(base + 2u * wstep, xa, ya);
+  phase1(1u, base + wstep, xb, yb);
+  __builtin_amdgcn_wave_barrier();
+  uint32_t cur = 0;
+  // one full batch.  (The first iteration is peeled so that the loop is entered in its steady state -- this batch's records
+  // requested, the queries and the previous batch's stores behind them: the compiler takes the smaller count of two entry
+  // paths, and a prologue without stores would make every iteration wait for part of the previous batch's stores.)
+  auto full_batch = [&]() {
+    evaluate(cur);
+    load_q(base + 3u * wstep, xb, yb);
+    request(cur ^ 1u);                               // batch k + 1: AHEAD of this batch's stores
+#ifdef NDI_TUNING
+    if ((A.debug & 2) && res[0] != T(-12345.678)) {} else
+#endif
+    if (CONTIG == 2) {                               // 64 * LC values = 64 * LC / VN vectors, lane after lane
+      V* const ov = reinterpret_cast<V*>(out + base * (uint64_t)LC) + lane;
+      const V* const sv = reinterpret_cast<const V*>(w_res) + lane;
+      constexpr int NV = 64 * LC / VN;               // (64 * LC is a multiple of VN)
+#pragma unroll
+      for (int v = 0; v < (NV + 63) / 64; ++v)
+        if (v * 64 + 64 <= NV || lane < (uint32_t)(NV - v * 64)) store_stream<true>(ov + v * 64, sv[v * 64]);
+    } else if (CONTIG) {
+      T* const orow = out + base * (uint64_t)LC + lane;
+#ifdef NDI_TUNING
+      if (A.debug & 16) {
+#pragma unroll
+        for (int t = 0; t < LC; ++t) orow[(uint32_t)t * 64u] = res[t];
+      } else
+#endif
+#pragma unroll
+      for (int t = 0; t < LC; ++t) store_stream<true>(orow + (uint32_t)t * 64u, res[t]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < LC; ++t) out[(base + tq[t]) * A.out_stride + tc[t] / (uint32_t)sizeof(P2)] = res[t];
+    }
+    __builtin_amdgcn_wave_barrier();                 // strip `cur` has been read: the batch after next takes it
+    phase1(cur, base + 2u * wstep, xa, ya);
+    xa = xb; ya = yb;
+    __builtin_amdgcn_wave_barrier();
+    base += wstep;
+    cur ^= 1u;
+  };
+  if (limit - base >= 64u) {
+    full_batch();
+    while (base < limit && limit - base >= 64u) full_batch();
   }
-  for (; base < limit; base += wstep) {
-    const T x = xq, y = yq;
-    {
-      const uint64_t pn = base + wstep + lane;
-      const uint64_t pcq = pn < A.nq ? pn : A.nq - 1u;
-      xq = A.qx[pcq];
-      yq = A.qy[pcq];
-    }
-    if (A.check && base + lane < limit) lane_check2<T>(A.first_fail, base + lane, x, y, SX.k0, SX.kn, SY.k0, SY.kn, A.mode);
-    {
-      const LaneCell<T> c = lane_cell<T>(SX, SY, XX, XY, A.ny - 1u, 4u * L, x, y);
-      w_o[lane] = c.o;
-      w_s[0 * 64 + lane] = c.fx;
-      w_s[1 * 64 + lane] = c.fy;
-      w_s[2 * 64 + lane] = c.dx.d;
-      w_s[3 * 64 + lane] = c.dx.ok ? c.dx.r : T(0);
-      w_s[4 * 64 + lane] = c.dy.d;
-      w_s[5 * 64 + lane] = c.dy.ok ? c.dy.r : T(0);
-    }
-    __builtin_amdgcn_wave_barrier();        // LDS operations of one wave execute in order: no s_barrier needed
-    const uint32_t nq_here = (limit - base < 64u) ? (uint32_t)(limit - base) : 64u;
-    // (Requesting the pieces of six trips before the first is used -- 24 more VGPRs -- was measured SLOWER, 0.75 vs 0.66 ms
-    //  at L = 5 in f64, 0.35 vs 0.33 in f32: the kernel is bound by instruction issue, not by the latency of its loads.)
-    for (uint32_t q0 = 0; q0 < nq_here; q0 += QT) {
-      const uint32_t q = q0 + ql;
-      const bool act = worker && q < nq_here;
-      const uint32_t qc = NDI_CHK(act ? q : 0u, 64u, BC_STRIP);
-      const V piece = *reinterpret_cast<const V*>(quads + w_o[qc] + (worker ? pc * (uint32_t)VN : 0u));
-      SharedDivisor<T> dx, dy;
-      const T fx = w_s[0 * 64 + qc], fy = w_s[1 * 64 + qc];
-      dx.d = w_s[2 * 64 + qc]; dx.r = w_s[3 * 64 + qc]; dx.ok = dx.r > T(0);
-      dy.d = w_s[4 * 64 + qc]; dy.r = w_s[5 * 64 + qc]; dy.ok = dy.r > T(0);
-      T z1, z2;
-      if constexpr (F32) {                  // piece = {z11, z21, z12, z22} of this lane's channel
-        z1 = div_shared<T, T>(piece[1] - piece[0], dx) * fx + piece[0];
-        z2 = div_shared<T, T>(piece[3] - piece[2], dx) * fx + piece[2];
-      } else {                              // piece = {z11, z21} (even lane) or {z12, z22} (odd lane)
-        const T zx = div_shared<T, T>(piece[1] - piece[0], dx) * fx + piece[0];
-        const T other = __shfl_xor(zx, 1, 64);
-        z1 = zx;
-        z2 = other;
+  if (base < limit) {                                // the wave's last, partial batch
+    const uint32_t nq_here = (uint32_t)(limit - base);
+    evaluate(cur);
+#pragma unroll
+    for (int t = 0; t < LC; ++t)
+      if (tq[t] < nq_here) {
+        if (CONTIG) out[base * (uint64_t)LC + ((uint32_t)t * 64u + lane)] = res[t];
+        else out[(base + tq[t]) * A.out_stride + tc[t] / (uint32_t)sizeof(P2)] = res[t];
       }
-      if (act && writer) {
-        const T r = div_shared<T, T>(z2 - z1, dy) * fy + z1;
-        out[(base + q) * A.out_stride + ch] = r;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();        // the strip is rewritten by the next batch
+  }
+  if (check) {
+    if (failx != NO_FAIL) atomicMin(&A.first_fail[0], failx);
+    if (faily != NO_FAIL) atomicMin(&A.first_fail[1], faily);
   }
 }
 

@@ -2509,65 +2509,91 @@ struct Interp2DImpl final : Interp2DBase {
   bool pair_packed = false;   // data holds the pair-packed layout (pack_pairs_kernel)
   SpaceSet spaces;
   OwnedRing ring_own;
-  // the cell-quad copy of a small / medium grid with short rows (quad_pack_kernel, eval_quads2d_kernel): built on first
-  // use by a kernel on the caller's stream, as Interp1DImpl::ensure_packed builds its copy -- 0 = not built, 1 = built and
-  // complete, 2 = not available, 3 = enqueued on quads_stream, completion signalled by quads_ev
-  DevBuf quads;
-  std::atomic<int> quads_state{0};
-  std::mutex quads_mu;
-  hipEvent_t quads_ev = nullptr;
-  hipStream_t quads_stream = nullptr;
-  static constexpr size_t QUADS_LIMIT = (size_t)64 << 20;
+  // lazy copies of the grid are built on first use by a kernel on the caller's stream, as Interp1DImpl::ensure_packed builds
+  // its copy -- state 0 = not built, 1 = built and complete, 2 = not available, 3 = enqueued on *_stream, completion
+  // signalled by *_ev
   ~Interp2DImpl() {
-    if (quads_ev) (void)hipEventDestroy(quads_ev);
+    if (slopes_ev) (void)hipEventDestroy(slopes_ev);
   }
-  size_t quads_bytes() const { return (size_t)(nx - 1) * (ny - 1) * 4 * lanes * sizeof(T); }
-  bool ensure_quads(hipStream_t s) {
-    int st = quads_state.load(std::memory_order_acquire);
+  // the slope-record copy (slope_pack_kernel, eval_slopes2d_kernel): {z, m} per grid point of rows 0 .. nx - 2, 2 x the
+  // grid, built on first use
+  DevBuf slopes;
+  std::atomic<int> slopes_state{0};
+  std::mutex slopes_mu;
+  hipEvent_t slopes_ev = nullptr;
+  hipStream_t slopes_stream = nullptr;
+  static constexpr size_t SLOPES_LIMIT = (size_t)256 << 20;
+  // Layout of the copy: POINT records (2 x the grid; a query reads 4 L sizeof(T) contiguous bytes at the alignment of one
+  // record) or CELL records (every cell owns its 4 L values at a stride padded to a power of two / a multiple of 128 bytes: a
+  // query then touches ceil(bytes / 128) lines exactly).  The kernel is bound by L1 misses in flight (counters:
+  // profiles/r06_slopes2d_*), so the layout with fewer lines per query wins; a tie goes to the smaller table.
+  // NDI_SLOPES2D_CELLS=0 / 1: A/B.
+  size_t slopes_cell_stride_bytes() const {
+    const size_t need = 4 * lanes * sizeof(T);
+    size_t sb = 32;
+    while (sb < need && sb < 128) sb *= 2;
+    if (sb < need) sb = (need + 127) / 128 * 128;
+    return sb;
+  }
+  bool slopes_cells() const {
+    static const int env = ShortKnobs::env("NDI_SLOPES2D_CELLS", -1);
+    if (env >= 0) return env != 0;
+    const double need = (double)(4 * lanes * sizeof(T));
+    const double lines_point = 1.0 + (need - 2.0 * sizeof(T)) / 128.0;
+    const double lines_cell = (double)((slopes_cell_stride_bytes() + 127) / 128);
+    return lines_cell <= 0.85 * lines_point;
+  }
+  size_t slopes_bytes() const {
+    return slopes_cells() ? (size_t)(nx - 1) * (ny - 1) * slopes_cell_stride_bytes() : (size_t)(nx - 1) * ny * 2 * lanes * sizeof(T);
+  }
+  bool ensure_slopes(hipStream_t s) {
+    int st = slopes_state.load(std::memory_order_acquire);
     if (st == 1) return true;
     if (st == 2) return false;
-    std::lock_guard<std::mutex> g(quads_mu);
-    st = quads_state.load(std::memory_order_acquire);
+    std::lock_guard<std::mutex> g(slopes_mu);
+    st = slopes_state.load(std::memory_order_acquire);
     if (st == 1) return true;
     if (st == 2) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
     if (cs != hipStreamCaptureStatusNone) return false;   // this batch takes another kernel
     if (st == 0) {
-      const size_t bytes = quads_bytes();
-      if (bytes == 0 || bytes > QUADS_LIMIT) {
-        quads_state.store(2, std::memory_order_release);
+      const size_t bytes = slopes_bytes();
+      if (bytes == 0 || bytes > SLOPES_LIMIT) {
+        slopes_state.store(2, std::memory_order_release);
         return false;
       }
       try {
         maybe_fail_lazy_alloc(__LINE__);
-        quads.reserve(bytes);
-        if (!quads_ev) NDI_HIP(hipEventCreateWithFlags(&quads_ev, hipEventDisableTiming));
-        const uint64_t total = (uint64_t)(nx - 1) * (ny - 1) * lanes;
+        slopes.reserve(bytes);
+        if (!slopes_ev) NDI_HIP(hipEventCreateWithFlags(&slopes_ev, hipEventDisableTiming));
+        const uint64_t total = (uint64_t)(nx - 1) * ny * 2 * lanes;
         const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((total + BLOCK - 1) / BLOCK, 65536));
-        hipLaunchKernelGGL(quad_pack_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, (const T*)data.as<T>(), quads.as<T>(), nx, ny, lanes,
-                           (uint64_t)(pair_packed ? ny - 1 : ny), (uint64_t)(pair_packed ? 2 * lanes : lanes));
+        if (slopes_cells()) NDI_HIP(hipMemsetAsync(slopes.p, 0, bytes, s));     // (the padding is never read; kept defined)
+        hipLaunchKernelGGL(slope_pack_kernel<T>, dim3(gr), dim3(BLOCK), 0, s, (const T*)data.as<T>(), (const T*)px.view.lv0,
+                           slopes.as<T>(), nx, ny, lanes, (uint64_t)(pair_packed ? ny - 1 : ny),
+                           (uint64_t)(pair_packed ? 2 * lanes : lanes),
+                           (uint64_t)(slopes_cells() ? slopes_cell_stride_bytes() / sizeof(T) : 0));
         NDI_HIP(hipGetLastError());
-        NDI_HIP(hipEventRecord(quads_ev, s));
+        NDI_HIP(hipEventRecord(slopes_ev, s));
       } catch (const HipFailure&) {
         (void)hipGetLastError();
-        quads.release();
-        quads_state.store(2, std::memory_order_release);
+        slopes.release();
+        slopes_state.store(2, std::memory_order_release);
         return false;
       }
-      quads_stream = s;
-      quads_state.store(3, std::memory_order_release);
+      slopes_stream = s;
+      slopes_state.store(3, std::memory_order_release);
       return true;
     }
-    if (hipEventQuery(quads_ev) == hipSuccess) {   // st == 3
-      quads_state.store(1, std::memory_order_release);
+    if (hipEventQuery(slopes_ev) == hipSuccess) {   // st == 3
+      slopes_state.store(1, std::memory_order_release);
       return true;
     }
     (void)hipGetLastError();
-    if (s != quads_stream) NDI_HIP(hipStreamWaitEvent(s, quads_ev, 0));
+    if (s != slopes_stream) NDI_HIP(hipStreamWaitEvent(s, slopes_ev, 0));
     return true;
   }
-
   uint64_t signature() const override {
     uint64_t h = fnv1a(FNV_SEED, px.host_knots.data(), px.host_knots.size() * sizeof(T));
     h = fnv1a(h, py.host_knots.data(), py.host_knots.size() * sizeof(T));
@@ -2578,9 +2604,10 @@ struct Interp2DImpl final : Interp2DBase {
   // Two stages as in Interp1DImpl: prep() = both searches (+ the optional tile grouping) into a scratch set,
   // launch_eval() = the bilinear kernel reading that set.
   struct Plan2 {
-    enum Kind { SMALL, GATHER, TILED, FUSED2, LANES2, STAGED2, QUADS2 } kind = GATHER;
+    enum Kind { SMALL, GATHER, TILED, FUSED2, LANES2, SLOPES2 } kind = GATHER;
     int l_qpl = 1;          // LANES2, scalar grids: queries per lane (1, or one 16-byte vector)
     bool l_check = false;   // LANES2: no range pre-pass (NDI_EVAL_FRESH_OUTPUT)
+    bool f_lds_wide = false;   // SLOPES2: f_lds includes the result strip of the 16-byte store path
     // FUSED2 (eval_fused2d_kernel)
     bool f_vec = false, f_lut = false;
     uint64_t f_lv = 0;
@@ -2651,85 +2678,38 @@ struct Interp2DImpl final : Interp2DBase {
         }
       }
     }
-    // Short rows (up to 64 bytes) on a grid whose cell-quad copy (4 x the grid) stays under 64 MiB, large batches: one
-    // contiguous record per query read by neighbouring lanes (eval_quads2d_kernel; the copy is built on first use).
-    // NDI_QUADS2D_KERNEL=0 / 1: A/B.
+    // Short rows (up to 64 bytes) on a grid that does not fit LDS, large batches: slope records {z, m} -- one contiguous
+    // run of 4 L values per query, one division per value instead of three, an item per lane (eval_slopes2d_kernel; the
+    // copy, 2 x the grid, is built on first use).  NDI_SLOPES2D_KERNEL=0 / 1: A/B.
     {
-      static const bool tune_live4 = std::getenv("NDI_TUNE_LIVE") != nullptr;
-      static const int on_once4 = ShortKnobs::env("NDI_QUADS2D_KERNEL", -1);
-      const int on = tune_live4 ? ShortKnobs::env("NDI_QUADS2D_KERNEL", -1) : on_once4;
+      static const bool tune_live5 = std::getenv("NDI_TUNE_LIVE") != nullptr;
+      static const int on_once5 = ShortKnobs::env("NDI_SLOPES2D_KERNEL", -1);
+      const int on = tune_live5 ? ShortKnobs::env("NDI_SLOPES2D_KERNEL", -1) : on_once5;
       const size_t cell_b = (size_t)lanes * sizeof(T);
-      const uint32_t pl = (uint32_t)(sizeof(T) == 4 ? lanes : 2 * lanes);
-      if (on != 0 && path != NDI_PATH_BUCKETED && lanes >= 2 && pl <= 32 && cell_b <= 64 && nx <= 16384 && ny <= 16384 &&
-          (uint64_t)(nx - 1) * (ny - 1) * 4 * lanes < (1ull << 32) && quads_bytes() <= QUADS_LIMIT &&
-          (on > 0 || (nq >= (lanes <= 2 ? 524288u : 65536u) && (double)nq * (double)cell_b >= 2.0 * (double)quads_bytes() &&   // (1-2 values: the one-thread-per-query kernel keeps the smaller batches, as before)
-                      // AUTO: where it was measured ahead of the other kernels (profiles/r05_tuning.md 9): f32 rows of up to
-                      // 32 bytes (100 x 100 x 5: 61-63 vs 52-54 staged / 37 query order; 1000 x 1000 x 4: 37-42 vs 28), f64
-                      // pairs (45 -> 57); wider rows and f64 from three values are bound by instruction issue and lose
-                      ((std::is_same<T, float>::value && cell_b <= 32) || (std::is_same<T, double>::value && lanes == 2))))) {
+      if (on != 0 && path != NDI_PATH_BUCKETED && lanes >= 1 && cell_b <= 64 && nx <= 16384 && ny <= 16384 &&
+          (uint64_t)slopes_bytes() < (1ull << 32) && slopes_bytes() <= SLOPES_LIMIT &&
+          // AUTO: measured ahead of (f64 x 8, f32 x 16: level with) the query-order kernel on every row of up to 64 bytes
+          // (profiles/r06_slopes2d_rates.txt); batches large enough to pay for building the copy; 1-2 values per point:
+          // the one-thread-per-query kernel keeps the smaller batches, as before
+          (on > 0 || (nq >= (lanes <= 2 ? 524288u : 65536u) && (double)nq * (double)cell_b >= 2.0 * (double)slopes_bytes()))) {
         px.ensure_dense_lut();
         py.ensure_dense_lut();
         const size_t fixed = (((size_t)(nx + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
                              (((size_t)(ny + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
-                             px.dlut_bytes + py.dlut_bytes + (size_t)(nx - 1 + ny - 1) * 4 * sizeof(T);
-        static const int qtb_env = ShortKnobs::env("NDI_QUADS2D_TB", 0);
-        const unsigned tb = (qtb_env == 64 || qtb_env == 128 || qtb_env == 256 || qtb_env == 512) ? (unsigned)qtb_env : 256u;
-        const size_t need = fixed + (size_t)(tb / 64) * 64 * (4 + 6 * sizeof(T));
-        if (px.dense_ok && py.dense_ok && need <= FUSED_LDS_LIMIT && ensure_quads(s)) {
-          P.kind = Plan2::QUADS2;
+                             px.dlut_bytes + py.dlut_bytes + (size_t)(ny - 1) * 4 * sizeof(T);
+        const unsigned tb = 256u;
+        size_t need = fixed + (size_t)(tb / 64) * 2 * 64 * (4 + 4 * sizeof(T));
+        const size_t res_strip = (size_t)(tb / 64) * 64 * lanes * sizeof(T);      // the rows of a batch, for 16-byte stores
+        const bool wide_fits = need + res_strip <= FUSED_LDS_LIMIT;
+        if (wide_fits) need += res_strip;
+        if (px.dense_ok && py.dense_ok && need <= FUSED_LDS_LIMIT && ensure_slopes(s)) {
+          P.kind = Plan2::SLOPES2;
           P.f_tb = tb;
           P.f_lds = need;
-          const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
-          P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + P.f_tb - 1) / P.f_tb, (uint64_t)cu_count() * wg_per_cu));
-          g_last_path.store(NDI_PATH_GATHER);
-          P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
-          if (P.l_check) return P;
-          const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + BLOCK - 1) / BLOCK, 4096));
-          ProfScope ps(s, PC_LOCATE);
-          hipLaunchKernelGGL(range_check_kernel<T>, dim3(g), dim3(BLOCK), 0, s, qx, qy, nq, px.host_knots.front(),
-                             px.host_knots.back(), py.host_knots.front(), py.host_knots.back(), mode, &st->first_fail[0]);
-          NDI_HIP(hipGetLastError());
-          ps.done();
-          return P;
-        }
-      }
-    }
-    // Short rows on a grid too large for LDS but at home in L2 (the reference's 100 x 100 x 5 bench grid): query per lane
-    // with the batch's corner rows staged through LDS by cooperative 16-byte loads (eval_staged2d_kernel) -- the
-    // query-order kernel is bound by the L1 address path on these.  Measured (profiles/r05_tuning.md): 100 x 100 x 5 f32
-    // 53 vs 37 Gqueries/s; f64 26 vs 33 and every wider row slower (instruction issue + LDS bank conflicts) -- AUTO
-    // takes it for f32 rows of 16-24 bytes only.  NDI_STAGED2D_KERNEL=0 / 1: A/B.
-    {
-      static const bool tune_live3 = std::getenv("NDI_TUNE_LIVE") != nullptr;
-      static const int on_once3 = ShortKnobs::env("NDI_STAGED2D_KERNEL", -1);
-      const int on = tune_live3 ? ShortKnobs::env("NDI_STAGED2D_KERNEL", -1) : on_once3;
-      constexpr int VNg = Wide<T>::N;
-      const size_t cell_b = (size_t)lanes * sizeof(T);
-      const uint64_t cell_e = pair_packed ? 2 * lanes : lanes, row_c = pair_packed ? ny - 1 : ny;
-      const size_t grid_b = (size_t)nx * row_c * cell_e * sizeof(T);
-      if (on != 0 && path != NDI_PATH_BUCKETED && lanes >= 2 && cell_b >= 16 && cell_b <= 128 && nx <= 16384 && ny <= 16384 &&
-          (uint64_t)nx * row_c * cell_e < (1ull << 31) &&
-          (on > 0 || (std::is_same<T, float>::value && cell_b <= 24 && nq >= 65536 && grid_b <= ((size_t)32 << 20) &&
-                      (double)nq * (double)cell_b >= 4.0 * (double)grid_b))) {   // AUTO: where it was measured faster (f32 rows of 16-24 B)
-        px.ensure_dense_lut();
-        py.ensure_dense_lut();
-        const size_t fixed = (((size_t)(nx + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
-                             (((size_t)(ny + LANE_SENTINELS) * sizeof(T) + 15) & ~(size_t)15) +
-                             px.dlut_bytes + py.dlut_bytes + (size_t)(nx - 1 + ny - 1) * 4 * sizeof(T);
-        const size_t pieces = (2 * lanes + VNg - 1) / VNg;
-        const size_t qs_e = 2 * pieces * VNg + 2;
-        auto need_of = [&](unsigned tb) {
-          const size_t w = tb / 64;
-          return fixed + w * 64 * 4 + ((w * 64 * qs_e * sizeof(T) + 15) & ~(size_t)15) + w * 64 * lanes * sizeof(T);
-        };
-        static const int tb_env = ShortKnobs::env("NDI_STAGED2D_TB", 0);
-        unsigned tb = (tb_env == 64 || tb_env == 128 || tb_env == 256) ? (unsigned)tb_env : 256u;
-        if (need_of(tb) > FUSED_LDS_LIMIT) tb = 128u;
-        if (px.dense_ok && py.dense_ok && need_of(tb) <= FUSED_LDS_LIMIT) {
-          P.kind = Plan2::STAGED2;
-          P.f_tb = tb;
-          P.f_lds = need_of(tb);
-          const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
+          P.f_lds_wide = wide_fits;
+          static const int swg_env = ShortKnobs::env("NDI_SLOPES2D_WG", 0);   // workgroups per CU (0: what fits)
+          size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
+          if (swg_env > 0) wg_per_cu = (size_t)swg_env;
           P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + P.f_tb - 1) / P.f_tb, (uint64_t)cu_count() * wg_per_cu));
           g_last_path.store(NDI_PATH_GATHER);
           P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
@@ -3092,12 +3072,22 @@ struct Interp2DImpl final : Interp2DBase {
       launch1<T>(s, PC_EVAL, dim3(gs), dim3(BLOCK), shm, eval_small2d_kernel<T>, S);
       return;
     }
-    if (P.kind == Plan2::QUADS2) {
-      EvalQuads2Args<T> F{};
+    if (P.kind == Plan2::SLOPES2) {
+      EvalSlopes2Args<T> F{};
       F.xk = px.view.lv0; F.yk = py.view.lv0;
       F.nx = (uint32_t)nx; F.ny = (uint32_t)ny;
       F.dx = px.dlut; F.dy = py.dlut;
-      F.quads = quads.as<T>();
+      F.recs = slopes.as<T>();
+#ifdef NDI_TUNING
+      F.debug = ShortKnobs::env("NDI_SLOPES2D_DEBUG", 0);
+#endif
+      if (slopes_cells()) {
+        F.col_bytes = (uint32_t)slopes_cell_stride_bytes();
+        F.row_bytes = (uint32_t)((ny - 1) * slopes_cell_stride_bytes());
+      } else {
+        F.col_bytes = (uint32_t)(2 * lanes * sizeof(T));
+        F.row_bytes = (uint32_t)(ny * 2 * lanes * sizeof(T));
+      }
       F.qx = P.qx; F.qy = P.qy;
       F.out = P.out;
       F.nq = nq;
@@ -3107,19 +3097,40 @@ struct Interp2DImpl final : Interp2DBase {
       F.first_fail = &st->first_fail[0];
       F.check = P.l_check ? 1 : 0;
       if (std::getenv("NDI_TRACE_PLAN"))
-        std::fprintf(stderr, "[ndi plan] quads2d L=%llu tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes, P.f_tb, P.f_grid,
-                     P.f_lds, P.l_check ? 0 : 1);
-#define NDI_Q2(TBS)                                                                       \
+        std::fprintf(stderr, "[ndi plan] slopes2d L=%llu recs=%s tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes,
+                     slopes_cells() ? "cell" : "point", P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
+      static const bool tune_live6 = std::getenv("NDI_TUNE_LIVE") != nullptr;
+      static const int wide_once = ShortKnobs::env("NDI_SLOPES2D_WIDE", 1);     // A/B: 0 = direct stores of one value per lane
+      const int wide_env = tune_live6 ? ShortKnobs::env("NDI_SLOPES2D_WIDE", 1) : wide_once;
+      const int contig = P.out_stride != lanes ? 0 : (wide_env && aligned16(P.out) && P.f_lds_wide) ? 2 : 1;
+      const int mk = (int)std::max(px.dlut.lut ? px.dlut.maxk : 0u, py.dlut.lut ? py.dlut.maxk : 0u) <= 4 ? 4 : 8;
+#define NDI_SL2K(LCS, MKS, CT)                                                            \
   do {                                                                                    \
-    auto kern = eval_quads2d_kernel<T, TBS>;                                              \
+    auto kern = eval_slopes2d_kernel<T, LCS, MKS, CT, 256>;                               \
     allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);         \
-    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(TBS), P.f_lds, kern, F);                  \
+    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(256), P.f_lds, kern, F);                  \
   } while (0)
-      if (P.f_tb == 512) NDI_Q2(512); else if (P.f_tb == 128) NDI_Q2(128); else if (P.f_tb == 64) NDI_Q2(64); else NDI_Q2(256);
-#undef NDI_Q2
+#define NDI_SL2(LCS)                                                                      \
+  case LCS:                                                                               \
+    if (mk == 4) { if (contig == 2) NDI_SL2K(LCS, 4, 2); else if (contig) NDI_SL2K(LCS, 4, 1); else NDI_SL2K(LCS, 4, 0); }    \
+    else { if (contig == 2) NDI_SL2K(LCS, 8, 2); else if (contig) NDI_SL2K(LCS, 8, 1); else NDI_SL2K(LCS, 8, 0); }            \
+    break
+      switch ((int)lanes) {
+        NDI_SL2(1); NDI_SL2(2); NDI_SL2(3); NDI_SL2(4); NDI_SL2(5); NDI_SL2(6); NDI_SL2(7); NDI_SL2(8);
+        default:
+          if constexpr (sizeof(T) == 4) {
+            switch ((int)lanes) {
+              NDI_SL2(9); NDI_SL2(10); NDI_SL2(11); NDI_SL2(12); NDI_SL2(13); NDI_SL2(14); NDI_SL2(15); NDI_SL2(16);
+              default: break;
+            }
+          }
+          break;
+      }
+#undef NDI_SL2K
+#undef NDI_SL2
       return;
     }
-    if (P.kind == Plan2::LANES2 || P.kind == Plan2::STAGED2) {
+    if (P.kind == Plan2::LANES2) {
       EvalLanes2Args<T> F{};
       F.xk = px.view.lv0; F.yk = py.view.lv0;
       F.nx = (uint32_t)nx; F.ny = (uint32_t)ny;
@@ -3133,22 +3144,6 @@ struct Interp2DImpl final : Interp2DBase {
       F.mode = mode;
       F.first_fail = &st->first_fail[0];
       F.check = P.l_check ? 1 : 0;
-      F.row_cells = (uint32_t)(pair_packed ? ny - 1 : ny);
-      F.cell_elems = (uint32_t)(pair_packed ? 2 * lanes : lanes);
-      if (P.kind == Plan2::STAGED2) {
-        if (std::getenv("NDI_TRACE_PLAN"))
-          std::fprintf(stderr, "[ndi plan] staged2d L=%llu packed=%d tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes,
-                       (int)pair_packed, P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
-#define NDI_S2(TBS)                                                                       \
-  do {                                                                                    \
-    auto kern = eval_staged2d_kernel<T, TBS>;                                             \
-    allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)FUSED_LDS_LIMIT);         \
-    launch1<T>(s, PC_EVAL, dim3(P.f_grid), dim3(TBS), P.f_lds, kern, F);                  \
-  } while (0)
-        if (P.f_tb == 256) NDI_S2(256); else if (P.f_tb == 64) NDI_S2(64); else NDI_S2(128);
-#undef NDI_S2
-        return;
-      }
       if (std::getenv("NDI_TRACE_PLAN"))
         std::fprintf(stderr, "[ndi plan] lanes2d L=%llu qpl=%d maxk=%u,%u tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes,
                      P.l_qpl, px.dlut.maxk, py.dlut.maxk, P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
@@ -3818,7 +3813,7 @@ static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
   h->pair_packed = d.lanes * sizeof(T) <= 64 && d.ny >= 2 && (pack_env > 0 || (pack_env < 0 && bytes > FUSED_LDS_LIMIT));
   if (h->pair_packed) {
     const size_t packed = (size_t)d.nx * (d.ny - 1) * 2 * d.lanes * sizeof(T);
-    h->data.reserve(packed + 16);   // (+16: eval_staged2d_kernel's last 16-byte piece may read past the values)
+    h->data.reserve(packed);
     const void* src = d.data;
     DevBuf tmp;
     if (d.memspace != NDI_MEM_DEVICE) {
@@ -3845,7 +3840,7 @@ static ndi_status create2d(const ndi_interp2d_desc& d, Interp2DBase** out) {
     NDI_HIP(hipGetLastError());
     NDI_HIP(hipDeviceSynchronize());
   } else {
-    h->data.reserve(bytes + 16);    // (+16: see above)
+    h->data.reserve(bytes);
     NDI_HIP(hipMemcpy(h->data.p, d.data, bytes, kind));
   }
   *out = h.release();

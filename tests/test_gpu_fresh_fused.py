@@ -106,7 +106,7 @@ def test_fused_2d_interp_array_skips_the_prepass(pkg, capfd, dt, C):
     qx = rng.uniform(x[0], x[-1], Q).astype(dt); qy = rng.uniform(y[0], y[-1], Q).astype(dt)
     ref = oracle.interp2d_bilinear(x, y, g, qx, qy)[3].reshape(Q, C)
     it = pkg.Interp2DBuilder.new(torch.as_tensor(g, device=dev)).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
-    env = dict(NDI_STAGED2D_KERNEL="0", NDI_LANES2D_KERNEL="0")
+    env = dict(NDI_SLOPES2D_KERNEL="0", NDI_LANES2D_KERNEL="0")
     with traced(capfd, **env) as t:
         got = it.interp_array(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev))
         out = torch.full((Q, C), -2.0, dtype=_tdt(dt), device=dev)

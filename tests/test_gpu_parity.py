@@ -1161,8 +1161,8 @@ def test_bilinear_small_channels_device_buffers(pkg, dt, C, capfd):
             finally:
                 del os.environ["NDI_TRACE_PLAN"]
             err = capfd.readouterr().err
-            # (f32 rows of up to 32 bytes / f64 pairs on grids beyond LDS: the cell-quad kernel, eval_quads2d_kernel)
-            took_query_order = "[ndi plan] fused2d" in err or "[ndi plan] staged2d" in err or "[ndi plan] quads2d" in err
+            # (rows of up to 64 bytes on grids beyond LDS: the slope-record kernel, eval_slopes2d_kernel)
+            took_query_order = "[ndi plan] fused2d" in err or "[ndi plan] slopes2d" in err
             # the query-order kernel from 65 536 queries (1-2 values per point: from 524 288), else the two-kernel / one-thread forms
             assert took_query_order == (Q >= (524_288 if C <= 2 else 65_536)), (nx, ny, C, Q)
             check_equal(out.cpu().numpy(), ref.reshape(Q, C), f"2-D small rows {nx}x{ny}x{C} Q={Q} ext={ext}")

@@ -1,11 +1,12 @@
-"""GPU parity of eval_quads2d_kernel (round 5): short rows on small / medium grids through the CELL-QUAD copy of the grid
-(quad_pack_kernel: the four corners of a cell and channel next to each other, one contiguous record per query read by
-neighbouring lanes) -- the reference's 100 x 100 x 5 bench grid (benches/bench_interp2d.rs:87-92) -- against the CPU oracle, bit for bit, through the C ABI.
-Bilinear = bilinear.rs:64-99.  The kernel is forced with NDI_QUADS2D_KERNEL=1 (conftest sets NDI_TUNE_LIVE: the knob is
-read per call; NDI_LANES2D_KERNEL=0 keeps the LDS-resident-grid kernel from taking the small grids first) and the plan
-line is asserted.  Covered: both element types, both grid layouts (plain: grids under 160 KB; pair-packed: above), rows of
-16 to 128 bytes whose corner pairs are / are not whole 16-byte pieces, ragged batches, strided output, extrapolation, the
-first-error cut (x before y), interp_array's own range test (no pre-pass), and what AUTO takes on the bench shape."""
+"""GPU parity of eval_slopes2d_kernel (round 6): short rows on grids that do not fit LDS through the SLOPE-RECORD copy of the
+grid (slope_pack_kernel: {z, m = (z[xi+1] - z[xi]) / (x[xi+1] - x[xi])} per grid point -- linear.rs:33's division done once per
+grid point, so a query costs one division per value instead of three and reads one contiguous run of 4 L values) -- the
+reference's 100 x 100 x 5 bench grid (benches/bench_interp2d.rs:87-92) -- against the CPU oracle, bit for bit, through the
+C ABI.  Bilinear = bilinear.rs:64-99.  The kernel is forced with NDI_SLOPES2D_KERNEL=1 (conftest sets NDI_TUNE_LIVE: the knob
+is read per call; NDI_LANES2D_KERNEL=0 keeps the LDS-resident-grid kernel from taking the small grids first) and the plan
+line is asserted.  Covered: both element types, both source layouts of the grid (plain: grids under 160 KB; pair-packed:
+above), 1 to 8 (f64) / 16 (f32) values per grid point, odd counts included, ragged batches, strided output, extrapolation,
+the first-error cut (x before y), interp_array's own range test (no pre-pass), and what AUTO takes on the bench shape."""
 import os
 
 import numpy as np
@@ -22,14 +23,14 @@ class forced:
         self.capfd, self.value = capfd, value
 
     def __enter__(self):
-        os.environ["NDI_QUADS2D_KERNEL"] = self.value
+        os.environ["NDI_SLOPES2D_KERNEL"] = self.value
         os.environ["NDI_LANES2D_KERNEL"] = "0"
         os.environ["NDI_TRACE_PLAN"] = "1"
         self.capfd.readouterr()
         return self
 
     def __exit__(self, *a):
-        for k in ("NDI_QUADS2D_KERNEL", "NDI_LANES2D_KERNEL", "NDI_TRACE_PLAN"):
+        for k in ("NDI_SLOPES2D_KERNEL", "NDI_LANES2D_KERNEL", "NDI_TRACE_PLAN"):
             os.environ.pop(k, None)
         self.plans = [ln for ln in self.capfd.readouterr().err.splitlines() if ln.startswith("[ndi plan]")]
 
@@ -40,16 +41,17 @@ def _tdt(dt):
 
 
 SHAPES = [("rand", "rand", 100, 100, 5), ("rand", "jit", 40, 57, 5), ("lin", "lin", 64, 64, 8), ("log", "rand", 17, 300, 2),
-          ("rand", "rand", 2, 2, 4), ("rand", "lin", 130, 97, 7), ("rand", "rand", 33, 41, 6), ("rand", "rand", 3, 90, 3)]
+          ("rand", "rand", 2, 2, 4), ("rand", "lin", 130, 97, 7), ("rand", "rand", 33, 41, 6), ("rand", "rand", 3, 90, 3),
+          ("rand", "rand", 150, 160, 1), ("rand", "log", 210, 120, 7)]
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("kx,ky,nx,ny,C", SHAPES)
-def test_quads_2d_bit_exact(pkg, capfd, dt, kx, ky, nx, ny, C):
+def test_slopes_2d_bit_exact(pkg, capfd, dt, kx, ky, nx, ny, C):
     import torch
     dev = torch.device("cuda:0")
     if dt == np.float32:
-        C = {5: 5, 8: 12, 2: 16, 4: 4, 7: 9, 6: 13, 3: 3}[C]      # 12 .. 64-byte rows
+        C = {5: 5, 8: 12, 2: 16, 4: 4, 7: 9 if nx == 130 else 15, 6: 13, 3: 3, 1: 1}[C]      # 4 .. 64-byte rows
     rng = np.random.default_rng(nx * 13 + ny * 7 + C)
     Q = 70_003
     x = knots(kx, nx, rng, dt) if nx > 2 else np.asarray([0.25, 1.5], dtype=dt)
@@ -69,9 +71,9 @@ def test_quads_2d_bit_exact(pkg, capfd, dt, kx, ky, nx, ny, C):
         qxo.copy_(qxd)
         wide = torch.full((Q, C + 2), -9.0, dtype=_tdt(dt), device=dev)
         it.strategy.interp_array_into(it, qxo, qyd, wide[:, :C])
-    assert len(f.plans) == 2 and all(" quads2d L=" in p for p in f.plans), f.plans
-    check_equal(out.cpu().numpy(), ref, f"quads2d {nx}x{ny}x{C}")
-    check_equal(wide[:, :C].cpu().numpy(), ref, f"quads2d strided {nx}x{ny}x{C}")
+    assert len(f.plans) == 2 and all(" slopes2d L=" in p for p in f.plans), f.plans
+    check_equal(out.cpu().numpy(), ref, f"slopes2d {nx}x{ny}x{C}")
+    check_equal(wide[:, :C].cpu().numpy(), ref, f"slopes2d strided {nx}x{ny}x{C}")
     assert bool((wide[:, C:] == -9.0).all())
     # extrapolation
     ex = pkg.Interp2DBuilder.new(torch.as_tensor(g, device=dev)).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)) \
@@ -80,15 +82,15 @@ def test_quads_2d_bit_exact(pkg, capfd, dt, kx, ky, nx, ny, C):
     qx2 = rng.uniform(x[0] - sx, x[-1] + sx, Q).astype(dt); qy2 = rng.uniform(y[0] - sy, y[-1] + sy, Q).astype(dt)
     with forced(capfd) as f:
         got2 = ex.interp_array(torch.as_tensor(qx2, device=dev), torch.as_tensor(qy2, device=dev)).cpu().numpy()
-    assert " quads2d L=" in f.plans[0], f.plans
-    check_equal(got2.reshape(Q, C), oracle.interp2d_bilinear(x, y, g, qx2, qy2, True)[3].reshape(Q, C), "quads2d extrapolate")
+    assert " slopes2d L=" in f.plans[0], f.plans
+    check_equal(got2.reshape(Q, C), oracle.interp2d_bilinear(x, y, g, qx2, qy2, True)[3].reshape(Q, C), "slopes2d extrapolate")
     # the first-error cut (x before y for the same query: bilinear.rs:71-80)
     qy[31_000] = y[-1] + 1; qx[31_000] = x[0] - 1; qx[35_000] = x[0] - 1
     buf = torch.full((Q, C), -3.0, dtype=_tdt(dt), device=dev)
     with forced(capfd) as f:
         with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
             it.interp_array_into(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), buf)
-    assert (ei.value.index, ei.value.axis) == (31_000, 0) and " quads2d L=" in f.plans[0], f.plans
+    assert (ei.value.index, ei.value.axis) == (31_000, 0) and " slopes2d L=" in f.plans[0], f.plans
     got = buf.cpu().numpy()
     assert np.array_equal(got[:31_000], ref[:31_000]) and np.all(got[31_000:] == -3.0)
     with forced(capfd) as f:
@@ -103,7 +105,7 @@ def test_quads_2d_bit_exact(pkg, capfd, dt, kx, ky, nx, ny, C):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
-def test_quads_2d_auto_takes_the_bench_shape(pkg, capfd, dt):
+def test_slopes_2d_auto_takes_the_bench_shape(pkg, capfd, dt):
     import torch
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(9)
@@ -120,8 +122,7 @@ def test_quads_2d_auto_takes_the_bench_shape(pkg, capfd, dt):
     finally:
         os.environ.pop("NDI_TRACE_PLAN", None)
     plans = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("[ndi plan]")]
-    # AUTO takes the quad kernel where it was measured ahead (f32 rows of up to 32 bytes; f64 pairs); f64 x 5 stays query-order
-    assert any((" quads2d L=5 " if dt == np.float32 else " fused2d ") in p for p in plans), plans
+    assert any(" slopes2d L=5 " in p for p in plans), plans
     sel = rng.choice(Q, 50_000, replace=False)
     ref = oracle.interp2d_bilinear(x, y, g, qx.cpu().numpy()[sel], qy.cpu().numpy()[sel])[3].reshape(-1, 5)
-    check_equal(got.reshape(Q, 5)[sel], ref, "quads2d auto 100x100x5")
+    check_equal(got.reshape(Q, 5)[sel], ref, "slopes2d auto 100x100x5")

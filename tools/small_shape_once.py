@@ -43,6 +43,11 @@ else:
     it = pkg.Interp2DBuilder.new(grid).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
     qx = torch.rand(Q, dtype=tdt, device=dev) * float(x[-1] - x[0]) * 0.999 + float(x[0])
     qy = torch.rand(Q, dtype=tdt, device=dev) * float(y[-1] - y[0]) * 0.999 + float(y[0])
+    qmode = os.environ.get("QMODE", "")       # experiments: const = every query in one cell (L1 hits), sorted = by x
+    if qmode == "const":
+        qx = qx * 0 + float(x[nx // 2] + 0.3 * (x[nx // 2 + 1] - x[nx // 2])); qy = qy * 0 + float(y[ny // 3] + 0.6 * (y[ny // 3 + 1] - y[ny // 3]))
+    elif qmode == "sorted":
+        qx, _ = torch.sort(qx)
     out = torch.empty((Q, C), dtype=tdt, device=dev)
     call = lambda: it.strategy.interp_array_into(it, qx, qy, out, async_launch=True, fresh=fresh)
 call()

@@ -549,10 +549,11 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
         runs = [time_into(o) for o in bufs]
         del bufs
         torch.cuda.empty_cache()
-        owned = []
+        owned, owned_info = [], []
         if hasattr(pkg, "output_empty"):          # library-owned outputs, one after the other (each freed before the next)
             for _ in range(3):
                 o = pkg.output_empty((nq, lanes), dt, dev.index)
+                owned_info.append(o.ndi_output_info)
                 owned.append(time_into(o))
                 del o
         kms, wall, prof = runs[0]                  # the FIRST allocation, no selection
@@ -572,6 +573,7 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
                     "frac_per_output_buffer": [frac_of(r[0]) for r in runs],
                     "kernel_ms_library_owned_outputs": [round(r[0], 4) for r in owned],
                     "frac_library_owned_outputs": [frac_of(r[0]) for r in owned],
+                    "library_owned_info": owned_info,
                     "Mpoints_s": round(nq * lanes / wall / 1e6, 1),
                     "compulsory_bytes_per_launch": int(comp), "frac": frac_of(kms),
                     "bytes_basis": "compulsory bytes per launch (output + tables + query records, once)",

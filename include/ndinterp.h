@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define NDI_VERSION_MAJOR 0
-#define NDI_VERSION_MINOR 4
+#define NDI_VERSION_MINOR 5
 
 /* BuilderError / InterpolateError (src/lib.rs:127-146) + ABI-only codes. */
 typedef enum ndi_status {
@@ -186,7 +186,17 @@ typedef struct ndi_eval_opts {
  * always.  Without the flag (interp_array_into semantics: a caller-owned buffer) rows at / after the first failing query
  * are left untouched, as the reference's serial loop leaves them (:334-342) -- which costs the short-row kernels a
  * pre-pass over the queries (8-16 bytes per query, a quarter of the time of a scalar batch). */
-typedef enum ndi_eval_flags { NDI_EVAL_DEFAULT = 0, NDI_EVAL_FRESH_OUTPUT = 1 } ndi_eval_flags;
+/* NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED (v0.5): an interp_array_into caller's opt-in to the same kernels on a buffer it
+ * OWNS -- if the call fails, rows at / after the first failing query hold unspecified values (rows before it are the
+ * reference's, the failure report is unchanged).  The reference leaves those rows untouched (:334-342); a caller that
+ * discards or overwrites the buffer on Err anyway gets the pre-pass back: scalar f64 data 200 -> 280 Gqueries/s.
+ * Unknown flag bits and a non-zero `reserved` are refused with NDI_BAD_ARG (v0.5): a binary built against an older,
+ * shorter ndi_eval_opts cannot silently select an option. */
+typedef enum ndi_eval_flags {
+  NDI_EVAL_DEFAULT = 0,
+  NDI_EVAL_FRESH_OUTPUT = 1,
+  NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED = 2
+} ndi_eval_flags;
 
 /* ---- build ------------------------------------------------------------------ */
 ndi_status ndi_interp1d_create(const ndi_interp1d_desc* desc, ndi_interp1d** out);
@@ -374,6 +384,25 @@ ndi_status ndi_validate1d(int32_t dtype, const void* host_x, uint64_t x_len, uin
                           int32_t strategy);
 ndi_status ndi_validate2d(int32_t dtype, const void* host_x, uint64_t x_len, const void* host_y,
                           uint64_t y_len, uint64_t nx, uint64_t ny);
+
+/* ---- library-owned output buffers ---------------------------------------------------------------------------
+ * Replaces the `Array::zeros(..)` of Interp1D::interp_array / Interp2D::interp_array (src/interp1d/mod.rs:204-209,
+ * src/interp2d/mod.rs:183-188): a device buffer of `bytes` zero bytes for a batch's output rows.  On MI355X the rate at
+ * which rows stream into a multi-gigabyte buffer depends on the physical pages behind it (4.6 .. 6.1 ms per 1e6 queries of
+ * BASELINE configs[1] into buffers allocated one after the other; a property of the buffer, not of order or warm-up), so
+ * the zero fill is timed and a slowly filling buffer is set aside for another candidate, up to `max_tries` (0 = as many as
+ * fit into half of the free memory, 2 .. 8; buffers under 1 GiB: 1), while the device has room; the best candidate is returned, the others are freed.  `info` (may be NULL)
+ * reports what happened.  Free with ndi_output_free (NDI_BAD_ARG for any other pointer).  The mirrors' interp_array uses
+ * it for device outputs of >= 1 GiB; interp_array_into never allocates. */
+typedef struct ndi_output_info {
+  uint32_t tries;          /* candidates allocated and filled */
+  uint32_t reserved;
+  double fill_tbps;        /* zero-fill rate of the buffer returned, TB/s */
+  double worst_fill_tbps;  /* ... of the slowest candidate seen */
+  double alloc_ms;         /* wall time of the whole call */
+} ndi_output_info;
+ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max_tries, void** out, ndi_output_info* info);
+ndi_status ndi_output_free(void* p);
 
 /* ---- runtime ------------------------------------------------------------------ */
 int32_t ndi_device_count(void);

@@ -79,3 +79,47 @@ def striped_ring(chunk_queries: int, lanes: int, n_slots: int, dtype=np.float64,
     tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[np.dtype(dtype)]
     base = torch.empty((chunk_queries, n_slots, lanes), dtype=tdt, device=f"cuda:{device}")
     return [base[:, s, :] for s in range(n_slots)]
+
+
+class _OwnedOutput:
+    """A buffer from ndi_output_alloc exposed through __cuda_array_interface__: torch.as_tensor() wraps it without a copy
+    and keeps this object alive; the buffer goes back with ndi_output_free when the last tensor over it is gone."""
+
+    def __init__(self, shape, dtype, device, max_tries=0):
+        import ctypes
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.device = int(device)
+        nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        ptr = ctypes.c_void_p()
+        self.info = _capi.OutputInfo()
+        st = _capi.lib().ndi_output_alloc(self.device, nbytes, int(max_tries), ctypes.byref(ptr), ctypes.byref(self.info))
+        if st != _capi.OK:
+            from .errors import DeviceError
+            raise DeviceError(_capi.last_error())
+        self.ptr = ptr.value
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False),
+                                         "version": 2, "strides": None}
+
+    def __del__(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p:
+            try:
+                _capi.lib().ndi_output_free(p)
+            except Exception:   # interpreter shutdown
+                pass
+
+
+OUTPUT_OWNED_MIN_BYTES = 1 << 30
+
+
+def output_empty(shape, dtype=np.float64, device: int = 0, max_tries: int = 0):
+    """A library-owned device output buffer (ndi_output_alloc: the reference's Array::zeros, interp1d/mod.rs:209, with the
+    placement check of include/ndinterp.h) as a torch tensor of `shape`.  `tensor.ndi_output_info` tells how many candidates
+    were tried and the fill rate of the one kept."""
+    own = _OwnedOutput(shape, dtype, device, max_tries)
+    with torch.cuda.device(device):
+        t = torch.as_tensor(own, device=f"cuda:{device}")
+    t.ndi_output_info = {"tries": own.info.tries, "fill_TBps": round(own.info.fill_tbps, 3),
+                         "worst_fill_TBps": round(own.info.worst_fill_tbps, 3), "alloc_ms": round(own.info.alloc_ms, 2)}
+    return t

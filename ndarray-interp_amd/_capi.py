@@ -24,7 +24,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 LINEAR, CUBIC_SPLINE = 0, 1
 BC_NOT_A_KNOT, BC_NATURAL, BC_CLAMPED, BC_FIRST_DERIV, BC_SECOND_DERIV = range(5)
 BUILD_DEFAULT, BUILD_REFERENCE_ORDER = 0, 1
-EVAL_DEFAULT, EVAL_FRESH_OUTPUT = 0, 1
+EVAL_DEFAULT, EVAL_FRESH_OUTPUT, EVAL_ROWS_AFTER_ERROR_UNSPECIFIED = 0, 1, 2
 PATH_AUTO, PATH_GATHER, PATH_BUCKETED = 0, 1, 2
 PATH_NAMES = {0: "auto", 1: "gather", 2: "bucketed"}
 
@@ -68,6 +68,11 @@ class Profile(C.Structure):
                 ("locate_launches", C.c_uint64), ("locate_ms", C.c_double),
                 ("group_launches", C.c_uint64), ("group_ms", C.c_double),
                 ("last_path", C.c_int32), ("reserved", C.c_int32)]
+
+
+class OutputInfo(C.Structure):
+    _fields_ = [("tries", C.c_uint32), ("reserved", C.c_uint32), ("fill_tbps", C.c_double),
+                ("worst_fill_tbps", C.c_double), ("alloc_ms", C.c_double)]
 
 
 class RingChunk(C.Structure):
@@ -125,6 +130,8 @@ SYMBOLS = {
     "ndi_monotonic_prop": (C.c_int32, [C.c_int32, _P, C.c_uint64]),
     "ndi_validate1d": (C.c_int, [C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_int32]),
     "ndi_validate2d": (C.c_int, [C.c_int32, _P, C.c_uint64, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "ndi_output_alloc": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(_P), C.POINTER(OutputInfo)]),
+    "ndi_output_free": (C.c_int, [_P]),
     "ndi_device_count": (C.c_int32, []),
     "ndi_last_error_string": (C.c_char_p, []),
     "ndi_version": (C.c_uint32, []),

@@ -4102,6 +4102,14 @@ __global__ __launch_bounds__(TB) void eval_slopes2d_kernel(EvalSlopes2Args<T> A)
   }
 }
 
+// ndi_output_alloc: Array::zeros (interp1d/mod.rs:209) -- the buffer is filled with zeros by 16-byte non-temporal stores; the
+// duration of this very fill is the allocator's measure of where the buffer landed in physical memory.
+__global__ __launch_bounds__(BLOCK) void zero_fill_kernel(dbl2* p, uint64_t nvec) {
+  const dbl2 z = {0.0, 0.0};
+  for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * BLOCK)
+    __builtin_nontemporal_store(z, p + i);
+}
+
 // Measurement aid (ndi_interp2d_probe_ceiling): the memory access mix of eval_bilinear_kernel and nothing else --
 // per item one pre-generated uniformly random cell, the four corner vectors from the handle's own grid with the
 // kernel's lane mapping, a token amount of arithmetic, the output vector stored -- no searches, no knots, no query

@@ -20,6 +20,7 @@
 #include <set>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -758,6 +759,20 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 //                    0 = never, 1 = always
 //   NDI_FUSED_MAXLV  the gather formulation of rows of fewer than this many 16-byte vectors is the fused kernel
 //                    (longer rows: locate_kernel + eval_rows_kernel)
+// ndi_eval_opts as the entry points take it: defaults for NULL, unknown flag bits and a non-zero `reserved` refused (a
+// caller compiled against an older header -- a shorter struct, uninitialised padding -- is told so instead of silently
+// selecting an option), and NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED folded into the internal "no range pre-pass" bit.
+static ndi_status take_opts(const ndi_eval_opts* opts, ndi_eval_opts& o) {
+  o = ndi_eval_opts{};
+  if (!opts) return NDI_OK;
+  o = *opts;
+  constexpr int32_t KNOWN = NDI_EVAL_FRESH_OUTPUT | NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED;
+  if (o.flags & ~KNOWN) return fail(NDI_BAD_ARG, "ndi_eval_opts.flags has unknown bits (0x%x): built against another header version?", (unsigned)o.flags);
+  if (o.reserved != 0) return fail(NDI_BAD_ARG, "ndi_eval_opts.reserved must be 0 (got %d): built against another header version?", (int)o.reserved);
+  if (o.flags & NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED) o.flags |= NDI_EVAL_FRESH_OUTPUT;
+  return NDI_OK;
+}
+
 struct ShortKnobs {
   int mode = 0, unr = 2, tb = 0, lds = -1, wgs = 0, cq = 64, rowb = 1024, pack = -1, maxlv = 256;
   static int env(const char* name, int dflt) {
@@ -2222,7 +2237,7 @@ struct Interp1DImpl final : Interp1DBase {
     DeviceGuard dg(device);
     Range rg("ndi_interp1d_eval");
     ndi_eval_opts o{};
-    if (opts) o = *opts;
+    if (const ndi_status vs__ = take_opts(opts, o); vs__ != NDI_OK) return vs__;
     hipStream_t s = (hipStream_t)o.stream;  // NULL = the HIP default stream
     if (out_stride < lanes) return fail(NDI_BAD_ARG, "out_row_stride (%llu) < lanes (%llu)",
                                         (unsigned long long)out_stride, (unsigned long long)lanes);
@@ -2329,7 +2344,7 @@ struct Interp1DImpl final : Interp1DBase {
                        void* user, const ndi_eval_opts* opts, ndi_oob_info* info) override {
     DeviceGuard dg(device);
     ndi_eval_opts o{};
-    if (opts) o = *opts;
+    if (const ndi_status vs__ = take_opts(opts, o); vs__ != NDI_OK) return vs__;
     hipStream_t s = (hipStream_t)o.stream;
     uint64_t stride = 0;
     ndi_status rs = check_ring_desc(ring, lanes, &stride);
@@ -3591,7 +3606,7 @@ struct Interp2DImpl final : Interp2DBase {
     DeviceGuard dg(device);
     Range rg("ndi_interp2d_eval");
     ndi_eval_opts o{};
-    if (opts) o = *opts;
+    if (const ndi_status vs__ = take_opts(opts, o); vs__ != NDI_OK) return vs__;
     hipStream_t s = (hipStream_t)o.stream;  // NULL = the HIP default stream
     if (out_stride < lanes) return fail(NDI_BAD_ARG, "out_row_stride (%llu) < lanes (%llu)",
                                         (unsigned long long)out_stride, (unsigned long long)lanes);
@@ -3693,7 +3708,7 @@ struct Interp2DImpl final : Interp2DBase {
                        ndi_oob_info* info) override {
     DeviceGuard dg(device);
     ndi_eval_opts o{};
-    if (opts) o = *opts;
+    if (const ndi_status vs__ = take_opts(opts, o); vs__ != NDI_OK) return vs__;
     hipStream_t s = (hipStream_t)o.stream;
     uint64_t stride = 0;
     ndi_status rs = check_ring_desc(ring, lanes, &stride);
@@ -4587,7 +4602,7 @@ NDI_API ndi_status ndi_interp1d_eval_sharded(const ndi_interp1d* const* handles,
   ndi::Range rg("ndi_interp1d_eval_sharded");
   const int dtype = handles[0]->impl->dtype;
   ndi_eval_opts o{};
-  if (opts) o = *opts;
+  if (const ndi_status vs__ = ndi::take_opts(opts, o); vs__ != NDI_OK) return vs__;
   if (dtype == NDI_F32) {
     ndi::Job1<float> J{{}, q, nq, io, out_row_stride, nullptr, nullptr, nullptr, o};
     st = gather_handles(handles, n_shards, dtype, J.H);
@@ -4609,7 +4624,7 @@ NDI_API ndi_status ndi_interp1d_eval_ring_sharded(const ndi_interp1d* const* han
   ndi::Range rg("ndi_interp1d_eval_ring_sharded");
   const int dtype = handles[0]->impl->dtype;
   ndi_eval_opts o{};
-  if (opts) o = *opts;
+  if (const ndi_status vs__ = ndi::take_opts(opts, o); vs__ != NDI_OK) return vs__;
   if (dtype == NDI_F32) {
     ndi::Job1<float> J{{}, q, nq, io, 0, rings, consume, user, o};
     st = gather_handles(handles, n_shards, dtype, J.H);
@@ -4631,7 +4646,7 @@ NDI_API ndi_status ndi_interp2d_eval_sharded(const ndi_interp2d* const* handles,
   ndi::Range rg("ndi_interp2d_eval_sharded");
   const int dtype = handles[0]->impl->dtype;
   ndi_eval_opts o{};
-  if (opts) o = *opts;
+  if (const ndi_status vs__ = ndi::take_opts(opts, o); vs__ != NDI_OK) return vs__;
   if (dtype == NDI_F32) {
     ndi::Job2<float> J{{}, qx, qy, nq, io, out_row_stride, nullptr, nullptr, nullptr, o};
     st = gather_handles(handles, n_shards, dtype, J.H);
@@ -4654,7 +4669,7 @@ NDI_API ndi_status ndi_interp2d_eval_ring_sharded(const ndi_interp2d* const* han
   ndi::Range rg("ndi_interp2d_eval_ring_sharded");
   const int dtype = handles[0]->impl->dtype;
   ndi_eval_opts o{};
-  if (opts) o = *opts;
+  if (const ndi_status vs__ = ndi::take_opts(opts, o); vs__ != NDI_OK) return vs__;
   if (dtype == NDI_F32) {
     ndi::Job2<float> J{{}, qx, qy, nq, io, 0, rings, consume, user, o};
     st = gather_handles(handles, n_shards, dtype, J.H);
@@ -4757,6 +4772,131 @@ NDI_API ndi_status ndi_validate2d(int32_t dtype, const void* host_x, uint64_t x_
   if (dtype == NDI_F64)
     return ndi::check_axes_2d<double>((const double*)host_x, x_len, (const double*)host_y, y_len, nx, ny);
   return ndi::fail(NDI_BAD_ARG, "unknown dtype");
+}
+
+// ---- library-owned output buffers -------------------------------------------------------------------------------
+// The rate at which a kernel streams rows into a multi-gigabyte buffer depends on which physical pages back it: the same
+// evaluation runs 4.6 .. 6.1 ms per 1e6 queries (C2) into buffers the allocator hands out one after the other, stable per
+// buffer whatever the order or the warm-up (profiles/r06_placement_vs_ramp.jsonl), and neither hipMemCreate chunks nor
+// chunks spread over the physical range change the odds (profiles/r06_output_alloc_probe*.jsonl).  What user space CAN do
+// is look: the zero fill Array::zeros performs anyway is timed, and a buffer that fills slowly is set aside and another
+// one is asked for while it is still held (so the allocator cannot hand the same pages back), up to `max_tries`; the
+// fastest-filling candidate is kept, the others are freed.  A sequential fill and the scattered row stream of the
+// evaluation run at the same rate into a given buffer (profiles/r03_tuning.md, "Output placement").
+namespace ndi {
+struct OutputRegistry {
+  std::mutex mu;
+  std::unordered_map<void*, std::pair<int, size_t>> live;   // ptr -> (device, bytes)
+};
+static OutputRegistry& output_registry() {
+  static OutputRegistry r;
+  return r;
+}
+static double timed_zero_fill(void* p, size_t bytes, hipEvent_t a, hipEvent_t b) {
+  const uint64_t nvec = bytes / 16;
+  const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nvec + BLOCK - 1) / BLOCK, (uint64_t)cu_count() * 32));
+  NDI_HIP(hipEventRecord(a, nullptr));
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(gr), dim3(BLOCK), 0, (hipStream_t) nullptr, (dbl2*)p, nvec);
+  NDI_HIP(hipGetLastError());
+  if (bytes % 16) NDI_HIP(hipMemsetAsync((char*)p + nvec * 16, 0, bytes % 16, nullptr));
+  NDI_HIP(hipEventRecord(b, nullptr));
+  NDI_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  NDI_HIP(hipEventElapsedTime(&ms, a, b));
+  return (double)ms;
+}
+}  // namespace ndi
+
+NDI_API ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max_tries, void** out, ndi_output_info* info) {
+  if (!out) return ndi::fail(NDI_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (info) *info = ndi_output_info{};
+  if (bytes == 0) return ndi::fail(NDI_BAD_ARG, "zero-sized output");
+  NDI_TRY
+  ndi::DeviceGuard dg(device);
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  static const double accept_tbs = [] { const char* e = std::getenv("NDI_OUTPUT_ACCEPT_TBPS"); return e ? std::atof(e) : 6.6; }();
+  static const int tries_env = ndi::ShortKnobs::env("NDI_OUTPUT_TRIES", 0);
+  uint32_t tries = max_tries;
+  if (tries == 0) {       // as many candidates as fit into about half of what is free, 2 .. 8
+    size_t fr = 0, tot = 0;
+    NDI_HIP(hipMemGetInfo(&fr, &tot));
+    tries = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(2, (uint64_t)(0.55 * (double)fr / (double)bytes)));
+  }
+  if (tries_env > 0) tries = (uint32_t)tries_env;
+  // small buffers: a fill this short says nothing about placement, and placement matters little to them
+  if (bytes < ((uint64_t)1 << 30)) tries = 1;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  NDI_HIP(hipEventCreate(&ea));
+  NDI_HIP(hipEventCreate(&eb));
+  struct Ev { hipEvent_t a, b; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{ea, eb};
+  std::vector<std::pair<void*, double>> cand;   // (pointer, TB/s of its zero fill)
+  auto free_all_but = [&](void* keep) {
+    for (auto& c : cand)
+      if (c.first != keep) (void)hipFree(c.first);
+  };
+  void* best = nullptr;
+  double best_rate = 0.0;
+  try {
+    for (uint32_t t = 0; t < tries; ++t) {
+      if (t > 0) {     // a further candidate only while the device has room for it beside what is held
+        size_t fr = 0, tot = 0;
+        NDI_HIP(hipMemGetInfo(&fr, &tot));
+        if (fr < bytes + ((size_t)2 << 30)) break;
+      }
+      void* p = nullptr;
+      const hipError_t me = hipMalloc(&p, bytes);
+      if (me != hipSuccess) {
+        (void)hipGetLastError();
+        if (cand.empty()) throw ndi::HipFailure{me, "hipMalloc(output buffer)", __LINE__};
+        break;
+      }
+      double ms = ndi::timed_zero_fill(p, bytes, ea, eb);
+      if (tries > 1 && t == 0) ms = ndi::timed_zero_fill(p, bytes, ea, eb);   // (the first fill of a process also pays clock ramp-up)
+      const double rate = (double)bytes / (ms * 1e-3) / 1e12;
+      cand.emplace_back(p, rate);
+      if (rate > best_rate) { best_rate = rate; best = p; }
+      if (rate >= accept_tbs) break;
+    }
+  } catch (...) {
+    free_all_but(nullptr);
+    throw;
+  }
+  free_all_but(best);
+  {
+    auto& R = ndi::output_registry();
+    std::lock_guard<std::mutex> g(R.mu);
+    R.live[best] = {device, (size_t)bytes};
+  }
+  if (info) {
+    info->tries = (uint32_t)cand.size();
+    info->fill_tbps = best_rate;
+    info->alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    info->worst_fill_tbps = best_rate;
+    for (auto& c : cand) info->worst_fill_tbps = std::min(info->worst_fill_tbps, c.second);
+  }
+  *out = best;
+  return NDI_OK;
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_output_free(void* p) {
+  if (!p) return NDI_OK;
+  NDI_TRY
+  int dev = -1;
+  {
+    auto& R = ndi::output_registry();
+    std::lock_guard<std::mutex> g(R.mu);
+    auto it = R.live.find(p);
+    if (it == R.live.end()) return ndi::fail(NDI_BAD_ARG, "pointer was not returned by ndi_output_alloc");
+    dev = it->second.first;
+    R.live.erase(it);
+  }
+  ndi::DeviceGuard dg(dev);
+  NDI_HIP(hipFree(p));
+  return NDI_OK;
+  NDI_CATCH
 }
 
 NDI_API int32_t ndi_device_count(void) {

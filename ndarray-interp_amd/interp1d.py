@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._arrays import Buf, current_stream_ptr, dtype_id, is_torch, np_dtype_of
+from ._arrays import OUTPUT_OWNED_MIN_BYTES, Buf, current_stream_ptr, dtype_id, is_torch, np_dtype_of, output_empty
 from .errors import BuilderError, InterpolateError, Panic, raise_builder, raise_eval
 from .vector_extensions import Monotonic, get_lower_index, monotonic_prop
 
@@ -128,7 +128,8 @@ class _DeviceStrategy1D(Interp1DStrategy):
     # -- evaluate -----------------------------------------------------------------------------
     _takes_fresh = True   # interp_array() may tell this strategy that the output buffer is its own (ndi_eval_flags)
 
-    def interp_array_into(self, interpolator, xs_flat, out2d, *, async_launch=False, fresh=False):
+    def interp_array_into(self, interpolator, xs_flat, out2d, *, async_launch=False, fresh=False,
+                          rows_after_error_unspecified=False):
         """Replaces the reference's query loop (interp1d/mod.rs:326-343) by one C-ABI call.  `fresh`: the buffer was
         allocated for this call and is dropped on Err (Interp1D::interp_array, :197-211) -- NDI_EVAL_FRESH_OUTPUT."""
         qb = Buf(xs_flat, self._np_dtype)
@@ -137,7 +138,10 @@ class _DeviceStrategy1D(Interp1DStrategy):
         opts.q_memspace = qb.memspace
         opts.path = self.path
         opts.async_launch = int(bool(async_launch))
-        opts.flags = _capi.EVAL_FRESH_OUTPUT if fresh else _capi.EVAL_DEFAULT
+        # rows_after_error_unspecified: a caller-owned buffer whose rows at / after a failing query the caller gives up
+        # (NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED; the reference leaves them untouched, interp1d/mod.rs:334-342)
+        opts.flags = (_capi.EVAL_FRESH_OUTPUT if fresh else _capi.EVAL_DEFAULT) | \
+            (_capi.EVAL_ROWS_AFTER_ERROR_UNSPECIFIED if rows_after_error_unspecified else 0)
         # an async batch reads the query array until finish(): keep every (possibly converted) copy alive
         if async_launch:
             self._inflight.append(qb)
@@ -539,7 +543,11 @@ class Interp1D:
                 np_dtype_of(self.data))
             if tdt is None:
                 raise TypeError("device query tensors need f32 / f64 data; other element types use host arrays")
-            ys = torch.empty(shape, dtype=tdt, device=xs.device)
+            nbytes = int(np.prod(shape, dtype=np.int64)) * np_dtype_of(self.data).itemsize
+            if nbytes >= OUTPUT_OWNED_MIN_BYTES:     # Array::zeros through the library's placement-checked allocator
+                ys = output_empty(shape, np_dtype_of(self.data), xs.device.index or 0)
+            else:
+                ys = torch.empty(shape, dtype=tdt, device=xs.device)
             # the reference hands back zeros for rows it never reached only on Err, where the buffer
             # is dropped anyway (:210); no memset of the output is needed
         else:

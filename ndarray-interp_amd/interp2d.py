@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._arrays import Buf, current_stream_ptr, dtype_id, is_torch, np_dtype_of
+from ._arrays import OUTPUT_OWNED_MIN_BYTES, Buf, current_stream_ptr, dtype_id, is_torch, np_dtype_of, output_empty
 from .errors import BuilderError, InterpolateError, Panic, raise_builder, raise_eval
 from .interp1d import _check_out_dtype, _default_device, _host, _to_device
 from .vector_extensions import Monotonic, get_lower_index, monotonic_prop
@@ -132,7 +132,8 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
 
     _takes_fresh = True   # see _DeviceStrategy1D
 
-    def interp_array_into(self, interpolator, xs_flat, ys_flat, out2d, *, async_launch=False, fresh=False):
+    def interp_array_into(self, interpolator, xs_flat, ys_flat, out2d, *, async_launch=False, fresh=False,
+                          rows_after_error_unspecified=False):
         """Replaces the reference's query loop (interp2d/mod.rs:287-307) by one C-ABI call.  `fresh`: the buffer was
         allocated for this call and is dropped on Err (Interp2D::interp_array, :175-196) -- NDI_EVAL_FRESH_OUTPUT."""
         qx = Buf(xs_flat, self._np_dtype)
@@ -146,7 +147,10 @@ class Bilinear(Interp2DStrategyBuilder, Interp2DStrategy):
         opts.q_memspace = qx.memspace
         opts.path = self.path
         opts.async_launch = int(bool(async_launch))
-        opts.flags = _capi.EVAL_FRESH_OUTPUT if fresh else _capi.EVAL_DEFAULT
+        # rows_after_error_unspecified: a caller-owned buffer whose rows at / after a failing query the caller gives up
+        # (NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED; the reference leaves them untouched, interp1d/mod.rs:334-342)
+        opts.flags = (_capi.EVAL_FRESH_OUTPUT if fresh else _capi.EVAL_DEFAULT) | \
+            (_capi.EVAL_ROWS_AFTER_ERROR_UNSPECIFIED if rows_after_error_unspecified else 0)
         if is_torch(out2d):
             if not out2d.is_cuda:
                 raise TypeError("torch output buffers must live on the device; use numpy for host buffers")
@@ -322,7 +326,11 @@ class Interp2D:
                 np_dtype_of(self.data))
             if tdt is None:
                 raise TypeError("device query tensors need f32 / f64 data; other element types use host arrays")
-            zs = torch.empty(shape, dtype=tdt, device=xs.device)
+            nbytes = int(np.prod(shape, dtype=np.int64)) * np_dtype_of(self.data).itemsize
+            if nbytes >= OUTPUT_OWNED_MIN_BYTES:     # Array::zeros through the library's placement-checked allocator
+                zs = output_empty(shape, np_dtype_of(self.data), xs.device.index or 0)
+            else:
+                zs = torch.empty(shape, dtype=tdt, device=xs.device)
         else:
             zs = np.zeros(shape, dtype=np_dtype_of(self.data))
         # the buffer is this call's own and is dropped on Err (:193-195): strategies that can use the knowledge are told

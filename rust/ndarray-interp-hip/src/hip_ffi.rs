@@ -1,4 +1,4 @@
-//! `extern "C"` bindings of libndinterp_hip.so -- one to one with `include/ndinterp.h` (v0.3).
+//! `extern "C"` bindings of libndinterp_hip.so -- one to one with `include/ndinterp.h` (v0.5).
 //!
 //! Every `#[repr(C)]` struct and every function below is compared with the header by
 //! `tests/test_rust_ffi_abi.py`: field / argument ORDER and C TYPE, not only names.  Keep one field
@@ -41,13 +41,14 @@ pub const NDI_MONO_RISING_STRICT: i32 = 1;
 pub const NDI_MONO_RISING: i32 = 2;
 pub const NDI_MONO_FALLING_STRICT: i32 = 3;
 pub const NDI_MONO_FALLING: i32 = 4;
-/// `ndi_path`
+/// `ndi_build_flags` (`ndi_interp1d_desc::build_flags`)
 pub const NDI_BUILD_DEFAULT: i32 = 0;
 pub const NDI_BUILD_REFERENCE_ORDER: i32 = 1;
-
+/// `ndi_eval_flags` (`ndi_eval_opts::flags`)
 pub const NDI_EVAL_DEFAULT: i32 = 0;
 pub const NDI_EVAL_FRESH_OUTPUT: i32 = 1;
-
+pub const NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED: i32 = 2;
+/// `ndi_path`
 pub const NDI_PATH_AUTO: i32 = 0;
 pub const NDI_PATH_GATHER: i32 = 1;
 pub const NDI_PATH_BUCKETED: i32 = 2;
@@ -185,6 +186,16 @@ pub struct ndi_profile {
     pub group_ms: f64,
     pub last_path: i32,
     pub reserved: i32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct ndi_output_info {
+    pub tries: u32,
+    pub reserved: u32,
+    pub fill_tbps: f64,
+    pub worst_fill_tbps: f64,
+    pub alloc_ms: f64,
 }
 
 // ---- functions --------------------------------------------------------------------------------
@@ -331,6 +342,14 @@ extern "C" {
         nx: u64,
         ny: u64,
     ) -> i32;
+    pub fn ndi_output_alloc(
+        device: i32,
+        bytes: u64,
+        max_tries: u32,
+        out: *mut *mut c_void,
+        info: *mut ndi_output_info,
+    ) -> i32;
+    pub fn ndi_output_free(p: *mut c_void) -> i32;
     pub fn ndi_device_count() -> i32;
     pub fn ndi_last_error_string() -> *const c_char;
     pub fn ndi_version() -> u32;

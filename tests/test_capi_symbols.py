@@ -47,7 +47,7 @@ def test_rust_shim_binds_every_export():
 
 def test_version_and_error_string(pkg):
     lib = pkg._capi.lib()
-    assert lib.ndi_version() == (0 << 16) | 4
+    assert lib.ndi_version() == (0 << 16) | 5
     assert isinstance(pkg._capi.last_error(), str)
 
 

@@ -45,11 +45,21 @@ __global__ __launch_bounds__(256) void scatter_kernel(dbl2* out, const uint32_t*
   }
 }
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static float scatter_ms(void* p, const uint32_t* order) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
   hipLaunchKernelGGL(scatter_kernel, dim3(7816), dim3(256), 0, 0, (dbl2*)p, order, NROWS, 2.0);
+  // WARM_MS: sustained load before the timed launches (is the spread a clock / power-state ramp rather than placement?)
+  if (const char* w = getenv("WARM_MS")) {
+    const double t_end = now_s() + atof(w) * 1e-3;
+    while (now_s() < t_end) {
+      hipLaunchKernelGGL(scatter_kernel, dim3(7816), dim3(256), 0, 0, (dbl2*)p, order, NROWS, 2.0);
+      CK(hipDeviceSynchronize());
+    }
+  }
   std::vector<float> ts;
   for (int r = 0; r < 3; ++r) {
     CK(hipEventRecord(a, 0));
@@ -66,7 +76,6 @@ static float scatter_ms(void* p, const uint32_t* order) {
   return ts[1];
 }
 
-static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
   const size_t chunk_gib = argc > 1 ? atoi(argv[1]) : 1;
@@ -92,7 +101,10 @@ int main(int argc, char** argv) {
   CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
   printf("{\"granularity\": %zu, \"chunk_GiB\": %zu, \"need_chunks\": %d}\n", gran, chunk_gib, need);
   for (int rep = 0; rep < reps; ++rep) {
-    for (int K : {0, 1, 2, 3, 4, 6}) {
+    std::vector<int> Ks = {0, 1, 2, 3, 4, 6};
+    if (const char* ke = getenv("KS")) { Ks.clear(); for (const char* c = ke; *c; ++c) if (*c >= '0' && *c <= '9') Ks.push_back(*c - '0'); }
+    const size_t va_align = getenv("ALIGN") ? (size_t)atoll(getenv("ALIGN")) : 0;
+    for (int K : Ks) {
       size_t fr = 0, tot = 0;
       CK(hipMemGetInfo(&fr, &tot));
       if (K == 0) {
@@ -101,8 +113,8 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&p, out_bytes));
         const double t1 = now_s();
         const float ms = scatter_ms(p, order);
-        printf("{\"rep\": %d, \"alloc\": \"hipMalloc\", \"alloc_ms\": %.1f, \"scatter_ms\": %.3f, \"TBs\": %.2f, \"free_GB\": %.0f}\n", rep,
-               (t1 - t0) * 1e3, ms, out_bytes / ms / 1e9, fr / 1e9);
+        printf("{\"rep\": %d, \"alloc\": \"hipMalloc\", \"alloc_ms\": %.1f, \"scatter_ms\": %.3f, \"TBs\": %.2f, \"free_GB\": %.0f, \"va\": \"%p\"}\n", rep,
+               (t1 - t0) * 1e3, ms, out_bytes / ms / 1e9, fr / 1e9, p);
         fflush(stdout);
         CK(hipFree(p));
         continue;
@@ -119,13 +131,13 @@ int main(int argc, char** argv) {
       for (int i = 0; i < total; ++i)
         if (i % K != K / 2) CK(hipMemRelease(hs[i]));       // keep one chunk of every K
       void* va = nullptr;
-      CK(hipMemAddressReserve(&va, (size_t)need * chunk, 0, nullptr, 0));
+      CK(hipMemAddressReserve(&va, (size_t)need * chunk, va_align, nullptr, 0));
       for (int k = 0; k < need; ++k) CK(hipMemMap((char*)va + (size_t)k * chunk, chunk, 0, hs[k * K + K / 2], 0));
       CK(hipMemSetAccess(va, (size_t)need * chunk, &acc, 1));
       const double t2 = now_s();
       const float ms = scatter_ms(va, order);
       printf("{\"rep\": %d, \"alloc\": \"vmm\", \"K\": %d, \"create_ms\": %.1f, \"release_map_ms\": %.1f, \"scatter_ms\": %.3f, \"TBs\": %.2f, "
-             "\"free_GB\": %.0f}\n", rep, K, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ms, out_bytes / ms / 1e9, fr / 1e9);
+             "\"free_GB\": %.0f, \"va\": \"%p\", \"va_align\": %zu}\n", rep, K, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ms, out_bytes / ms / 1e9, fr / 1e9, va, va_align);
       fflush(stdout);
       CK(hipMemUnmap(va, (size_t)need * chunk));
       CK(hipMemAddressFree(va, (size_t)need * chunk));

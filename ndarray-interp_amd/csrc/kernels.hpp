@@ -1997,7 +1997,9 @@ __global__ __launch_bounds__(TB) void eval_lanes_kernel(EvalLanesArgs<T> A) {
   __syncthreads();
   unsigned long long limit = A.check ? NO_FAIL : *A.first_fail;
   if (limit > A.nq) limit = A.nq;
-  const bool contig = A.out_stride == (uint64_t)L;
+  // (16-byte vector stores of the batch's rows: the rows must be contiguous AND the buffer 16-byte aligned -- a sliced
+  //  view such as out[1:] with 5 lanes takes the per-element path)
+  const bool contig = A.out_stride == (uint64_t)L && (reinterpret_cast<uintptr_t>(A.out) & 15u) == 0u;
   // even L: lane j writes its row starting at value (j mod L) -- a plain l = 0, 1, ... order would put the lanes of a
   // wave on L-element strides, i.e. (for L = 8 doubles) on two bank groups; odd strides spread by themselves
   const uint32_t rot = (L & 1u) ? 0u : lane % L;
@@ -3766,7 +3768,9 @@ __global__ __launch_bounds__(TB) void eval_lanes2d_kernel(EvalLanes2Args<T> A) {
   unsigned long long limit = A.check ? NO_FAIL : (A.first_fail[0] < A.first_fail[1] ? A.first_fail[0] : A.first_fail[1]);
   if (limit > A.nq) limit = A.nq;
   const uint32_t ny = A.ny, rowe = ny * L;
-  const bool contig = A.out_stride == (uint64_t)L;
+  // (16-byte vector stores of the batch's rows: the rows must be contiguous AND the buffer 16-byte aligned -- a sliced
+  //  view such as out[1:] with 5 lanes takes the per-element path)
+  const bool contig = A.out_stride == (uint64_t)L && (reinterpret_cast<uintptr_t>(A.out) & 15u) == 0u;
   const uint32_t rot = (L & 1u) ? 0u : lane % L;
   const uint64_t wstep = (uint64_t)gridDim.x * TB;
   uint64_t base = ((uint64_t)blockIdx.x * (TB / 64) + (tid >> 6)) * 64u;
@@ -4597,16 +4601,21 @@ __global__ __launch_bounds__(BLOCK) void spline_build_lds_kernel(BuildArgs<T> A)
 
 // The x-only elimination factors of the GENERAL system on the device, for axes of 1e5-1e6 knots where the host's division
 // chain of n steps was half of the build (8.7 of 18 ms at 1e6 knots): w[i] = low[i] / mid'[i-1], mid'[i] = mid[i] - w[i] up[i-1]
-// (thomas, cubic_spline.rs:690-692, on the diagonals alone) with low / mid / up formed from the knots (:440-451).  The map
-// mid'[i-1] -> mid'[i] is a contraction -- its derivative low[i] up[i-1] / mid'[i-1]^2 is below 0.15 for ANY strictly rising
-// axis because mid' >= 4/3 (dx[i] + dx[i-1]) -- so a chain started WARM = 32 rows early from the uneliminated diagonal has
-// forgotten its start (0.25 * 0.15^32 ~ 1e-27) by the time it reaches its own rows: every thread owns SE consecutive rows
-// and runs the reference's recurrence, in the reference's operation order, from 32 rows before them (the first thread from
-// row 0, exactly).  Used by the blocked build only, whose tables carry their own few-ulp tolerance.
+// (thomas, cubic_spline.rs:690-692, on the diagonals alone) with low / mid / up formed from the knots (:440-451).  A chain
+// started a few rows early from the uneliminated diagonal forgets its start: an error e in mid'[i-1] becomes
+// e low[i] up[i-1] / mid'[i-1]^2 in mid'[i] -- not bounded in absolute terms where dx[i] is much larger than its neighbours,
+// but the RELATIVE error contracts: (e'/mid'[i]) / (e/mid'[i-1]) = low[i] up[i-1] / (mid'[i-1] mid'[i]) =
+// dx[i] dx[i-2] / (mid'[i-1] mid'[i]) <= 9/16, because mid'[i] >= 4/3 (dx[i] + dx[i-1]) on every strictly rising axis (by
+// induction: mid'[i] = 2 (dx[i] + dx[i-1]) - dx[i] dx[i-2] / mid'[i-1] >= 2 dx[i] + 2 dx[i-1] - 3/4 dx[i]); evenly spaced knots
+// contract by 0.07 per row.  WARM = 64 rows bring the worst case to (9/16)^64 ~ 1e-16 of the starting error (a relative
+// 0.25 at most): every thread owns SE consecutive rows and runs the reference's recurrence, in the reference's operation
+// order, from 64 rows before them (the first thread from row 0, exactly).  Used by the blocked build only -- whose tables
+// carry their own few-ulp tolerance -- and only on axes that pass its `tame` test (forced blocked builds of other axes take
+// the host's factors).
 template <class T>
 __global__ __launch_bounds__(BLOCK) void spline_eliminate_kernel(const T* x, uint64_t n, T up_first, T mid_first, T low_last,
                                                                  T mid_last, T* w, T* midp, uint64_t SE) {
-  constexpr uint64_t WARM = 32;
+  constexpr uint64_t WARM = 64;
   const T two = T(2);
   const uint64_t b = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
   const uint64_t i0 = b * SE;

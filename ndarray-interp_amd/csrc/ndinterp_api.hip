@@ -1025,7 +1025,7 @@ struct Interp1DImpl final : Interp1DBase {
     // at 4e-5 on gaps drawn log-uniformly over six decades, tests/test_gpu_spline_blocked.py).  Such axes keep the serial
     // kernels: bit-identical.
     bool tame = true;
-    if (blocked_env < 0) {
+    if (blocked_env != 0 && n >= 16) {      // (also when the blocked build is forced: the device-side elimination needs it)
       const double lim = sizeof(T) == 4 ? 1e3 : 1e9;
       const T* xs = pyr.host_knots.data();
       for (uint64_t i = 2; tame && i < n; ++i) {
@@ -1039,7 +1039,7 @@ struct Interp1DImpl final : Interp1DBase {
     // Long axes: the x-only elimination factors on the device as well (spline_eliminate_kernel); the host then forms only
     // the boundary rows' scalars.  NDI_SPLINE_DEVICE_ELIM=0: A/B.
     static const int elim_env = ShortKnobs::env("NDI_SPLINE_DEVICE_ELIM", 1);
-    const bool dev_elim = blocked && !periodic && n >= 32768 && elim_env != 0;
+    const bool dev_elim = blocked && tame && !periodic && n >= 32768 && elim_env != 0;
     SplineEnds<T> ends;
     SplinePlan<T> P = dev_elim ? make_spline_plan_scalars<T>(pyr.host_knots.data(), n, d.left.kind, d.left.value, d.right.kind,
                                                              d.right.value, ends)

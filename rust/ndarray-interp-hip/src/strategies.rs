@@ -1,8 +1,8 @@
 //! The strategy types of the MI355X backend.  They implement the reference's own traits
 //! (`Interp1DStrategyBuilder` / `Interp1DStrategy`, src/interp1d/strategies/mod.rs:12-65, and the 2-D pair,
 //! src/interp2d/strategies/mod.rs:14-73) -- with `rust/patches/ndarray-interp-0.6.0-batched-hook.patch` applied, which
-//! adds ONE defaulted method per finished-strategy trait (`interp_array_into`, default body = the reference's
-//! per-query loop) -- so a caller switches by naming another strategy:
+//! adds TWO defaulted methods per finished-strategy trait (`interp_array_into`, default body = the reference's
+//! per-query loop, and `interp_array_into_owned`, default = the former, for `interp_array`'s own buffer) -- so a caller switches by naming another strategy:
 //!
 //! ```ignore
 //! use ndarray_interp::interp1d::Interp1DBuilder;
@@ -132,10 +132,13 @@ fn eval_error_1d<T: NumCast + Debug>(st: i32, info: &ffi::ndi_oob_info) -> Resul
 }
 
 /// One `ndi_interp1d_eval` call over a flattened query array (host arrays in and out).
+/// `flags`: `ndi_eval_flags` -- `NDI_EVAL_FRESH_OUTPUT` when the rows belong to `Interp1D::interp_array`'s own
+/// `Array::zeros` buffer (the `interp_array_into_owned` hook), else `NDI_EVAL_DEFAULT`.
 fn eval_1d<T, Sq, D>(
     dev: &DeviceTables1D,
     xs: &ArrayBase<Sq, Ix1>,
     buffer: ArrayViewMut<'_, T, D>,
+    flags: i32,
 ) -> Result<(), InterpolateError>
 where
     T: Num + NumCast + Copy + Debug + 'static,
@@ -150,7 +153,7 @@ where
         stream: per_thread_stream(),
         path: ffi::NDI_PATH_AUTO,
         async_launch: 0,
-        flags: ffi::NDI_EVAL_DEFAULT,
+        flags,
         reserved: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
@@ -309,7 +312,7 @@ where
         x: Sx::Elem,
     ) -> Result<(), InterpolateError> {
         let xs = ndarray::arr1(&[x]);
-        eval_1d(&self.dev, &xs, target.insert_axis(ndarray::Axis(0)))
+        eval_1d(&self.dev, &xs, target.insert_axis(ndarray::Axis(0)), ffi::NDI_EVAL_DEFAULT)
     }
 
     fn interp_array_into<Sq>(
@@ -322,7 +325,22 @@ where
         Sq: Data<Elem = Sd::Elem>,
         D: RemoveAxis,
     {
-        eval_1d(&self.dev, xs, buffer)
+        eval_1d(&self.dev, xs, buffer, ffi::NDI_EVAL_DEFAULT)
+    }
+
+    /// `Interp1D::interp_array`'s own buffer (dropped on `Err`, src/interp1d/mod.rs:209-210): the library may skip the
+    /// range pre-pass (`NDI_EVAL_FRESH_OUTPUT`); the error report is unchanged.
+    fn interp_array_into_owned<Sq>(
+        &self,
+        _interpolator: &Interp1D<Sd, Sx, D, Self>,
+        xs: &ArrayBase<Sq, Ix1>,
+        buffer: ArrayViewMut<'_, Sd::Elem, D>,
+    ) -> Result<(), InterpolateError>
+    where
+        Sq: Data<Elem = Sd::Elem>,
+        D: RemoveAxis,
+    {
+        eval_1d(&self.dev, xs, buffer, ffi::NDI_EVAL_FRESH_OUTPUT)
     }
 }
 
@@ -515,7 +533,7 @@ where
         x: Sx::Elem,
     ) -> Result<(), InterpolateError> {
         let xs = ndarray::arr1(&[x]);
-        eval_1d(&self.dev, &xs, target.insert_axis(ndarray::Axis(0)))
+        eval_1d(&self.dev, &xs, target.insert_axis(ndarray::Axis(0)), ffi::NDI_EVAL_DEFAULT)
     }
 
     fn interp_array_into<Sq>(
@@ -528,7 +546,22 @@ where
         Sq: Data<Elem = Sd::Elem>,
         D: RemoveAxis,
     {
-        eval_1d(&self.dev, xs, buffer)
+        eval_1d(&self.dev, xs, buffer, ffi::NDI_EVAL_DEFAULT)
+    }
+
+    /// `Interp1D::interp_array`'s own buffer (dropped on `Err`, src/interp1d/mod.rs:209-210): the library may skip the
+    /// range pre-pass (`NDI_EVAL_FRESH_OUTPUT`); the error report is unchanged.
+    fn interp_array_into_owned<Sq>(
+        &self,
+        _interpolator: &Interp1D<Sd, Sx, D, Self>,
+        xs: &ArrayBase<Sq, Ix1>,
+        buffer: ArrayViewMut<'_, Sd::Elem, D>,
+    ) -> Result<(), InterpolateError>
+    where
+        Sq: Data<Elem = Sd::Elem>,
+        D: RemoveAxis,
+    {
+        eval_1d(&self.dev, xs, buffer, ffi::NDI_EVAL_FRESH_OUTPUT)
     }
 }
 
@@ -610,11 +643,13 @@ where
     }
 }
 
+/// `flags`: see `eval_1d`.
 fn eval_2d<T, Sqx, Sqy, D>(
     dev: &DeviceTables2D,
     xs: &ArrayBase<Sqx, Ix1>,
     ys: &ArrayBase<Sqy, Ix1>,
     buffer: ArrayViewMut<'_, T, D>,
+    flags: i32,
 ) -> Result<(), InterpolateError>
 where
     T: Num + NumCast + Copy + Debug + 'static,
@@ -630,7 +665,7 @@ where
         stream: per_thread_stream(),
         path: ffi::NDI_PATH_AUTO,
         async_launch: 0,
-        flags: ffi::NDI_EVAL_DEFAULT,
+        flags,
         reserved: 0,
     };
     let mut info = ffi::ndi_oob_info::default();
@@ -681,7 +716,7 @@ where
         y: Sy::Elem,
     ) -> Result<(), InterpolateError> {
         let (xs, ys) = (ndarray::arr1(&[x]), ndarray::arr1(&[y]));
-        eval_2d(&self.dev, &xs, &ys, target.insert_axis(ndarray::Axis(0)))
+        eval_2d(&self.dev, &xs, &ys, target.insert_axis(ndarray::Axis(0)), ffi::NDI_EVAL_DEFAULT)
     }
 
     fn interp_array_into<Sqx, Sqy>(
@@ -695,6 +730,21 @@ where
         Sqx: Data<Elem = Sd::Elem>,
         Sqy: Data<Elem = Sd::Elem>,
     {
-        eval_2d(&self.dev, xs, ys, buffer)
+        eval_2d(&self.dev, xs, ys, buffer, ffi::NDI_EVAL_DEFAULT)
+    }
+
+    /// `Interp2D::interp_array`'s own buffer (dropped on `Err`, src/interp2d/mod.rs:194-195): `NDI_EVAL_FRESH_OUTPUT`.
+    fn interp_array_into_owned<Sqx, Sqy>(
+        &self,
+        _interpolator: &Interp2D<Sd, Sx, Sy, D, Self>,
+        xs: &ArrayBase<Sqx, Ix1>,
+        ys: &ArrayBase<Sqy, Ix1>,
+        buffer: ArrayViewMut<'_, Sd::Elem, D::Smaller>,
+    ) -> Result<(), InterpolateError>
+    where
+        Sqx: Data<Elem = Sd::Elem>,
+        Sqy: Data<Elem = Sd::Elem>,
+    {
+        eval_2d(&self.dev, xs, ys, buffer, ffi::NDI_EVAL_FRESH_OUTPUT)
     }
 }

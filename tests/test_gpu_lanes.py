@@ -258,3 +258,44 @@ def test_lanes_2d_auto_takes_the_bench_shape(pkg, capfd):
     sel = rng.choice(Q, 50_000, replace=False)
     ref = oracle.interp2d_bilinear(x, y, g.reshape(100, 100, 1), qx.cpu().numpy()[sel], qy.cpu().numpy()[sel])[3].reshape(-1)
     check_equal(got.reshape(-1)[sel], ref, "lanes2d auto 100x100")
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_sliced_output_views_with_odd_lane_counts(pkg, capfd, dt):
+    """ADVICE r5: `out[1:]` of a (Q + 1, 5) buffer is contiguous, T-aligned and NOT 16-byte aligned -- the C ABI accepts it;
+    the kernels that store rows as 16-byte vectors (eval_lanes_kernel, eval_lanes2d_kernel, eval_slopes2d_kernel) must
+    take their per-element store path for it.  1-D (100, 5) and 2-D 40 x 30 x 5 / 150 x 140 x 5, bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    Q, L = 70_001, 5
+    x = knots("rand", 100, rng, dt)
+    y = rng.uniform(-1, 1, (100, L)).astype(dt)
+    q = rng.uniform(x[0], x[-1], Q).astype(dt)
+    it = pkg.Interp1DBuilder.new(torch.as_tensor(y, device=dev)).x(torch.as_tensor(x, device=dev)).strategy(pkg.CubicSpline.new()).build()
+    st, a, b = oracle.cubic_build(x, y)
+    ref = oracle.interp1d_cubic(x, y, a, b, q)[2]
+    big = torch.full((Q + 1, L), -5.0, dtype=_tdt(dt), device=dev)
+    view = big[1:]
+    assert view.data_ptr() % 16 != 0 and view.is_contiguous()
+    with forced(capfd) as f:
+        it.interp_array_into(torch.as_tensor(q, device=dev), view)
+    assert " lanes L=5" in f.plans[0], f.plans
+    check_equal(view.cpu().numpy(), ref, "1-D lanes into out[1:]")
+    assert bool((big[0] == -5.0).all())
+    for nx, ny, plan, env in ((40, 30, " lanes2d L=5", {}), (150, 140, " slopes2d L=5", {"NDI_SLOPES2D_KERNEL": "1"})):
+        gx = knots("rand", nx, rng, dt); gy = knots("jit", ny, rng, dt)
+        g = rng.uniform(-1, 1, (nx, ny, L)).astype(dt)
+        qx = rng.uniform(gx[0], gx[-1], Q).astype(dt); qy = rng.uniform(gy[0], gy[-1], Q).astype(dt)
+        it2 = pkg.Interp2DBuilder.new(torch.as_tensor(g, device=dev)).x(torch.as_tensor(gx, device=dev)).y(torch.as_tensor(gy, device=dev)).build()
+        big = torch.full((Q + 1, L), -5.0, dtype=_tdt(dt), device=dev)
+        os.environ.update(env)
+        try:
+            with forced(capfd) as f:
+                it2.interp_array_into(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), big[1:])
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert plan in f.plans[0], f.plans
+        check_equal(big[1:].cpu().numpy(), oracle.interp2d_bilinear(gx, gy, g, qx, qy)[3].reshape(Q, L), f"2-D {plan} into out[1:]")
+        assert bool((big[0] == -5.0).all())

@@ -113,12 +113,17 @@ def _axis(kind, n, rng, dt):
         return np.unique(np.geomspace(1e-3, 1e3, n).astype(dt))
     if kind == "clustered":                       # gaps log-uniform over six decades: neighbours differ by up to 1e6
         return np.unique(np.cumsum(10.0 ** rng.uniform(-6, 0, n)).astype(dt))
+    if kind == "alternating":                     # gaps alternating between decades -- 1, 1e-4, 1, 1e-2, ... -- on an
+        g = np.ones(n)                            # axis long enough for the device-side elimination (n >= 32 768): the warm
+        g[1::2] = 10.0 ** (-(np.arange(g[1::2].size) % 3 + 2.0))     # start of spline_eliminate_kernel against the host's chain
+        g[::7] *= 50.0
+        return np.unique(np.cumsum(g).astype(dt))
     return knots(kind, n, rng, dt)
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("kind,n,L", [("geom", 4096, 4), ("clustered", 8192, 1), ("clustered", 3000, 64), ("geom", 50_000, 1),
-                                       ("rand", 20_000, 2), ("jit", 4096, 8)])
+                                       ("rand", 20_000, 2), ("jit", 4096, 8), ("alternating", 40_000, 2), ("clustered", 70_000, 1)])
 def test_blocked_build_local_bound_on_non_uniform_axes(pkg, dt, kind, n, L):
     """a per-entry bound relative to the NEIGHBOURING magnitudes (not to the largest entry of the table), on
     axes whose gaps -- and therefore the table's magnitudes -- vary over many decades, with data whose scale varies

@@ -231,3 +231,40 @@ def test_ctypes_structs_match_the_header(pkg):
                 assert C.sizeof(ct) == C.sizeof(C.c_void_p), (cname, n)
             else:   # nested struct by value
                 assert C.sizeof(ct) == C.sizeof(pairs[rt]), (cname, n)
+
+
+PATCH = os.path.join(ROOT, "rust", "patches", "ndarray-interp-0.6.0-batched-hook.patch")
+STRATEGIES = os.path.join(ROOT, "rust", "ndarray-interp-hip", "src", "strategies.rs")
+
+
+def test_patch_adds_both_hooks_and_the_strategies_override_them():
+    """Round 6: `interp_array` reaches the strategy through `interp_array_into_owned` (so the device strategies can pass
+    NDI_EVAL_FRESH_OUTPUT), `interp_array_into` through `interp_array_into`; both are defaulted trait methods on both
+    traits, and every device strategy overrides both."""
+    patch = open(PATCH).read()
+    for f in ("src/interp1d/strategies/mod.rs", "src/interp2d/strategies/mod.rs"):
+        part = patch.split(f"+++ b/{f}")[1].split("\ndiff ")[0]
+        assert re.search(r"^\+    fn interp_array_into<", part, flags=re.M), f
+        assert re.search(r"^\+    fn interp_array_into_owned<", part, flags=re.M), f
+    for f, call in (("src/interp1d/mod.rs", "self.interp_array_into_owned(xs, ys.view_mut())"),
+                    ("src/interp2d/mod.rs", "self.interp_array_into_owned(xs, ys, zs.view_mut())")):
+        part = patch.split(f"+++ b/{f}")[1].split("\ndiff ")[0]
+        assert "+        " + call in part, f
+        assert "+            return self.strategy.interp_array_into_owned(" in part or \
+            re.search(r"\+\s+\.interp_array_into_owned\(self, xs_1d, ys_1d, buffer_d\)", part), f
+    src = open(STRATEGIES).read()
+    assert len(re.findall(r"fn interp_array_into<", src)) == 3 and len(re.findall(r"fn interp_array_into_owned<", src)) == 3
+    assert src.count("ffi::NDI_EVAL_FRESH_OUTPUT)") == 3       # one per owned hook
+    ffi = open(RUST).read()
+    assert "pub const NDI_EVAL_FRESH_OUTPUT: i32 = 1;" in ffi and "pub const NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED: i32 = 2;" in ffi
+
+
+def test_patch_applies_to_the_reference_sources(tmp_path):
+    """Where the reference checkout is present (this container; not the GPU box): `patch --dry-run` of the hook patch."""
+    import shutil
+    import subprocess
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref) or shutil.which("patch") is None:
+        pytest.skip("no reference checkout / no patch(1) here")
+    r = subprocess.run(["patch", "-p1", "--dry-run", "-d", "/root/reference", "-i", PATCH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -495,14 +495,17 @@ def short_rows_leg(pkg, torch, dev, out_bytes=4e9, steps=5):
                 torch.cuda.synchronize()
                 walls[fresh] = (time.perf_counter() - t0) / steps
                 interp.strategy.finish()
-            wall = walls[True]
+            wall, fwall = walls[False], walls[True]
+            # `ms` / `Gqueries_s` are interp_array_into (a caller-owned buffer; comparable with rounds 1-4); the
+            # interp_array figures exclude the allocation of the output (the reference's includes its Array::zeros)
             res["reference_shapes"].append({"dtype": np.dtype(dt).name, "knots": int(xd.numel()), "lanes": L, "queries": Q,
                                             "ms": round(wall * 1e3, 4), "Gqueries_s": round(Q / wall / 1e9, 1),
                                             "out_TBps": round(Q * L * el / wall / 1e12, 3),
                                             "io_frac_of_peak": round(Q * (L + 1) * el / wall / 1e9 / HBM_PEAK_GBS, 4),
-                                            "semantics": "interp_array (fresh output, NDI_EVAL_FRESH_OUTPUT)",
-                                            "interp_array_into_ms": round(walls[False] * 1e3, 4),
-                                            "interp_array_into_Gqueries_s": round(Q / walls[False] / 1e9, 1)})
+                                            "semantics": "interp_array_into (caller-owned buffer, range pre-pass)",
+                                            "interp_array_excl_alloc_ms": round(fwall * 1e3, 4),
+                                            "interp_array_excl_alloc_Gqueries_s": round(Q / fwall / 1e9, 1),
+                                            "interp_array_excl_alloc_io_frac_of_peak": round(Q * (L + 1) * el / fwall / 1e9 / HBM_PEAK_GBS, 4)})
             interp.strategy.release()
             del interp, qd, yd, out
         torch.cuda.empty_cache()
@@ -588,6 +591,52 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
     return res
 
 
+def c2_variants_leg(pkg, torch, dev, steps=3):
+    """SURVEY 8(d)'s secondary runs at BASELINE configs[1]'s shape (4096 knots x 4096 f64 lanes, 1e6 queries, one resident
+    32.8 GB buffer): the four knot families of benches/bench_vector_extensions.rs:19-78 -- g1 linspace (the O(1) guess of
+    vector_extensions.rs:70-90 is exact), g2 sorted-unique uniform (the headline's), g3 linspace + uniform(+-0.2/n) noise,
+    g4 logspace -- and, on g2, SORTED queries (cache reuse in the gather order), each with both formulations: kernel time
+    (library HIP events), the search pass, and the rate on the SURVEY 8(d) gather model (40 B per point) for the gather
+    kernel / on compulsory bytes for the bucketed one."""
+    n = lanes = 4096
+    nq = 1_000_000
+    rng = np.random.default_rng(42)
+    fam = {"g1_linspace": np.linspace(0.0, 1.0, n),
+           "g2_random": np.unique(rng.uniform(0.0, 1.0, 2 * n))[:n],
+           "g3_jittered": np.sort(np.linspace(0.0, 1.0, n) + rng.uniform(-0.2 / n, 0.2 / n, n)),
+           "g4_logspace": np.logspace(-3.0, 0.0, n)}
+    yd = torch.rand((n, lanes), dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+    out = torch.empty((nq, lanes), dtype=torch.float64, device=dev)
+    table_bytes = (n + 2 * (n - 1)) * lanes * 8
+    rows = []
+    for name, x in fam.items():
+        interp = pkg.Interp1DBuilder.new(yd).x(torch.as_tensor(x, device=dev)).strategy(pkg.CubicSpline.new()).build()
+        q = np.random.default_rng(123).uniform(x[0], x[-1], nq)
+        for order in (("unsorted", "sorted") if name == "g2_random" else ("unsorted",)):
+            qd = torch.as_tensor(np.sort(q) if order == "sorted" else q, device=dev)
+            r = {"knots": name, "queries": order}
+            for pname, path in (("bucketed", pkg.PATH_BUCKETED), ("gather", pkg.PATH_GATHER)):
+                interp.strategy.path = path
+                step = lambda: interp.strategy.interp_array_into(interp, qd, out, async_launch=True)
+                step(); interp.strategy.finish()
+                pkg.profile_enable(True); pkg.profile_read(reset=True)
+                for _ in range(steps):
+                    step()
+                interp.strategy.finish()
+                p = pkg.profile_read(reset=True); pkg.profile_enable(False)
+                kms = p["eval_ms"] / max(1, p["eval_launches"])
+                nbytes = nq * lanes * 8 + nq * 16 + table_bytes if pname == "bucketed" else nq * lanes * 40 + nq * 8
+                r[pname] = {"kernel_ms": round(kms, 4), "locate_ms": round(p["locate_ms"] / max(1, p["locate_launches"]), 4),
+                            "group_ms": round(p["group_ms"] / steps, 4),
+                            ("frac_compulsory" if pname == "bucketed" else "survey_8d_ratio"): round(nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            rows.append(r)
+        interp.strategy.release()
+        del interp
+    del out, yd
+    torch.cuda.empty_cache()
+    return {"what": "BASELINE configs[1] shape, knot families g1-g4 and sorted queries (SURVEY 8(d) secondary runs)", "rows": rows}
+
+
 def reference_shapes_2d_leg(pkg, torch, dev, steps=5):
     """The reference's 2-D bench shapes (benches/bench_interp2d.rs:12-18, 87-92: a 100 x 100 scalar grid and a
     100 x 100 x 5 grid) scaled to 5e7 / 2e7 queries on device buffers, f64 and f32: wall time of a whole
@@ -614,14 +663,15 @@ def reference_shapes_2d_leg(pkg, torch, dev, steps=5):
                 torch.cuda.synchronize()
                 walls[fresh] = (time.perf_counter() - t0) / steps
                 it.strategy.finish()
-            wall = walls[True]
+            wall, fwall = walls[False], walls[True]
             io = Q * (C + 2) * el
             rows.append({"dtype": np.dtype(dt).name, "grid": [nx, ny, C], "queries": Q, "ms": round(wall * 1e3, 4),
                          "Gqueries_s": round(Q / wall / 1e9, 1), "io_TBps": round(io / wall / 1e12, 3),
                          "io_frac_of_peak": round(io / wall / 1e9 / HBM_PEAK_GBS, 4),
-                         "semantics": "interp_array (fresh output, NDI_EVAL_FRESH_OUTPUT)",
-                         "interp_array_into_ms": round(walls[False] * 1e3, 4),
-                         "interp_array_into_Gqueries_s": round(Q / walls[False] / 1e9, 1)})
+                         "semantics": "interp_array_into (caller-owned buffer, range pre-pass)",
+                         "interp_array_excl_alloc_ms": round(fwall * 1e3, 4),
+                         "interp_array_excl_alloc_Gqueries_s": round(Q / fwall / 1e9, 1),
+                         "interp_array_excl_alloc_io_frac_of_peak": round(io / fwall / 1e9 / HBM_PEAK_GBS, 4)})
             it.strategy.release()
             del it, qx, qy, out, grid
         torch.cuda.empty_cache()
@@ -730,7 +780,8 @@ def secondary_legs(pkg, torch, dev):
         traffic_store = None
     # the long tables first (they go to a line of their own, printed BEFORE the contract line), the BASELINE configs last
     detail = {"short_rows": short_rows_leg(pkg, torch, dev),
-              "reference_shapes_2d": reference_shapes_2d_leg(pkg, torch, dev)}
+              "reference_shapes_2d": reference_shapes_2d_leg(pkg, torch, dev),
+              "c2_knot_families_and_sorted_queries": c2_variants_leg(pkg, torch, dev)}
     sec = {"detail_line": "the JSON line before this one ({\"detail\": ...}) carries short_rows (+ reference_shapes) and reference_shapes_2d"}
     sec["reference_shapes_summary"] = reference_summary(detail)
     sec["host_path"] = host_path_leg(pkg, torch, dev)
@@ -767,14 +818,15 @@ def secondary_legs(pkg, torch, dev):
 
 def reference_summary(detail):
     """The reference's own bench shapes (benches/bench_interp1d.rs:12-47, 82-122, benches/bench_interp2d.rs:12-18, 87-92) as
-    [Gqueries/s with interp_array semantics, with interp_array_into semantics, q-in / row-out stream as a fraction of the
-    HBM peak] -- the compact copy of the detail line's tables that rides in the contract line."""
-    out = {}
+    [Gqueries/s of interp_array_into, of interp_array without its allocation, the latter's q-in / row-out stream as a
+    fraction of the HBM peak] -- the compact copy of the detail line's tables that rides in the contract line."""
+    out = {"columns": ["interp_array_into Gq/s", "interp_array (excl. alloc) Gq/s", "interp_array io frac of peak"]}
+    pick = lambda r: [r["Gqueries_s"], r["interp_array_excl_alloc_Gqueries_s"], r["interp_array_excl_alloc_io_frac_of_peak"]]
     for r in detail["short_rows"]["reference_shapes"]:
-        out[f"1d_{r['knots']}x{r['lanes']}_{r['dtype']}"] = [r["Gqueries_s"], r["interp_array_into_Gqueries_s"], r["io_frac_of_peak"]]
+        out[f"1d_{r['knots']}x{r['lanes']}_{r['dtype']}"] = pick(r)
     for r in detail["reference_shapes_2d"]:
         g = r["grid"]
-        out[f"2d_{g[0]}x{g[1]}x{g[2]}_{r['dtype']}"] = [r["Gqueries_s"], r["interp_array_into_Gqueries_s"], r["io_frac_of_peak"]]
+        out[f"2d_{g[0]}x{g[1]}x{g[2]}_{r['dtype']}"] = pick(r)
     out["short_rows_out_TBps_by_lanes"] = {f"{r['dtype']}x{r['lanes']}": r["out_TBps"] for r in detail["short_rows"]["shapes"]}
     return out
 
@@ -799,7 +851,7 @@ def secondary_summary(sec):
     rs = sec.get("reference_shapes_summary", {})
     for k in ("2d_100x100x5_float64", "2d_100x100x5_float32", "2d_100x100x1_float64", "1d_100x5_float64", "1d_100x1_float64"):
         if k in rs:
-            out[k + "_Gq_s"] = rs[k][0]
+            out[k + "_Gq_s_into_and_array"] = rs[k][:2]
     return out
 
 
@@ -1242,9 +1294,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ranks = gather_ranks(torch, dist, world, rank, 1.0 + rank, 0.5 + rank,
                                  {"rank": rank, "ordinal": local_rank, "uuid": f"rehearsal-{rank}", "name": "none"}, "cpu")
+        c5 = None
+        if world > 1:     # the per-rank C5-share leg's gather (all_gather_object of one dict per rank), with stand-in numbers
+            per = [None] * world
+            dist.all_gather_object(per, {"ms_per_step": 0.7 + 0.01 * rank, "kernel_ms": 0.6 + 0.01 * rank})
+            c5 = {"per_rank_ms": [p["ms_per_step"] for p in per], "per_rank_kernel_ms": [p["kernel_ms"] for p in per],
+                  "ms_per_step": max(p["ms_per_step"] for p in per)}
         if rank == 0:
             print(json.dumps({"rehearsal": True, "n_gpus": world, "max_over_ranks": float(t.item()),
-                              "local_rank": local_rank, "ranks": ranks, "queries_per_gpu": args.queries,
+                              "local_rank": local_rank, "ranks": ranks, "queries_per_gpu": args.queries, "c5_share": c5,
                               "workload": workload_name(args.knots, args.lanes, args.queries, world)}), flush=True)
         if world > 1:
             dist.barrier()

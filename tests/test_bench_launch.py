@@ -12,9 +12,21 @@ from conftest import ROOT
 
 
 def _one_json_line(stdout):
+    """The contract line: the LAST JSON line of the output; any JSON line before it is a `detail` line (the secondary
+    legs' long tables, printed first so that the contract line -- with the BASELINE configs at its end -- stays last)."""
     lines = [l for l in stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, stdout
-    return json.loads(lines[0])
+    assert lines, stdout
+    for l in lines[:-1]:
+        assert "detail" in json.loads(l), l[:200]
+    line = json.loads(lines[-1])
+    assert "detail" not in line
+    return line
+
+
+def _run(args, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                          timeout=timeout, env=env)
 
 
 def test_bench_self_launches_two_ranks():
@@ -63,7 +75,43 @@ def test_bench_single_rank_rehearsal():
     assert line["queries_per_gpu"] == 10_000_000 and line["workload"] == "Target"
 
 
+def test_bench_eight_rank_rehearsal_is_c4_with_eight_ranks():
+    """The N = 8 launch the driver makes (rehearsed on the CPU over gloo: 8 real GPU ranks are the driver's to start, and a
+    1-GPU box admits at most 6 processes on its card): the defaults land on BASELINE configs[3] -- "= C4" --, the line
+    carries 8 ranks' clocks and devices, and the per-rank C5-share gather carries 8 entries."""
+    r = _run(["--gpus", "8", "--launch-rehearsal"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 8 and line["queries_per_gpu"] == 12_500_000
+    assert line["workload"] == "C4 (BASELINE configs[3]) per-GPU share x 8 = C4"
+    rk = line["ranks"]
+    assert rk["world"] == 8 and len(rk["per_rank_ms"]) == 8 and len(rk["devices"]) == 8 and rk["slowest_rank"] == 7
+    assert sorted(d["rank"] for d in rk["devices"]) == list(range(8))
+    c5 = line["c5_share"]
+    assert len(c5["per_rank_ms"]) == 8 and len(c5["per_rank_kernel_ms"]) == 8 and c5["ms_per_step"] == max(c5["per_rank_ms"])
+
+
 import pytest
+
+
+@pytest.mark.gpu
+def test_bench_six_ranks_on_one_gpu_line_carries_every_rank():
+    """The real N > 1 code path with as many ranks as a 1-GPU box admits on its card (6; gloo, every rank on device 0,
+    a small C4-shaped workload, children spawned before any GPU call): 6 ranks' clocks in `ranks`, 6 per-rank entries in
+    the C5-share leg, max-over-ranks timing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--backend", "gloo",
+                        "--device-override", "0", "--knots", "512", "--lanes", "512", "--queries", "200000",
+                        "--chunk", "50000", "--steps", "2", "--warmup", "1", "--placement-probe", "0", "--no-check",
+                        "--no-gather-leg", "--no-pmc", "--c5-leg-grid", "512", "--c5-leg-queries", "100000"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _one_json_line(r.stdout)
+    rk = line["ranks"]
+    assert line["n_gpus"] == 6 and rk["world"] == 6 and len(rk["per_rank_ms"]) == 6 and rk["distinct_devices"] == 1
+    c5 = line["c5_share"]
+    assert len(c5["per_rank_ms"]) == 6 and len(c5["per_rank_kernel_ms"]) == 6 and all(v > 0 for v in c5["per_rank_ms"])
+    assert line["ms_per_step"] >= max(rk["per_rank_ms"]) * 0.999 and line["scaling"] == "weak"
 
 
 @pytest.mark.gpu
@@ -119,7 +167,13 @@ def test_bench_in_process_sharded_leg():
     line = _one_json_line(r.stdout)
     leg = line["in_process_sharded"]
     assert leg["devices"] == [0, 0] and "error" not in leg and leg["Mpoints_s"] > 0 and leg["queries_per_device"] == 400000
-    assert set(line["secondary"]) == {"c3", "c5_share", "c1", "short_rows", "c2_linear", "c2_f32", "reference_shapes_2d", "host_path"}
+    assert set(line["secondary"]) == {"detail_line", "reference_shapes_summary", "host_path", "c2", "c2_linear", "c2_f32", "c5_share",
+                                      "c3", "c1"}
+    # the BASELINE configs ride in `config` (what a truncating reader keeps) and, compactly, at the very end of the line
+    summ = line["config"]["secondary_summary"]
+    assert {"c3", "c5_share", "c2", "c2_linear", "c2_f32"} <= set(summ) and summ["c3"]["ms_per_step"] > 0 and summ["c2"]["frac"] > 0
+    assert list(line)[-1] == "tail_summary" and list(line)[-2] == "secondary"
+    assert line["secondary"]["c3"]["step_minus_kernels_ms"] >= 0 and line["secondary"]["c5_share"]["step_minus_kernels_ms"] >= 0
     assert line["roofline"].get("survey_8d_frac") is None   # (--no-gather-leg: the 8(d) basis belongs to the gather kernel's leg)
     # the leg is bounded in wall-clock time and says what it timed
     assert leg["leg_wall_s"] <= leg["budget_s"] + 30 and "timed" in leg and leg["first_step_s"] > 0

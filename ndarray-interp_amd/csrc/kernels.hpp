@@ -4800,39 +4800,6 @@ __global__ __launch_bounds__(BLOCK) void spline_blocked_finish_kernel(BuildArgs<
     spline_blocked_finish_elem<T>(A, e);
 }
 
-// The blocked sweeps of a SMALL system (n * lanes <= 2^17 values: 4096 knots x 8 lanes) in ONE launch: one 1024-thread
-// workgroup runs the phases of the multi-kernel form one after the other -- dx / up from the knots, the coefficient
-// products, every right-hand side, local forward sweeps, the carry chain, the forward correction with the division, the
-// same three steps backward, the a / b epilogue -- with a workgroup barrier (which orders its global-memory accesses too)
-// where the multi-kernel form has a launch boundary.  Nine dependent launches of a few microseconds of work each were
-// 0.13 of the 0.23 ms such a build took (profiles/r05_build_probe.jsonl).  Same operations: the tables are those of the
-// multi-kernel blocked build.
-template <class T>
-__global__ __launch_bounds__(1024) void spline_blocked_onewg_kernel(BuildArgs<T> A, T* dx, T* up, T up_first, T up_last_v,
-                                                                    uint64_t up_len) {
-  const uint64_t tid = threadIdx.x, nt = blockDim.x;
-  const uint64_t n = A.n, L = A.lanes;
-  for (uint64_t i = tid; i < n; i += nt) {          // spline_dx_up_kernel
-    if (i + 1 < n) dx[i] = A.x[i + 1] - A.x[i];
-    if (i < up_len) up[i] = (i == 0) ? up_first : ((i + 1 == up_len) ? up_last_v : A.x[i] - A.x[i - 1]);
-  }
-  __syncthreads();
-  for (uint64_t b = tid; b < A.nblocks; b += nt)
-    spline_blocked_coef_block<T>(A.w, A.up, A.midp, const_cast<T*>(A.fP), const_cast<T*>(A.dco), const_cast<T*>(A.bP), A.rows, A.S, b);
-  for (uint64_t e = tid; e < n * L; e += nt) A.rfull[e] = spline_rhs_at<T, false, true>(A, e / L, e % L);
-  __syncthreads();
-  for (int backward = 0; backward < 2; ++backward) {
-    for (uint64_t t = tid; t < A.nblocks * L; t += nt) spline_blocked_local_task<T, false>(A, backward, t);
-    __syncthreads();
-    for (uint64_t l = tid; l < L; l += nt) spline_blocked_carry_lane<T, false>(A, backward, l);
-    __syncthreads();
-    if (!backward) {
-      for (uint64_t e = tid; e < A.rows * L; e += nt) spline_blocked_fix_forward_elem<T, false>(A, e);
-      __syncthreads();
-    }
-  }
-  for (uint64_t e = tid; e < (n - 1) * L; e += nt) spline_blocked_finish_elem<T, false>(A, e);
-}
 
 // ---- periodic boundary (cubic_spline.rs:498-565) with the blocked sweeps: the condensed system of order m = n - 2
 // is swept exactly as above (rows = m), then k = k1 + k_{n-2} k2 with the lane-independent k2 of the host plan.

@@ -705,7 +705,7 @@ static void run_locate(hipStream_t s, const DevicePyramid<T>& pyr, const T* q, u
                          : std::min<uint64_t>((nq + 1023) / 1024, 2048);
   blocks = std::max<uint64_t>(blocks, 1);
   A.bx = BucketIndex<T>{nullptr, 0, T(0)};
-  static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+  constexpr int lut_env = 1;   // (the bucket index: A/B settled in round 3)
   if (lut_env && A.stage_lds && nq >= 4096) pyr.ensure_bucket_index();
   if (lut_env && A.stage_lds && pyr.lut_bytes && nq >= 4096 &&
       shmem + pyr.lut_bytes + (hist ? (size_t)nb * 4 : 0) <= LDS_STAGE_LIMIT) {
@@ -757,8 +757,6 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 //   NDI_SHORT_ROWB   auto: the grouped form is taken from rows of this many bytes upwards
 //   NDI_FUSED_PACK   interval-packed table copy for the fused kernel: -1 = rows shorter than a cache line,
 //                    0 = never, 1 = always
-//   NDI_FUSED_MAXLV  the gather formulation of rows of fewer than this many 16-byte vectors is the fused kernel
-//                    (longer rows: locate_kernel + eval_rows_kernel)
 // ndi_eval_opts as the entry points take it: defaults for NULL, unknown flag bits and a non-zero `reserved` refused (a
 // caller compiled against an older header -- a shorter struct, uninitialised padding -- is told so instead of silently
 // selecting an option), and NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED folded into the internal "no range pre-pass" bit.
@@ -789,7 +787,6 @@ struct ShortKnobs {
     k.cq = env("NDI_SHORT_CQ", k.cq);
     k.rowb = env("NDI_SHORT_ROWB", k.rowb);
     k.pack = env("NDI_FUSED_PACK", k.pack);
-    k.maxlv = env("NDI_FUSED_MAXLV", k.maxlv);
     return k;
   }
 };
@@ -799,15 +796,9 @@ static ShortKnobs short_knobs() {
   return live ? ShortKnobs::read() : once;
 }
 
-// Measurement knob (profiles/r03_ring_overlap.md): NDI_RING_OVERLAP=0 runs the ring's locate + group on the
-// evaluation stream instead of the side stream.  Read once.
-static bool ring_overlap() {
-  static const bool on = [] {
-    const char* e = std::getenv("NDI_RING_OVERLAP");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+// The ring's locate + group of chunk k + 1 run on a side stream beside chunk k's evaluation (measured against running
+// them on the evaluation stream: profiles/r03_ring_overlap.md).
+static constexpr bool ring_overlap() { return true; }
 
 static ndi_status check_ring_desc(const ndi_ring_desc* ring, uint64_t lanes, uint64_t* stride) {
   if (!ring || ring->n_slots == 0 || ring->chunk_queries == 0)
@@ -1037,8 +1028,8 @@ struct Interp1DImpl final : Interp1DBase {
     const bool blocked = n >= 16 && !(d.build_flags & NDI_BUILD_REFERENCE_ORDER) &&
                          (blocked_env > 0 || (blocked_env < 0 && n >= 2048 && lanes <= 256 && tame));
     // Long axes: the x-only elimination factors on the device as well (spline_eliminate_kernel); the host then forms only
-    // the boundary rows' scalars.  NDI_SPLINE_DEVICE_ELIM=0: A/B.
-    static const int elim_env = ShortKnobs::env("NDI_SPLINE_DEVICE_ELIM", 1);
+    // the boundary rows' scalars.
+    constexpr int elim_env = 1;
     const bool dev_elim = blocked && tame && !periodic && n >= 32768 && elim_env != 0;
     SplineEnds<T> ends;
     SplinePlan<T> P = dev_elim ? make_spline_plan_scalars<T>(pyr.host_knots.data(), n, d.left.kind, d.left.value, d.right.kind,
@@ -1050,8 +1041,7 @@ struct Interp1DImpl final : Interp1DBase {
     // substitution and the a / b epilogue in spline_build_general_kernel<FUSED>, dx / up formed from the resident knots;
     // the x-only factors w, mid' travel through a kept pinned buffer into a kept device buffer: no allocation, no free,
     // no status read-back (only the periodic build has one).  Same operations as the three-kernel form: bit-identical.
-    // NDI_SPLINE_FUSED_SMALL=0: A/B.
-    static const int small_env = ShortKnobs::env("NDI_SPLINE_FUSED_SMALL", 1);
+    constexpr int small_env = 1;
     if (small_env && P.mode == SPLINE_GENERAL && !blocked && (uint64_t)n * lanes <= (1u << 17)) {
       BuildScratch& bs = build_scratch();
       const size_t plan_b = 2 * (size_t)n * sizeof(T);
@@ -1084,7 +1074,7 @@ struct Interp1DImpl final : Interp1DBase {
       const unsigned grid1 = (unsigned)((lanes + 63) / 64);
       // the smallest systems -- data and right-hand sides fit LDS twice over, one workgroup covers the trailing axis --
       // form their right-hand sides with the whole workgroup and sweep out of LDS (spline_build_lds_kernel)
-      static const int lds_env = ShortKnobs::env("NDI_SPLINE_LDS_SMALL", 1);   // A/B
+      constexpr int lds_env = 1;
       const size_t lds_need = 2 * (size_t)n * lanes * sizeof(T);
       if (lds_env && lanes <= (uint64_t)BLOCK && lds_need <= 96 * 1024 && n >= 4) {
         allow_dynamic_lds(reinterpret_cast<const void*>(&spline_build_lds_kernel<T, true>), 96 * 1024);
@@ -1110,57 +1100,6 @@ struct Interp1DImpl final : Interp1DBase {
     // w, mid' and k2 -- the results of the host's division chain -- are uploaded straight from their vectors.
     const size_t plan_elems = 5 * (size_t)n;
     const size_t blk_elems = blocked ? 3 * (size_t)n + (size_t)n * lanes + 2 * (size_t)nblk * lanes : 0;
-    // Small blocked builds (4096 knots x 8 lanes): ONE launch -- one 1024-thread workgroup runs every phase
-    // (spline_blocked_onewg_kernel) -- on temporaries kept per host thread: nine dependent launches, an allocation, a
-    // free and the status read-back were 0.15 of the 0.23 ms of such a build.  NDI_SPLINE_ONEWG=0: A/B.
-    // (measured SLOWER than the nine launches it replaces -- 0.21 vs 0.13 ms at 4096 x 8: one workgroup pays every phase's
-    //  global-memory latency on one CU, the launches spread each phase over the chip -- so it is off: NDI_SPLINE_ONEWG=1: A/B)
-    static const int onewg_env = ShortKnobs::env("NDI_SPLINE_ONEWG", 0);
-    if (onewg_env && blocked && !per && (uint64_t)n * lanes <= (1u << 17)) {
-      BuildScratch& bs = build_scratch();
-      const size_t bytes = (plan_elems + blk_elems) * sizeof(T);
-      T* const plan = static_cast<T*>(bs.device_buf(device, bytes));
-      T* const hp = static_cast<T*>(bs.pinned(2 * (size_t)n * sizeof(T)));
-      std::memcpy(hp, P.w.data(), (size_t)n * sizeof(T));
-      std::memcpy(hp + n, P.midp.data(), (size_t)n * sizeof(T));
-      NDI_HIP(hipMemcpyAsync(plan + 2 * (size_t)n, hp, 2 * (size_t)n * sizeof(T), hipMemcpyHostToDevice, nullptr));   // [w | mid']
-      BuildArgs<T> A{};
-      A.data = data.as<T>();
-      A.ca = ca.as<T>();
-      A.cb = cb.as<T>();
-      A.x = pyr.view.lv0;
-      A.dx = plan;
-      A.up = plan + n;
-      A.w = plan + 2 * (size_t)n;
-      A.midp = plan + 3 * (size_t)n;
-      A.n = n;
-      A.lanes = lanes;
-      A.left_kind = P.left_kind;
-      A.right_kind = P.right_kind;
-      A.left_val = P.left_val;
-      A.right_val = P.right_val;
-      A.nkL_tmp1 = P.nkL_tmp1; A.nkL_d = P.nkL_d;
-      A.nkR_tmp1 = P.nkR_tmp1; A.nkR_d = P.nkR_d;
-      A.dx0_sq = P.dx0_sq; A.dxl_sq = P.dxl_sq;
-      A.kout = reserve_k();
-      T* sp = plan + plan_elems;
-      A.fP = sp;
-      A.dco = sp + n;
-      A.bP = sp + 2 * n;
-      A.rfull = sp + 3 * n;
-      A.ends = A.rfull + n * lanes;
-      A.carry = A.ends + nblk * lanes;
-      A.S = S;
-      A.nblocks = nblk;
-      A.rows = rows;
-      const uint64_t up_len = P.up.size();
-      hipLaunchKernelGGL(spline_blocked_onewg_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t) nullptr, A, plan, plan + n, P.up.front(),
-                         P.up.back(), up_len);
-      NDI_HIP(hipGetLastError());
-      NDI_HIP(hipStreamSynchronize(nullptr));
-      clk.mark("  blocked sweeps, one workgroup");
-      return NDI_OK;
-    }
     // temporaries: kept per host thread up to 64 MiB (hipMalloc + hipFree of a 48 MB buffer cost 4 ms of a 1e6-knot build,
     // and more than the kernels of a 4096 x 8 one); larger ones are allocated and freed here
     DevBuf tmp;
@@ -1408,16 +1347,16 @@ struct Interp1DImpl final : Interp1DBase {
   }
 
   // Query per lane with the whole table set in LDS (eval_scalar_kernel / eval_lanes_kernel): rows of up to 56 bytes
-  // (NDI_LANES_MAXB) whose records fit LDS beside the knots, an axis the branch-free search covers (dense bucket index
+  // whose records fit LDS beside the knots, an axis the branch-free search covers (dense bucket index
   // or exact O(1) guess), batches that give every workgroup several times its staging bytes to write.
   // NDI_LANES_KERNEL=0 leaves these shapes to the query-order kernel (A/B); =1 takes it whenever it fits.
   bool plan_lanes(hipStream_t s, Scratch& sc, Plan1& P, int path, int flags) {
     static const bool tune_live = std::getenv("NDI_TUNE_LIVE") != nullptr;
     // rows of up to 56 bytes: at 64 bytes the query-order kernel is level (f64 x 8: 65 vs 61-65 Gqueries/s) or ahead
     // (f32 x 16: 74 vs 57), profiles/r05_small_shapes_rates.txt
-    static const int on_once = ShortKnobs::env("NDI_LANES_KERNEL", -1), maxb_once = ShortKnobs::env("NDI_LANES_MAXB", 56);
+    static const int on_once = ShortKnobs::env("NDI_LANES_KERNEL", -1);
     const int on = tune_live ? ShortKnobs::env("NDI_LANES_KERNEL", -1) : on_once;
-    const int maxb = tune_live ? ShortKnobs::env("NDI_LANES_MAXB", 56) : maxb_once;
+    constexpr int maxb = 56;
     if (on == 0 || path == NDI_PATH_BUCKETED || n < 3 || n > 16384) return false;
     if (on < 0 && short_knobs().mode != 0) return false;   // a pinned short-row variant (NDI_SHORT_MODE) is what runs
     if (lanes * sizeof(T) > (size_t)(on > 0 ? std::max(maxb, 64) : maxb)) return false;   // (forced: up to 64 bytes, for the tests)
@@ -1523,11 +1462,11 @@ struct Interp1DImpl final : Interp1DBase {
   // Query-order fused search + evaluation (short rows): decides the variant and its launch shape, and enqueues the
   // range pre-pass the kernel relies on.  Returns false when the shape is not eligible.
   bool plan_fused(hipStream_t s, Scratch& sc, Plan1& P, const ShortKnobs& K, int flags = 0) {
-    static const int long_axes = ShortKnobs::env("NDI_FUSED_LONG_AXES", 1);   // A/B: 0 = axes up to half the LDS only
-    static const int global_axes = ShortKnobs::env("NDI_FUSED_GLOBAL_AXES", 1);   // A/B: 0 = two-kernel form for axes beyond LDS
+    constexpr int long_axes = 1;     // (axes beyond half the LDS: one large workgroup per CU)
+    constexpr int global_axes = 1;   // (axes beyond LDS: the u32 bucket index in global memory)
     const uint64_t LV = P.LV;
     if (LV == 0 || 64ull * LV * LV >= (1ull << 32) || (uint64_t)n * LV >= (1ull << 32) * 1ull) return false;   // 32-bit item / vector indices
-    static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+    constexpr int lut_env = 1;   // (the bucket index: A/B settled in round 3)
     if (pyr.lds_bytes > (long_axes ? LDS_STAGE_LIMIT - 8 * 1024 : LDS_STAGE_LIMIT / 2)) {
       // Axes too long for LDS: the same kernel with the knots left in global memory and searched through the u32 bucket
       // index (TLDS == 3) -- one launch, no idx[] / t[] round trip.  Batches below 4096 queries keep the two-kernel form.
@@ -1681,9 +1620,9 @@ struct Interp1DImpl final : Interp1DBase {
     // and the faster one up to a few million queries; beyond, the query-order kernel with the tables in LDS takes over
     // (scalar data at 1e8 queries: 98 -> 157 Gqueries/s f64, 2 lanes 45 -> 141).  Measured crossover
     // (profiles/r04_scalar_crossover.jsonl): ~8e6 output elements on <= 1024 knots, proportionally earlier on longer
-    // axes (8192 knots: ~1e6), whose table gathers miss L1.  NDI_SMALL_MAXQ overrides the 8e6.
+    // axes (8192 knots: ~1e6), whose table gathers miss L1.
     if (plan_lanes(s, sc, P, path, flags)) return P;
-    static const long small_maxq = ShortKnobs::env("NDI_SMALL_MAXQ", 8000000);
+    constexpr long small_maxq = 8000000;
     const bool small_first = lanes <= 2 && pyr.lds_bytes <= LDS_STAGE_LIMIT;
     const double small_work = (double)nq * (double)lanes * (double)std::max<uint64_t>(n, 1024) / 1024.0;
     if (small_first && small_work >= (double)small_maxq) {
@@ -1851,13 +1790,8 @@ struct Interp1DImpl final : Interp1DBase {
       const uint64_t segs = (LV + (uint64_t)BLOCK * U - 1) / ((uint64_t)BLOCK * U);
       // a multiple of 8 so that a workgroup keeps its XCD residue when it strides (XCD-aware chunk order);
       // every workgroup takes a run of consecutive chunks (operand rows stay in registers across them)
-      static const uint32_t run_env = [] {   // tuning knob (tools/sweep_target.py), read once
-        const char* e = std::getenv("NDI_BUCKETED_RUN");
-        const int v = e ? std::atoi(e) : 0;
-        return (uint32_t)(v > 0 && v <= 4096 ? v : 0);
-      }();
       const uint64_t per_xcd = ((nq + CQ - 1) / CQ + 7) / 8;
-      A.run = run_env ? run_env : BUCKETED_RUN;
+      A.run = BUCKETED_RUN;
       const uint64_t runs_per_xcd = (per_xcd + A.run - 1) / A.run;
       const unsigned gx = (unsigned)std::max<uint64_t>(8, std::min<uint64_t>(runs_per_xcd * 8, 65528));
       dim3 grid(gx, (unsigned)std::min<uint64_t>(segs, 64));
@@ -2467,7 +2401,7 @@ static ndi_status create1d(const ndi_interp1d_desc& d, Interp1DBase** out) {
     const size_t tab_b = d.strategy == NDI_CUBIC_SPLINE ? al((size_t)(d.n - 1) * d.lanes * sizeof(T)) : 0;
     const size_t k_b = (d.strategy == NDI_CUBIC_SPLINE && 2 * data_b <= FUSED_LDS_LIMIT) ? data_b : 0;
     const size_t total = pyr_b + data_b + 2 * tab_b + k_b;
-    static const int arena_env = ShortKnobs::env("NDI_HANDLE_ARENA", 1);   // A/B
+    constexpr int arena_env = 1;
     if (arena_env && total <= ((size_t)1 << 20)) {
       h->arena.reserve(total);
       char* p0 = static_cast<char*>(h->arena.p);
@@ -2542,7 +2476,6 @@ struct Interp2DImpl final : Interp2DBase {
   // record) or CELL records (every cell owns its 4 L values at a stride padded to a power of two / a multiple of 128 bytes: a
   // query then touches ceil(bytes / 128) lines exactly).  The kernel is bound by L1 misses in flight (counters:
   // profiles/r06_slopes2d_*), so the layout with fewer lines per query wins; a tie goes to the smaller table.
-  // NDI_SLOPES2D_CELLS=0 / 1: A/B.
   size_t slopes_cell_stride_bytes() const {
     const size_t need = 4 * lanes * sizeof(T);
     size_t sb = 32;
@@ -2551,8 +2484,6 @@ struct Interp2DImpl final : Interp2DBase {
     return sb;
   }
   bool slopes_cells() const {
-    static const int env = ShortKnobs::env("NDI_SLOPES2D_CELLS", -1);
-    if (env >= 0) return env != 0;
     const double need = (double)(4 * lanes * sizeof(T));
     const double lines_point = 1.0 + (need - 2.0 * sizeof(T)) / 128.0;
     const double lines_cell = (double)((slopes_cell_stride_bytes() + 127) / 128);
@@ -2701,7 +2632,9 @@ struct Interp2DImpl final : Interp2DBase {
       static const int on_once5 = ShortKnobs::env("NDI_SLOPES2D_KERNEL", -1);
       const int on = tune_live5 ? ShortKnobs::env("NDI_SLOPES2D_KERNEL", -1) : on_once5;
       const size_t cell_b = (size_t)lanes * sizeof(T);
-      if (on != 0 && path != NDI_PATH_BUCKETED && lanes >= 1 && cell_b <= 64 && nx <= 16384 && ny <= 16384 &&
+      // (f32 rows beyond 48 bytes: 13 .. 16 trips -- the compiler stops unrolling and the per-trip arrays go to scratch; the
+      //  query-order kernel was level there anyway)
+      if (on != 0 && path != NDI_PATH_BUCKETED && lanes >= 1 && cell_b <= (sizeof(T) == 4 ? 48 : 64) && nx <= 16384 && ny <= 16384 &&
           (uint64_t)slopes_bytes() < (1ull << 32) && slopes_bytes() <= SLOPES_LIMIT &&
           // AUTO: measured ahead of (f64 x 8, f32 x 16: level with) the query-order kernel on every row of up to 64 bytes
           // (profiles/r06_slopes2d_rates.txt); batches large enough to pay for building the copy; 1-2 values per point:
@@ -2722,9 +2655,7 @@ struct Interp2DImpl final : Interp2DBase {
           P.f_tb = tb;
           P.f_lds = need;
           P.f_lds_wide = wide_fits;
-          static const int swg_env = ShortKnobs::env("NDI_SLOPES2D_WG", 0);   // workgroups per CU (0: what fits)
-          size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
-          if (swg_env > 0) wg_per_cu = (size_t)swg_env;
+          const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / P.f_lds, 32 / (P.f_tb / 64)));
           P.f_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + P.f_tb - 1) / P.f_tb, (uint64_t)cu_count() * wg_per_cu));
           g_last_path.store(NDI_PATH_GATHER);
           P.l_check = (flags & NDI_EVAL_FRESH_OUTPUT) != 0;   // fresh output: the kernel's own range test, no pre-pass
@@ -2739,11 +2670,11 @@ struct Interp2DImpl final : Interp2DBase {
         }
       }
     }
-    static const int small2d_lanes = ShortKnobs::env("NDI_SMALL2D_LANES", 2);
+    constexpr int small2d_lanes = 2;
     constexpr int VNs = Wide<T>::N;
     const bool small2d = lanes <= 2 || (lanes <= (uint64_t)small2d_lanes && lanes % VNs != 0);
-    static const long f2_minlanes = ShortKnobs::env("NDI_FUSED2D_MINLANES", 1);   // (3: scalar / 2-value grids always stay with one thread per query)
-    static const long f2_minq0 = ShortKnobs::env("NDI_FUSED2D_MINQ", 65536);
+    constexpr long f2_minlanes = 1;
+    constexpr long f2_minq0 = 65536;
     const bool small2d_yields = (long)lanes >= f2_minlanes && f2_minq0 >= 0 && (long)std::min<uint64_t>(nq, 1ull << 40) >= 8 * f2_minq0;
     if (small2d && !small2d_yields && both <= LDS_STAGE_LIMIT && path != NDI_PATH_BUCKETED) {
       // short trailing axes: range pre-check, then both searches + evaluation fused in one launch
@@ -2759,19 +2690,19 @@ struct Interp2DImpl final : Interp2DBase {
       return P;
     }
     // Rows of fewer than 256 vectors on axes that fit LDS twice over (the reference's 100 x 100 x 5; few-channel grids),
-    // batches from NDI_FUSED2D_MINQ queries: query order with both searches fused in (eval_fused2d_kernel) -- no (xi, yi)
+    // batches from 65 536 queries: query order with both searches fused in (eval_fused2d_kernel) -- no (xi, yi)
     // round trip, one reciprocal per direction and query.  Grids the tile order takes (below) are left to it.
     {
-      static const long minq = ShortKnobs::env("NDI_FUSED2D_MINQ", 65536);
+      constexpr long minq = 65536;
       constexpr int VNf = Wide<T>::N;
       const bool vec = (lanes % VNf == 0) && (out_stride % VNf == 0) && aligned16(out);
       const uint64_t LVf = vec ? lanes / VNf : lanes;
       const uint64_t cell_e = pair_packed ? 2 * lanes : lanes, row_c = pair_packed ? ny - 1 : ny;
       const uint64_t grid_vecs = nx * row_c * cell_e / (vec ? VNf : 1);
-      static const int lut_env2 = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+      constexpr int lut_env2 = 1;
       // workgroup size and search: the combination that keeps most waves on a CU beside the staged axes (the gathers
       // are latency-bound: waves first); the bucket indices when they cost no waves, or at most half of them
-      static const int lut2_env = ShortKnobs::env("NDI_FUSED2D_LUT", -1);   // A/B: 0 never, 1 whenever they fit
+      constexpr int lut2_env = -1;
       size_t lut_b = 0;
       if (lut_env2 && lut2_env != 0 && nq >= 4096 && both <= LDS_STAGE_LIMIT) {
         px.ensure_bucket_index();
@@ -2823,7 +2754,7 @@ struct Interp2DImpl final : Interp2DBase {
     constexpr int VNp = Wide<T>::N;
     const bool vec_ok_p = (lanes % VNp == 0) && (out_stride % VNp == 0) && aligned16(out);
     const uint64_t LVp = vec_ok_p ? lanes / VNp : 0;
-    static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+    constexpr int lut_env = 1;   // (the bucket index: A/B settled in round 3)
     size_t both_l = both;
     const bool use_lut = lut_env && nq >= 4096 && both <= LDS_STAGE_LIMIT;
     if (use_lut) {
@@ -2952,9 +2883,9 @@ struct Interp2DImpl final : Interp2DBase {
         if (!P.compact) sc.recq2.reserve(nq * 2 * sizeof(T));
         sc.cursor2.reserve(((size_t)nb + 4) * sizeof(uint32_t));
         const size_t shm_c = ((size_t)3 * ntx + (size_t)2 * gthreads) * 4;
-        static const int fr_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_R"); return e ? std::atoi(e) : 4; }();
+        constexpr int fr_env = 4;
         static const int ft_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_THREADS"); return e ? std::atoi(e) : 0; }();
-        static const int fg_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_PARTS"); return e ? std::atoi(e) : 0; }();
+        constexpr int fg_env = 0;
         const int FR = (fr_env == 2 || fr_env == 8) ? fr_env : 4;   // records per thread and round of the fine pass
         const unsigned fthreads = (ft_env == 256 || ft_env == 512 || ft_env == 1024) ? (unsigned)ft_env : 1024u;
         // parts per tile row: one round per workgroup on evenly spread queries (measured at C3, profiles/r05_tuning.md:
@@ -3041,10 +2972,17 @@ struct Interp2DImpl final : Interp2DBase {
   // tile once (C3 grid, profiles/r04_c3_qpc_sweep.jsonl: 0.95 queries per cell +5 % time, 1.2: -12 %, 1.4: -23 %,
   // 1.9: -34 %, 2.4 (C3): -37 %; below 1 the gather order wins) and the grid is far larger than what the caches hold.
   bool auto_tiles(uint64_t nq) const {
-    static const double thr = [] { const char* e = std::getenv("NDI_TILE_QPC"); return e ? std::atof(e) : 1.1; }();
+    constexpr double thr = 1.1;
     const double cells = (double)(nx - 1) * (double)(ny - 1);
     const size_t grid_bytes = (size_t)nx * ny * lanes * sizeof(T);
-    return (double)nq >= thr * cells && grid_bytes >= ((size_t)256 << 20) && lanes * sizeof(T) >= 64;
+    if ((double)nq >= thr * cells && grid_bytes >= ((size_t)256 << 20) && lanes * sizeof(T) >= 64) return true;
+    // Smaller grids (they sit in L2 / the Infinity Cache, the gather order is not HBM-bound) with rows of 256 bytes and
+    // more: the tile order still wins -- up to 2 x -- once the batch is large enough to cover its fixed cost of staging
+    // every tile (~0.13 ms) and has two queries per cell (profiles/r06_tiles_small_grids.jsonl: 64 MB grid, 1e6 queries
+    // 0.206 -> 0.161 ms; 125 MB, 2e6: 0.38 -> 0.22; at 1 query per cell or 10 MB grids the gather order stays ahead).
+    // Found by tests/test_gpu_auto_guard.py.
+    return (double)nq >= 2.0 * cells && nq >= 800000 && lanes * sizeof(T) >= 256 && (lanes * sizeof(T)) % 16 == 0 && !pair_packed &&
+           grid_bytes >= ((size_t)20 << 20);
   }
 
   void launch_eval(hipStream_t s, Scratch& sc, const Plan2& P) {
@@ -3070,7 +3008,7 @@ struct Interp2DImpl final : Interp2DBase {
       // large batches: bucket indices behind the pyramids (as the two-axis search stages them), and from two values per
       // query the shared-divisor division (two reciprocals per query instead of three divisions per value: same bits)
       size_t shm = both;
-      static const int lut_env = [] { const char* e = std::getenv("NDI_LOCATE_LUT"); return e ? std::atoi(e) : 1; }();
+      constexpr int lut_env = 1;   // (the bucket index: A/B settled in round 3)
       if (lut_env && nq >= 4096) {
         px.ensure_bucket_index();
         py.ensure_bucket_index();
@@ -3114,10 +3052,8 @@ struct Interp2DImpl final : Interp2DBase {
       if (std::getenv("NDI_TRACE_PLAN"))
         std::fprintf(stderr, "[ndi plan] slopes2d L=%llu recs=%s tb=%u grid=%u lds=%zu prepass=%d\n", (unsigned long long)lanes,
                      slopes_cells() ? "cell" : "point", P.f_tb, P.f_grid, P.f_lds, P.l_check ? 0 : 1);
-      static const bool tune_live6 = std::getenv("NDI_TUNE_LIVE") != nullptr;
-      static const int wide_once = ShortKnobs::env("NDI_SLOPES2D_WIDE", 1);     // A/B: 0 = direct stores of one value per lane
-      const int wide_env = tune_live6 ? ShortKnobs::env("NDI_SLOPES2D_WIDE", 1) : wide_once;
-      const int contig = P.out_stride != lanes ? 0 : (wide_env && aligned16(P.out) && P.f_lds_wide) ? 2 : 1;
+      // rows leave as 16-byte vectors through a wave-private strip when the buffer allows it (+2-6 % over one value per lane)
+      const int contig = P.out_stride != lanes ? 0 : (aligned16(P.out) && P.f_lds_wide) ? 2 : 1;
       const int mk = (int)std::max(px.dlut.lut ? px.dlut.maxk : 0u, py.dlut.lut ? py.dlut.maxk : 0u) <= 4 ? 4 : 8;
 #define NDI_SL2K(LCS, MKS, CT)                                                            \
   do {                                                                                    \
@@ -3135,7 +3071,7 @@ struct Interp2DImpl final : Interp2DBase {
         default:
           if constexpr (sizeof(T) == 4) {
             switch ((int)lanes) {
-              NDI_SL2(9); NDI_SL2(10); NDI_SL2(11); NDI_SL2(12); NDI_SL2(13); NDI_SL2(14); NDI_SL2(15); NDI_SL2(16);
+              NDI_SL2(9); NDI_SL2(10); NDI_SL2(11); NDI_SL2(12);
               default: break;
             }
           }
@@ -3255,12 +3191,9 @@ struct Interp2DImpl final : Interp2DBase {
       const bool split2 = split_env != 0 && slope_env0 != 0 && lv_full >= 2 && lv_full % 2 == 0 &&
                           s1 * s1 * (lv_full / 2) <= 5 * 512 && 512 % (lv_full / 2) == 0 &&
                           2 * (shm_half + static512s) <= 160 * 1024;
-      // NDI_TILE_SPLIT=4 (A/B): four 256-thread workgroups per CU, a quarter of the trailing axis each
-      const size_t shm_quarter = (s1 * s1 + (s1 - 1) * s1) * (lanes / 4) * sizeof(T) + 5 * s1 * sizeof(T) + 16;
-      const bool split4 = split_env == 4 && slope_env0 != 0 && lv_full >= 4 && lv_full % 4 == 0 &&
-                          s1 * s1 * (lv_full / 4) <= 5 * 256 && 256 % (lv_full / 4) == 0 && ((lv_full / 4) & (lv_full / 4 - 1)) == 0 &&
-                          4 * (shm_quarter + static512s) <= 160 * 1024;
-      A.ch_split = split4 ? 4u : (split2 ? 2u : 1u);
+      // (Four quarter-row workgroups per CU were measured slower -- 1.05-1.08 vs 0.77-0.85 ms at C3: 64-byte half-line stores,
+      //  four decodes per record -- and are gone: profiles/r05_tuning.md 2.)
+      A.ch_split = split2 ? 2u : 1u;
       {   // item -> (grid row, vector) of the tile staging: ceil(2^32 / vectors per tile row), full and last-column tiles
         const uint64_t lvv = lv_full / A.ch_split;
         const uint64_t full = (((uint64_t)1 << P.ts) + 1) * lvv;
@@ -3301,20 +3234,6 @@ struct Interp2DImpl final : Interp2DBase {
   } while (0)
       if (std::getenv("NDI_TRACE_PLAN"))
         std::fprintf(stderr, "[ndi plan] tiles ts=%u split=%u compact=%d grid=%u\n", P.ts, A.ch_split, (int)P.compact, gx);
-      if (split4) {
-        if constexpr (std::is_same<T, float>::value) {
-          if (P.compact) {
-            auto kern = eval_bilinear_tiles_kernel<T, VNt, 256, 256, 5, true, true>;
-            allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(40 * 1024 - 256 * (16 + 2 * sizeof(T)) - 512));
-            launch1<T>(s, PC_EVAL, dim3(gx), dim3(256), shm_quarter, kern, A);
-            return;
-          }
-        }
-        auto kern = eval_bilinear_tiles_kernel<T, VNt, 256, 256, 5, false, true>;
-        allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)(40 * 1024 - 256 * (16 + 2 * sizeof(T)) - 512));
-        launch1<T>(s, PC_EVAL, dim3(gx), dim3(256), shm_quarter, kern, A);
-        return;
-      }
       if (split2) {
         if constexpr (std::is_same<T, float>::value) {
           if (P.compact) {
@@ -3350,7 +3269,7 @@ struct Interp2DImpl final : Interp2DBase {
     const uint64_t LV = vec_ok ? lanes / VN : lanes;
     // knots in LDS: both axes must fit next to each other with two 1024-thread workgroups per CU, and the batch
     // must be large enough to amortise the staging
-    static const int klds_env = [] { const char* e = std::getenv("NDI_BILINEAR_KLDS"); return e ? std::atoi(e) : -1; }();
+    constexpr int klds_env = -1;
     const size_t knot_bytes = (size_t)(nx + ny) * sizeof(T);
     bool klds = vec_ok && knot_bytes <= 72 * 1024 && nq >= (1u << 20);
     if (klds_env >= 0) klds = klds_env != 0 && vec_ok && knot_bytes <= LDS_STAGE_LIMIT;
@@ -3367,7 +3286,7 @@ struct Interp2DImpl final : Interp2DBase {
       // the IEEE divisions.  Same bits either way.
       allow_dynamic_lds(reinterpret_cast<const void*>(&eval_bilinear_kernel<T, VN, false, 2, TB, true>), (int)LDS_STAGE_LIMIT);
       allow_dynamic_lds(reinterpret_cast<const void*>(&eval_bilinear_kernel<T, VN, false, 2, TB, true, true>), (int)LDS_STAGE_LIMIT);
-      static const int sdiv_env = [] { const char* e = std::getenv("NDI_BILINEAR_SDIV"); return e ? std::atoi(e) : -1; }();   // A/B
+      constexpr int sdiv_env = -1;
       const bool sdiv = sdiv_env >= 0 ? sdiv_env != 0 : pair_packed;
       if (sdiv)
         hipLaunchKernelGGL((eval_bilinear_kernel<T, VN, false, 2, TB, true, true>), dim3(gx), dim3(TB), (knot_bytes + 15) & ~(size_t)15, s, A, tile_q);

@@ -43,7 +43,6 @@ VARIANTS = [
     {},                                   # what ships (the control of this harness): two half-row workgroups per CU
     {"NDI_TILE_SPLIT": "0"},              # one 1024-thread workgroup per CU staging whole rows (round 4's launch)
     {"NDI_TILE_SPLIT": "0", "NDI_GROUP_BLOCKS": "32"},
-    {"NDI_TILE_SPLIT": "4"},              # four 256-thread workgroups per CU, a quarter of the trailing axis each
     {"NDI_TILE_SLOPES": "0"},
     {"NDI_TILE_WG": "512", "NDI_TILE_SLOPES": "0"},
     {"NDI_TILE_TS": "2"},

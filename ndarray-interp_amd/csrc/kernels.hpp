@@ -4522,6 +4522,195 @@ __global__ __launch_bounds__(64) void spline_build_general_kernel(BuildArgs<T> A
   }
 }
 
+// WIDE trailing axes (round 6; BASELINE configs[1]: 4096 knots x 4096 lanes): the serial kernel above runs ONE wave per 64
+// lanes -- 64 waves on 256 CUs at C2 -- and that wave does everything: it waits for its own loads (16 rows in flight),
+// and a separate pass has to write every right-hand side to memory first and read it back (1.06 GB moved for 0.40 GB of
+// data in / tables out at 0.05 of the HBM peak: profiles/r05_pmc_hbm_counters.txt).  Here a workgroup of four waves owns
+// the 64 lanes: waves 1-3 PRODUCE a block of RB rows ahead -- forward: the right-hand sides (spline_rhs_at, the same
+// function, two divisions per element, no serial dependency) straight into LDS, never to memory; backward: the eliminated
+// right-hand sides and the data rows, and per row up / mid' / RN(1 / mid') / dx -- while wave 0 CONSUMES the previous
+// block out of LDS: the recurrence alone (cubic_spline.rs:690-702, 711-720) and the a / b epilogue (:354-365), one
+// barrier per block; every wave requests a whole block's operands before it computes (RW rows per producer wave).  Per element the operations and their order are those of spline_build_general_kernel; the back
+// substitution's division by mid'[i] -- one divisor for all lanes of a row -- is the correctly rounded shared-divisor
+// division (div_shared_fast: the bits of the IEEE division, which is redone when an operand leaves the exponent window).
+// Bit-identical tables (test_spline_coefficients_bit_exact runs both kernels).  LDS: 2 x RB x 64 x 2 values + factors.
+template <class T, int RW>      // RW rows per producer wave and block; a block is RB = 3 RW rows
+__global__ __launch_bounds__(256) void spline_build_wide_kernel(BuildArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int RB = 3 * RW;
+  T* const s_r = reinterpret_cast<T*>(smem_raw);                       // [2][RB][64]
+  T* const s_y = s_r + 2 * RB * 64;                                    // [2][RB][64]
+  T* const s_f = s_y + 2 * RB * 64;                                    // [2][4][RB]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint64_t n = A.n, L = A.lanes;
+  const uint64_t l0 = (uint64_t)blockIdx.x * 64u, l = l0 + lane;
+  const bool live = l < L;
+  const uint64_t lc = live ? l : L - 1u;                               // (loads of the padding lanes stay inside the rows)
+  const T* __restrict__ const y = A.data;
+  T* const sa = A.ca;
+  T* const sb = A.cb;
+  const T three = T(3);
+  // ---- forward elimination, rows 1 .. n-2 (row 0's right-hand side stays as it is)
+  const uint64_t nblk = (n - 2 + RB - 1) / RB;
+  // producer wave pw (0 .. 2): interior rows i0 + pw RW .. + RW - 1 of this lane: RW + 2 data rows and RW + 1 spacings
+  // requested together, then the right-hand sides (cubic_spline.rs:456-471, spline_rhs_at's interior branch verbatim)
+  auto produce_fwd = [&](uint32_t buf, uint64_t i0) {
+    const uint32_t pw = wave - 1u;
+    const uint64_t r0 = i0 + (uint64_t)pw * RW;                        // first row of this wave
+    T yv[RW + 2], dv[RW + 1];
+#pragma unroll
+    for (int k = 0; k < RW + 2; ++k) {
+      const uint64_t row = r0 - 1 + (uint64_t)k;
+      yv[k] = y[(row < n ? row : n - 1) * L + lc];
+    }
+#pragma unroll
+    for (int k = 0; k < RW + 1; ++k) {
+      const uint64_t row = r0 - 1 + (uint64_t)k;
+      dv[k] = A.dx[row < n - 1 ? row : n - 2];
+    }
+    T* const r = s_r + (size_t)buf * RB * 64 + (size_t)pw * RW * 64;
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const T a0 = yv[k], a1 = yv[k + 1], a2 = yv[k + 2];
+      const T dxn = dv[k + 1], dxn_1 = dv[k];
+      r[k * 64 + lane] = three * (dxn * (a1 - a0) / dxn_1 + dxn_1 * (a2 - a1) / dxn);   // (rows beyond n-2: never consumed)
+    }
+    if (lane < (uint32_t)RW) {
+      const uint64_t row = r0 + lane;
+      s_f[(size_t)buf * 4 * RB + pw * RW + lane] = A.w[row < n ? row : n - 1];
+    }
+  };
+  T r_prev = T(0);
+  if (wave == 0) {
+    r_prev = spline_rhs_at<T, false, false>(A, 0, lc);
+    if (live) sa[l] = r_prev;
+  } else if (nblk) {
+    produce_fwd(0u, 1u);
+  }
+  __syncthreads();
+  for (uint64_t blk = 0; blk < nblk; ++blk) {
+    const uint64_t i0 = 1u + blk * RB;
+    const uint32_t buf = (uint32_t)(blk & 1u);
+    if (wave != 0) {
+      if (blk + 1 < nblk) produce_fwd(buf ^ 1u, i0 + RB);
+    } else {
+      const uint64_t left = n - 1 - i0;
+      const T* const r = s_r + (size_t)buf * RB * 64;
+      const T* const wf = s_f + (size_t)buf * 4 * RB;
+      if (left >= (uint64_t)RB) {                                      // a full block: operands first, then the chain
+        T rv[RB], wv[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          rv[b] = r[b * 64 + lane];
+          wv[b] = wf[b];
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          const T rr = rv[b] - wv[b] * r_prev;                         // cubic_spline.rs:699-701
+          rv[b] = rr;
+          r_prev = rr;
+        }
+        if (live) {
+#pragma unroll
+          for (int b = 0; b < RB; ++b) sa[(i0 + (uint64_t)b) * L + l] = rv[b];
+        }
+      } else {
+        for (int b = 0; b < (int)left; ++b) {
+          const T rr = r[b * 64 + lane] - wf[b] * r_prev;
+          if (live) sa[(i0 + (uint64_t)b) * L + l] = rr;
+          r_prev = rr;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- last row, then the back substitution fused with a / b, rows n-2 .. 0
+  const uint64_t bblk = (n - 1 + RB - 1) / RB;
+  auto produce_bwd = [&](uint32_t buf, uint64_t hi) {                  // rows hi-1, hi-2, ..., at most RB of them
+    const uint32_t pw = wave - 1u;
+    T* const r = s_r + (size_t)buf * RB * 64 + (size_t)pw * RW * 64;
+    T* const yy = s_y + (size_t)buf * RB * 64 + (size_t)pw * RW * 64;
+    T rv[RW], yv[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const uint64_t b = (uint64_t)pw * RW + (uint64_t)k;
+      const uint64_t i = b < hi ? hi - 1 - b : 0;
+      rv[k] = sa[i * L + lc];
+      yv[k] = y[i * L + lc];
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      r[k * 64 + lane] = rv[k];
+      yy[k * 64 + lane] = yv[k];
+    }
+    if (lane < (uint32_t)RW) {
+      const uint64_t b = (uint64_t)pw * RW + lane;
+      const uint64_t i = b < hi ? hi - 1 - b : 0;
+      T* const f = s_f + (size_t)buf * 4 * RB;
+      const SharedDivisor<T> sd = shared_divisor<T>(A.midp[i]);
+      f[0 * RB + b] = A.up[i];
+      f[1 * RB + b] = sd.d;
+      f[2 * RB + b] = sd.ok ? sd.r : T(0);
+      f[3 * RB + b] = A.dx[i];
+    }
+  };
+  T k_next = T(0), y_hi = T(0);
+  if (wave == 0) {
+    const T rhs_last = spline_rhs_at<T, false, false>(A, n - 1, lc);
+    const T r_last = rhs_last - A.w[n - 1] * r_prev;
+    k_next = r_last / A.midp[n - 1];                                   // :704-708
+    y_hi = y[(n - 1) * L + lc];
+  } else {
+    produce_bwd(0u, n - 1);
+  }
+  __syncthreads();
+  auto back_row = [&](uint64_t i, T ri, T yl, T up, T mid, T rmid, T dxi) {
+    SharedDivisor<T> sd;
+    sd.d = mid; sd.r = rmid; sd.ok = rmid > T(0);
+    const T num = ri - up * k_next;
+    bool ok;
+    T k = div_shared_fast<T>(num, sd, ok);
+    if (__builtin_expect(!ok, 0)) k = num / mid;                       // :716-718
+    const T dy = y_hi - yl;
+    if (live) {
+      sa[i * L + l] = k * dxi - dy;                                    // :354-365
+      sb[i * L + l] = dy - k_next * dxi;
+    }
+    k_next = k;
+    y_hi = yl;
+  };
+  for (uint64_t blk = 0; blk < bblk; ++blk) {
+    const uint64_t hi = n - 1 - blk * RB;
+    const uint32_t buf = (uint32_t)(blk & 1u);
+    if (wave != 0) {
+      if (blk + 1 < bblk) produce_bwd(buf ^ 1u, hi - RB);
+    } else {
+      const T* const r = s_r + (size_t)buf * RB * 64;
+      const T* const yy = s_y + (size_t)buf * RB * 64;
+      const T* const f = s_f + (size_t)buf * 4 * RB;
+      if (hi >= (uint64_t)RB) {
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {                                  // RW rows at a time: operands first, then the chain
+          T rv[RW], yv[RW], fu[RW], fm[RW], fr[RW], fd[RW];
+#pragma unroll
+          for (int k = 0; k < RW; ++k) {
+            const int b = h * RW + k;
+            rv[k] = r[b * 64 + lane]; yv[k] = yy[b * 64 + lane];
+            fu[k] = f[0 * RB + b]; fm[k] = f[1 * RB + b]; fr[k] = f[2 * RB + b]; fd[k] = f[3 * RB + b];
+          }
+#pragma unroll
+          for (int k = 0; k < RW; ++k) back_row(hi - 1 - (uint64_t)(h * RW + k), rv[k], yv[k], fu[k], fm[k], fr[k], fd[k]);
+        }
+      } else {
+        for (int b = 0; b < (int)hi; ++b)
+          back_row(hi - 1 - (uint64_t)b, r[b * 64 + lane], yy[b * 64 + lane], f[0 * RB + b], f[1 * RB + b], f[2 * RB + b], f[3 * RB + b]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // The whole build of a SMALL system in one workgroup (the reference's own bench shape (100, 5), benches/bench_interp1d.rs:
 // 82-86: 500 values): data and right-hand sides live in LDS.  Phase A, all threads: every right-hand side (spline_rhs_at: the
 // boundary rows :597-670 and the interior rows :456-471, two divisions each) -- the part of the work that has no serial

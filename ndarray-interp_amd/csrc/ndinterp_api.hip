@@ -1203,6 +1203,19 @@ struct Interp1DImpl final : Interp1DBase {
     }
     switch (P.mode) {
       case SPLINE_GENERAL: {
+        // Wide trailing axes: four waves per 64 lanes, the right-hand sides never leave the chip (spline_build_wide_kernel).
+        // NDI_SPLINE_WIDE=0 / 1: A/B (1 takes it for every width).
+        static const bool tune_live_w = std::getenv("NDI_TUNE_LIVE") != nullptr;
+        static const int wide_once = ShortKnobs::env("NDI_SPLINE_WIDE", -1);
+        const int wide_env = tune_live_w ? ShortKnobs::env("NDI_SPLINE_WIDE", -1) : wide_once;
+        if (!A.kout && n >= 4 && (wide_env > 0 || (wide_env < 0 && lanes >= 1024))) {
+          constexpr int RW = 16, RBW = 3 * RW;       // rows per producer wave / per block
+          const size_t shm = (size_t)(4 * RBW * 64 + 2 * 4 * RBW) * sizeof(T);
+          auto kern = spline_build_wide_kernel<T, RW>;
+          allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)shm);
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, A);
+          break;
+        }
         const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * lanes + BLOCK - 1) / BLOCK, 65536));
         hipLaunchKernelGGL((spline_rhs_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, s, A);
         if (A.kout) hipLaunchKernelGGL((spline_build_general_kernel<T, false, true>), dim3(grid), dim3(64), 0, s, A);

@@ -559,6 +559,7 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
                 owned_info.append(o.ndi_output_info)
                 owned.append(time_into(o))
                 del o
+                pkg.output_trim()                 # (a kept buffer would be handed out again: every candidate is a fresh allocation here)
         kms, wall, prof = runs[0]                  # the FIRST allocation, no selection
         ntab = x.size + (2 * (x.size - 1) if strat_name == "cubic" else 0)
         comp = nq * lanes * el + ntab * lanes * el + nq * 16
@@ -782,7 +783,7 @@ def secondary_legs(pkg, torch, dev):
     detail = {"short_rows": short_rows_leg(pkg, torch, dev),
               "reference_shapes_2d": reference_shapes_2d_leg(pkg, torch, dev),
               "c2_knot_families_and_sorted_queries": c2_variants_leg(pkg, torch, dev)}
-    sec = {"detail_line": "the JSON line before this one ({\"detail\": ...}) carries short_rows (+ reference_shapes) and reference_shapes_2d"}
+    sec = {"detail_line": "the stdout line before this one (prefix `detail `, then JSON) carries short_rows (+ reference_shapes), reference_shapes_2d and the knot-family / sorted-query runs"}
     sec["reference_shapes_summary"] = reference_summary(detail)
     sec["host_path"] = host_path_leg(pkg, torch, dev)
     sec.update(long_rows_leg(pkg, torch, dev, traffic_store))
@@ -1170,7 +1171,10 @@ def run_target(args, pkg, torch, dist, dev, rank, world):
         progress("secondary legs: C3, C5 share, C1")
         line["secondary"], detail = secondary_legs(pkg, torch, dev)
         line["config"]["secondary_summary"] = secondary_summary(line["secondary"])
-        print(json.dumps({"detail": "tables of the secondary legs (the contract line follows as the LAST line)", **detail}), flush=True)
+        # The contract is ONE JSON line on stdout.  The long tables go out first, on a line that carries a `detail ` prefix and is
+        # therefore NOT a JSON line to any parser -- the contract line stays the only JSON line and the last line of the output.
+        print("detail " + json.dumps({"detail": "tables of the secondary legs (the contract line follows as the LAST line)", **detail}),
+              flush=True)
         if pkg.device_count() >= 2 or args.sharded_leg_devices:
             progress("in-process sharded leg over the visible devices")
             leg = in_process_sharded_leg(args, pkg, torch, x, y)

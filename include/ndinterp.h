@@ -393,9 +393,13 @@ ndi_status ndi_validate2d(int32_t dtype, const void* host_x, uint64_t x_len, con
  * the zero fill is timed and a slowly filling buffer is set aside for another candidate, up to `max_tries` (0 = as many as
  * fit into half of the free memory, 2 .. 8; buffers under 1 GiB: 1), while the device has room; the best candidate is returned, the others are freed.  `info` (may be NULL)
  * reports what happened.  Free with ndi_output_free (NDI_BAD_ARG for any other pointer).  The mirrors' interp_array uses
- * it for device outputs of >= 1 GiB; interp_array_into never allocates. */
+ * it for device outputs of >= 1 GiB; interp_array_into never allocates.
+ * ndi_output_free keeps up to two freed buffers of >= 1 GiB (together at most a third of the device's memory) for the next
+ * request of the same size on the same device -- a fresh 32.8 GB allocation costs the allocator 0.7-1.4 s, a caller that
+ * evaluates batch after batch would pay it on every call -- and ndi_output_alloc hands such a buffer out again, zeroed
+ * (info->tries == 0).  ndi_output_trim releases the kept buffers. */
 typedef struct ndi_output_info {
-  uint32_t tries;          /* candidates allocated and filled */
+  uint32_t tries;          /* candidates allocated and filled (0: a buffer kept by ndi_output_free was reused) */
   uint32_t reserved;
   double fill_tbps;        /* zero-fill rate of the buffer returned, TB/s */
   double worst_fill_tbps;  /* ... of the slowest candidate seen */
@@ -403,6 +407,7 @@ typedef struct ndi_output_info {
 } ndi_output_info;
 ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max_tries, void** out, ndi_output_info* info);
 ndi_status ndi_output_free(void* p);
+ndi_status ndi_output_trim(void);
 
 /* ---- runtime ------------------------------------------------------------------ */
 int32_t ndi_device_count(void);

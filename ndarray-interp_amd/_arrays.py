@@ -113,6 +113,11 @@ class _OwnedOutput:
 OUTPUT_OWNED_MIN_BYTES = 1 << 30
 
 
+def output_trim() -> None:
+    """Release the output buffers ndi_output_free keeps for reuse (ndi_output_trim)."""
+    _capi.lib().ndi_output_trim()
+
+
 def output_empty(shape, dtype=np.float64, device: int = 0, max_tries: int = 0):
     """A library-owned device output buffer (ndi_output_alloc: the reference's Array::zeros, interp1d/mod.rs:209, with the
     placement check of include/ndinterp.h) as a torch tensor of `shape`.  `tensor.ndi_output_info` tells how many candidates

@@ -132,6 +132,7 @@ SYMBOLS = {
     "ndi_validate2d": (C.c_int, [C.c_int32, _P, C.c_uint64, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "ndi_output_alloc": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(_P), C.POINTER(OutputInfo)]),
     "ndi_output_free": (C.c_int, [_P]),
+    "ndi_output_trim": (C.c_int, []),
     "ndi_device_count": (C.c_int32, []),
     "ndi_last_error_string": (C.c_char_p, []),
     "ndi_version": (C.c_uint32, []),

@@ -4719,6 +4719,17 @@ namespace ndi {
 struct OutputRegistry {
   std::mutex mu;
   std::unordered_map<void*, std::pair<int, size_t>> live;   // ptr -> (device, bytes)
+  // Freed buffers kept for the next request of the same size on the same device (a caller that evaluates batch after
+  // batch through interp_array would otherwise pay the allocator -- seconds for tens of gigabytes -- on every call, where a
+  // caching allocator pays it once): at most two, and together at most a third of the device's memory; ndi_output_trim
+  // releases them.  Their fill rate is known, so a cached buffer is taken without another search.
+  struct Spare { void* p; int dev; size_t bytes; double rate; };
+  std::vector<Spare> spare;
+  std::unordered_map<void*, double> rate;                    // fill rate of the live buffers (TB/s)
+  void rates_set(void* p, double r) {
+    std::lock_guard<std::mutex> g(mu);
+    rate[p] = r;
+  }
 };
 static OutputRegistry& output_registry() {
   static OutputRegistry r;
@@ -4763,6 +4774,37 @@ NDI_API ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max
   NDI_HIP(hipEventCreate(&ea));
   NDI_HIP(hipEventCreate(&eb));
   struct Ev { hipEvent_t a, b; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{ea, eb};
+  {   // a kept buffer of this size on this device: zero it again and hand it out
+    auto& R = ndi::output_registry();
+    void* hit = nullptr;
+    double rate = 0.0;
+    {
+      std::lock_guard<std::mutex> g(R.mu);
+      for (size_t i = 0; i < R.spare.size(); ++i)
+        if (R.spare[i].dev == device && R.spare[i].bytes == (size_t)bytes) {
+          hit = R.spare[i].p;
+          rate = R.spare[i].rate;
+          R.spare.erase(R.spare.begin() + (long)i);
+          break;
+        }
+    }
+    if (hit) {
+      const double ms = ndi::timed_zero_fill(hit, bytes, ea, eb);
+      {
+        std::lock_guard<std::mutex> g(R.mu);
+        R.live[hit] = {device, (size_t)bytes};
+      }
+      R.rates_set(hit, rate);
+      if (info) {
+        info->tries = 0;                                         // 0: a kept buffer, no candidate was allocated
+        info->fill_tbps = (double)bytes / (ms * 1e-3) / 1e12;
+        info->worst_fill_tbps = info->fill_tbps;
+        info->alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+      }
+      *out = hit;
+      return NDI_OK;
+    }
+  }
   std::vector<std::pair<void*, double>> cand;   // (pointer, TB/s of its zero fill)
   auto free_all_but = [&](void* keep) {
     for (auto& c : cand)
@@ -4800,6 +4842,7 @@ NDI_API ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max
     auto& R = ndi::output_registry();
     std::lock_guard<std::mutex> g(R.mu);
     R.live[best] = {device, (size_t)bytes};
+    R.rate[best] = best_rate;
   }
   if (info) {
     info->tries = (uint32_t)cand.size();
@@ -4817,16 +4860,64 @@ NDI_API ndi_status ndi_output_free(void* p) {
   if (!p) return NDI_OK;
   NDI_TRY
   int dev = -1;
+  size_t bytes = 0;
+  double rate = 0.0;
+  void* evict = nullptr;
+  int evict_dev = -1;
   {
     auto& R = ndi::output_registry();
     std::lock_guard<std::mutex> g(R.mu);
     auto it = R.live.find(p);
     if (it == R.live.end()) return ndi::fail(NDI_BAD_ARG, "pointer was not returned by ndi_output_alloc");
     dev = it->second.first;
+    bytes = it->second.second;
     R.live.erase(it);
+    auto ir = R.rate.find(p);
+    if (ir != R.rate.end()) { rate = ir->second; R.rate.erase(ir); }
   }
   ndi::DeviceGuard dg(dev);
-  NDI_HIP(hipFree(p));
+  // keep it for the next request of this size?  (buffers of >= 1 GiB only; two at most, a third of the device's memory)
+  static const int keep_env = ndi::ShortKnobs::env("NDI_OUTPUT_KEEP", 2);
+  bool kept = false;
+  if (keep_env > 0 && bytes >= ((size_t)1 << 30)) {
+    size_t fr = 0, tot = 0;
+    NDI_HIP(hipMemGetInfo(&fr, &tot));
+    auto& R = ndi::output_registry();
+    std::lock_guard<std::mutex> g(R.mu);
+    size_t held = bytes;
+    for (auto& sp : R.spare)
+      if (sp.dev == dev) held += sp.bytes;
+    if (held <= tot / 3) {
+      if (R.spare.size() >= (size_t)keep_env) {     // the oldest goes
+        evict = R.spare.front().p;
+        evict_dev = R.spare.front().dev;
+        R.spare.erase(R.spare.begin());
+      }
+      R.spare.push_back({p, dev, bytes, rate});
+      kept = true;
+    }
+  }
+  if (evict) {
+    ndi::DeviceGuard de(evict_dev);
+    NDI_HIP(hipFree(evict));
+  }
+  if (!kept) NDI_HIP(hipFree(p));
+  return NDI_OK;
+  NDI_CATCH
+}
+
+NDI_API ndi_status ndi_output_trim(void) {
+  NDI_TRY
+  std::vector<ndi::OutputRegistry::Spare> gone;
+  {
+    auto& R = ndi::output_registry();
+    std::lock_guard<std::mutex> g(R.mu);
+    gone.swap(R.spare);
+  }
+  for (auto& sp : gone) {
+    ndi::DeviceGuard dg(sp.dev);
+    NDI_HIP(hipFree(sp.p));
+  }
   return NDI_OK;
   NDI_CATCH
 }

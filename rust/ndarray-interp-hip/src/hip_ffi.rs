@@ -350,6 +350,7 @@ extern "C" {
         info: *mut ndi_output_info,
     ) -> i32;
     pub fn ndi_output_free(p: *mut c_void) -> i32;
+    pub fn ndi_output_trim() -> i32;
     pub fn ndi_device_count() -> i32;
     pub fn ndi_last_error_string() -> *const c_char;
     pub fn ndi_version() -> u32;

@@ -12,15 +12,15 @@ from conftest import ROOT
 
 
 def _one_json_line(stdout):
-    """The contract line: the LAST JSON line of the output; any JSON line before it is a `detail` line (the secondary
-    legs' long tables, printed first so that the contract line -- with the BASELINE configs at its end -- stays last)."""
-    lines = [l for l in stdout.splitlines() if l.startswith("{")]
-    assert lines, stdout
-    for l in lines[:-1]:
-        assert "detail" in json.loads(l), l[:200]
-    line = json.loads(lines[-1])
-    assert "detail" not in line
-    return line
+    """The contract: exactly ONE JSON line on stdout, and it is the last line.  The secondary legs' long tables go out before
+    it on a line prefixed `detail ` (JSON behind the prefix), which no JSON-lines parser takes for a result."""
+    all_lines = [l for l in stdout.splitlines() if l.strip()]
+    lines = [l for l in all_lines if l.startswith("{")]
+    assert len(lines) == 1 and all_lines[-1] == lines[0], stdout[-2000:]
+    for l in all_lines:
+        if l.startswith("detail "):
+            assert "detail" in json.loads(l[len("detail "):])
+    return json.loads(lines[0])
 
 
 def _run(args, timeout=240):

@@ -29,6 +29,29 @@ def test_output_alloc_zeroed_and_freed(pkg):
             assert info.tries == 1
         assert lib.ndi_output_free(p) == cap.OK
         assert lib.ndi_output_free(p) == cap.BAD_ARG          # already gone
+    # a freed buffer of >= 1 GiB is kept and handed out again for the same size (tries == 0), zeroed; trim releases it
+    big = (1 << 30) + 4096
+    p1 = ctypes.c_void_p(); info = cap.OutputInfo()
+    assert lib.ndi_output_trim() == cap.OK
+    assert lib.ndi_output_alloc(0, big, 1, ctypes.byref(p1), ctypes.byref(info)) == cap.OK and info.tries == 1
+    import torch
+    view = torch.as_tensor(type("V", (), {"__cuda_array_interface__": {"shape": (1024,), "typestr": "<f8", "data": (p1.value, False),
+                                                                       "version": 2, "strides": None}})(), device="cuda:0")
+    view.fill_(7.0)
+    torch.cuda.synchronize()
+    del view
+    assert lib.ndi_output_free(p1) == cap.OK
+    p2 = ctypes.c_void_p()
+    assert lib.ndi_output_alloc(0, big, 1, ctypes.byref(p2), ctypes.byref(info)) == cap.OK
+    assert info.tries == 0 and p2.value == p1.value
+    view = torch.as_tensor(type("V", (), {"__cuda_array_interface__": {"shape": (1024,), "typestr": "<f8", "data": (p2.value, False),
+                                                                       "version": 2, "strides": None}})(), device="cuda:0")
+    assert bool((view == 0).all())
+    del view
+    assert lib.ndi_output_free(p2) == cap.OK and lib.ndi_output_trim() == cap.OK
+    p3 = ctypes.c_void_p()
+    assert lib.ndi_output_alloc(0, big, 1, ctypes.byref(p3), ctypes.byref(info)) == cap.OK and info.tries == 1
+    assert lib.ndi_output_free(p3) == cap.OK and lib.ndi_output_trim() == cap.OK
     assert lib.ndi_output_free(ctypes.c_void_p(0x1000)) == cap.BAD_ARG
     assert lib.ndi_output_free(None) == cap.OK
     p = ctypes.c_void_p()

@@ -126,3 +126,44 @@ def test_slopes_2d_auto_takes_the_bench_shape(pkg, capfd, dt):
     sel = rng.choice(Q, 50_000, replace=False)
     ref = oracle.interp2d_bilinear(x, y, g, qx.cpu().numpy()[sel], qy.cpu().numpy()[sel])[3].reshape(-1, 5)
     check_equal(got.reshape(Q, 5)[sel], ref, "slopes2d auto 100x100x5")
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_slopes_2d_first_use_inside_the_ring_and_sharded(pkg, capfd, dt):
+    """The slope-record copy is built lazily, on the stream that first needs it.  Here the handle's FIRST evaluation is a ring
+    evaluation (Interp2D::interp_array through ndi_interp2d_eval_ring: search / pre-pass of chunk k + 1 on the side stream,
+    evaluation on the caller's), chunks large enough for AUTO to take the slope-record kernel; then one sharded call over two
+    replicas on the device, with a failing query (first-error over the whole batch: interp2d/mod.rs:297-306)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(21)
+    nx, ny, C, Q, chunk = 120, 90, 5, 800_000, 200_000
+    x = knots("rand", nx, rng, dt); y = knots("jit", ny, rng, dt)
+    g = rng.uniform(-1, 1, (nx, ny, C)).astype(dt)
+    qx = rng.uniform(x[0], x[-1], Q).astype(dt); qy = rng.uniform(y[0], y[-1], Q).astype(dt)
+    ref = oracle.interp2d_bilinear(x, y, g, qx, qy)[3].reshape(Q, C)
+    it = pkg.Interp2DBuilder.new(torch.as_tensor(g, device=dev)).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
+    got = np.zeros_like(ref)
+
+    def consumer(c, rows):
+        got[c.q_begin:c.q_begin + c.q_count] = rows.cpu().numpy()
+    os.environ["NDI_TRACE_PLAN"] = "1"
+    capfd.readouterr()
+    try:
+        slots = [torch.empty((chunk, C), dtype=_tdt(dt), device=dev) for _ in range(2)]
+        it.interp_array_ring(torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev), chunk, consumer, slots=slots)
+    finally:
+        os.environ.pop("NDI_TRACE_PLAN", None)
+    plans = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("[ndi plan]")]
+    assert sum(" slopes2d L=5 " in p for p in plans) == 4, plans
+    check_equal(got, ref, "slopes2d, first use inside the ring")
+    reps = [it] + it.replicate([0])
+    out = np.full_like(ref, -2.0)
+    pkg.sharding.interp_array_sharded(reps, qx, qy, out=out)
+    check_equal(out, ref, "slopes2d, sharded over two replicas")
+    qx2 = qx.copy(); qx2[600_123] = x[-1] + 1
+    out2 = np.full_like(ref, -2.0)
+    with pytest.raises(pkg.InterpolateError.OutOfBounds) as ei:
+        pkg.sharding.interp_array_sharded(reps, qx2, qy, out=out2)
+    assert (ei.value.index, ei.value.axis) == (600_123, 0)
+    assert np.array_equal(out2[:600_123], ref[:600_123]) and np.all(out2[600_123:] == -2.0)

@@ -787,12 +787,14 @@ __device__ __forceinline__ V div_shared(V n, const SharedDivisor<T>& s) {
 // sequence -- once, behind everything else, so that several independent quotients can be formed in straight-line code.
 template <class T>
 __device__ __forceinline__ T div_shared_fast(T n, const SharedDivisor<T>& s, bool& ok) {
+  // (type-generic FMAs: `__builtin_fma` is the DOUBLE builtin -- with T = float it computed every step in f64 between two
+  //  conversions, 100 of the 360 vector instructions of the f32 slope-record kernel's loop, and rounded twice)
   const T q0 = n * s.r;
-  const T e0 = __builtin_fma(-q0, s.d, n);
-  const T q1 = __builtin_fma(e0, s.r, q0);
-  const T e1 = __builtin_fma(-q1, s.d, n);
+  const T e0 = __builtin_elementwise_fma(-q0, s.d, n);
+  const T q1 = __builtin_elementwise_fma(e0, s.r, q0);
+  const T e1 = __builtin_elementwise_fma(-q1, s.d, n);
   ok = s.ok & nums_in_window(n);
-  return __builtin_fma(e1, s.r, q1);
+  return __builtin_elementwise_fma(e1, s.r, q1);
 }
 // Linear::calc_frac (linear.rs:29-36) with the divisor's reciprocal shared across the row
 template <class T, class V>

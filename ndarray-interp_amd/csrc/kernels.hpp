@@ -4012,13 +4012,6 @@ __global__ __launch_bounds__(TB) void eval_slopes2d_kernel(EvalSlopes2Args<T> A)
 #ifdef NDI_TUNING
       if (A.debug & 1) { r1[t] = P2(T(o)); r2[t] = P2(T(o + 1u)); continue; }
 #endif
-#ifdef NDI_TUNING
-      if (A.debug & 128) {     // experiment: non-temporal (L1-bypassing?) record loads
-        r1[t] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(recs + o));
-        r2[t] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(recs + o + (uint32_t)LC * (uint32_t)sizeof(P2)));
-        continue;
-      }
-#endif
       r1[t] = *reinterpret_cast<const P2*>(recs + o);
       r2[t] = *reinterpret_cast<const P2*>(recs + o + (uint32_t)LC * (uint32_t)sizeof(P2));
     }

@@ -75,8 +75,15 @@ def _time(call, finish, torch):
     return float(np.median(ts))
 
 
-def _judge(name, t_auto, forced):
+def _judge(name, t_auto, forced, again=None):
+    """`again(key)` re-times one form (key None: AUTO).  A verdict that would fail is confirmed first: AUTO and the best forced
+    form are timed three more times each, alternating, and their minima compared -- one noisy sample must not fail the suite."""
     best_name, best = min(forced.items(), key=lambda kv: kv[1])
+    if t_auto > SLACK * best + JITTER_MS and again is not None:
+        for _ in range(3):
+            t_auto = min(t_auto, again(None))
+            forced[best_name] = min(forced[best_name], again(best_name))
+        best_name, best = min(forced.items(), key=lambda kv: kv[1])
     assert t_auto <= SLACK * best + JITTER_MS, \
         f"{name}: AUTO {t_auto:.4f} ms is {t_auto / best:.2f} x the best forced form ({best_name}: {best:.4f} ms); all: " + \
         ", ".join(f"{k}={v:.4f}" for k, v in sorted(forced.items(), key=lambda kv: kv[1]))
@@ -108,8 +115,23 @@ def test_auto_is_within_15_percent_of_the_best_forced_form_1d(pkg, name, strat, 
             with knobs(env):
                 forced[" ".join(f"{k[4:]}={v}" for k, v in env.items())] = _time(call, fin, torch)
     t_auto = min(t_auto, _time(call, fin, torch))     # (a second AUTO sample: the first one of a process pays clock ramp-up)
-    it.strategy.release()
-    _judge(name, t_auto, forced)
+    envs = {" ".join(f"{k[4:]}={v}" for k, v in env.items()): env for env in SHORT1D}
+
+    def again(key):
+        if key is None:
+            return _time(call, fin, torch)
+        if key in ("gather", "bucketed"):
+            it.strategy.path = pkg.PATH_GATHER if key == "gather" else pkg.PATH_BUCKETED
+            try:
+                return _time(call, fin, torch)
+            finally:
+                it.strategy.path = pkg.PATH_AUTO
+        with knobs(envs[key]):
+            return _time(call, fin, torch)
+    try:
+        _judge(name, t_auto, forced, again)
+    finally:
+        it.strategy.release()
 
 
 @pytest.mark.parametrize("name,dt,nx,ny,C,Q", GRID_2D, ids=[g[0] for g in GRID_2D])
@@ -138,6 +160,21 @@ def test_auto_is_within_15_percent_of_the_best_forced_form_2d(pkg, name, dt, nx,
         with knobs(env):
             forced[" ".join(f"{k[4:]}={v}" for k, v in env.items())] = _time(call, fin, torch)
     t_auto = min(t_auto, _time(call, fin, torch))
-    it.strategy.release()
-    torch.cuda.empty_cache()
-    _judge(name, t_auto, forced)
+    envs = {" ".join(f"{k[4:]}={v}" for k, v in env.items()): env for env in FORMS2D}
+
+    def again(key):
+        if key is None:
+            return _time(call, fin, torch)
+        if key in ("gather", "bucketed"):
+            it.strategy.path = pkg.PATH_GATHER if key == "gather" else pkg.PATH_BUCKETED
+            try:
+                return _time(call, fin, torch)
+            finally:
+                it.strategy.path = pkg.PATH_AUTO
+        with knobs(envs[key]):
+            return _time(call, fin, torch)
+    try:
+        _judge(name, t_auto, forced, again)
+    finally:
+        it.strategy.release()
+        torch.cuda.empty_cache()

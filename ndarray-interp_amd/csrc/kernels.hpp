@@ -4110,10 +4110,22 @@ __global__ __launch_bounds__(TB) void eval_slopes2d_kernel(EvalSlopes2Args<T> A)
 
 // ndi_output_alloc: Array::zeros (interp1d/mod.rs:209) -- the buffer is filled with zeros by 16-byte non-temporal stores; the
 // duration of this very fill is the allocator's measure of where the buffer landed in physical memory.
-__global__ __launch_bounds__(BLOCK) void zero_fill_kernel(dbl2* p, uint64_t nvec) {
+// The fill walks the buffer the way the long-row evaluation writes it -- whole rows of 32 KiB at scattered positions, a
+// workgroup per row, 16-byte non-temporal stores -- because that is the pattern whose rate depends on the buffer: a plain
+// sequential fill runs at the same 6.76 TB/s into every buffer, including those the evaluation kernel writes 25 % slower
+// (profiles/r06_fill_vs_kernel.jsonl).  Row r of the walk is row (r * mult) mod nrows, mult coprime to nrows (host).
+__global__ __launch_bounds__(BLOCK) void zero_fill_kernel(dbl2* p, uint64_t nvec, uint64_t nrows, uint64_t mult) {
+  constexpr uint64_t ROWV = 2048;   // 16-byte vectors per 32 KiB row
   const dbl2 z = {0.0, 0.0};
-  for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * BLOCK)
-    __builtin_nontemporal_store(z, p + i);
+  for (uint64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const uint64_t row = (r * mult) % nrows;
+    dbl2* const o = p + row * ROWV;
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint64_t v = (uint64_t)u * BLOCK + threadIdx.x;
+      if (row * ROWV + v < nvec) __builtin_nontemporal_store(z, o + v);
+    }
+  }
 }
 
 // Measurement aid (ndi_interp2d_probe_ceiling): the memory access mix of eval_bilinear_kernel and nothing else --

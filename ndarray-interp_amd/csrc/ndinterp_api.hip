@@ -4737,9 +4737,14 @@ static OutputRegistry& output_registry() {
 }
 static double timed_zero_fill(void* p, size_t bytes, hipEvent_t a, hipEvent_t b) {
   const uint64_t nvec = bytes / 16;
-  const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nvec + BLOCK - 1) / BLOCK, (uint64_t)cu_count() * 32));
+  const uint64_t nrows = (nvec + 2047) / 2048;
+  uint64_t mult = 2654435761ull % (nrows ? nrows : 1);         // a multiplier coprime to nrows: the walk is a permutation of the rows
+  if (mult < 2) mult = 1;
+  auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+  while (mult > 1 && gcd(mult, nrows) != 1) --mult;
+  const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nrows, (uint64_t)cu_count() * 32));
   NDI_HIP(hipEventRecord(a, nullptr));
-  hipLaunchKernelGGL(zero_fill_kernel, dim3(gr), dim3(BLOCK), 0, (hipStream_t) nullptr, (dbl2*)p, nvec);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(gr), dim3(BLOCK), 0, (hipStream_t) nullptr, (dbl2*)p, nvec, nrows, mult);
   NDI_HIP(hipGetLastError());
   if (bytes % 16) NDI_HIP(hipMemsetAsync((char*)p + nvec * 16, 0, bytes % 16, nullptr));
   NDI_HIP(hipEventRecord(b, nullptr));

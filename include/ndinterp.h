@@ -390,7 +390,8 @@ ndi_status ndi_validate2d(int32_t dtype, const void* host_x, uint64_t x_len, con
  * src/interp2d/mod.rs:183-188): a device buffer of `bytes` zero bytes for a batch's output rows.  On MI355X the rate at
  * which rows stream into a multi-gigabyte buffer depends on the physical pages behind it (4.6 .. 6.1 ms per 1e6 queries of
  * BASELINE configs[1] into buffers allocated one after the other; a property of the buffer, not of order or warm-up), so
- * the zero fill is timed and a slowly filling buffer is set aside for another candidate, up to `max_tries` (0 = as many as
+ * the zero fill -- done the way the evaluation writes, whole 32 KiB rows at scattered positions: a sequential fill is blind
+ * to the difference -- is timed and a slowly filling buffer is set aside for another candidate, up to `max_tries` (0 = as many as
  * fit into half of the free memory, 2 .. 8; buffers under 1 GiB: 1), while the device has room; the best candidate is returned, the others are freed.  `info` (may be NULL)
  * reports what happened.  Free with ndi_output_free (NDI_BAD_ARG for any other pointer).  The mirrors' interp_array uses
  * it for device outputs of >= 1 GiB; interp_array_into never allocates.

@@ -3720,8 +3720,21 @@ struct Interp2DImpl final : Interp2DBase {
   ndi_status trim() override {
     DeviceGuard dg(device);
     spaces.trim();
-    std::lock_guard<std::mutex> g(ring_own.mu);
-    ring_own.clear();
+    {
+      std::lock_guard<std::mutex> g(ring_own.mu);
+      ring_own.clear();
+    }
+    {   // the slope-record copy (up to 256 MiB) goes too when it is complete and idle; the next batch that wants it rebuilds it
+      std::lock_guard<std::mutex> g(slopes_mu);
+      int st = slopes_state.load(std::memory_order_acquire);
+      if (st == 3 && hipEventQuery(slopes_ev) == hipSuccess) st = 1;
+      if (st == 1) {
+        slopes.release();
+        slopes_state.store(0, std::memory_order_release);
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     return NDI_OK;
   }
 };

@@ -167,3 +167,36 @@ def test_slopes_2d_first_use_inside_the_ring_and_sharded(pkg, capfd, dt):
         pkg.sharding.interp_array_sharded(reps, qx2, qy, out=out2)
     assert (ei.value.index, ei.value.axis) == (600_123, 0)
     assert np.array_equal(out2[:600_123], ref[:600_123]) and np.all(out2[600_123:] == -2.0)
+
+
+def test_slopes_copy_is_released_by_trim_and_rebuilt(pkg, capfd):
+    """ndi_interp2d_trim releases the lazily built slope-record copy (2 x the grid) when it is idle; the next batch rebuilds
+    it and gives the same bits."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4)
+    nx, ny, C, Q = 400, 300, 4, 200_000
+    x = knots("rand", nx, rng, np.float64); y = knots("rand", ny, rng, np.float64)
+    g = rng.uniform(-1, 1, (nx, ny, C))
+    qx = rng.uniform(x[0], x[-1], Q); qy = rng.uniform(y[0], y[-1], Q)
+    it = pkg.Interp2DBuilder.new(torch.as_tensor(g, device=dev)).x(torch.as_tensor(x, device=dev)).y(torch.as_tensor(y, device=dev)).build()
+    ref = oracle.interp2d_bilinear(x, y, g, qx, qy)[3].reshape(Q, C)
+    qxd, qyd = torch.as_tensor(qx, device=dev), torch.as_tensor(qy, device=dev)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    with forced(capfd) as f:
+        got = it.interp_array(qxd, qyd).cpu().numpy()
+    assert " slopes2d L=4 " in f.plans[0], f.plans
+    check_equal(got.reshape(Q, C), ref, "before trim")
+    it.strategy.finish()
+    torch.cuda.synchronize()
+    held = free0 - torch.cuda.mem_get_info(dev)[0]
+    it.strategy.trim()
+    torch.cuda.synchronize()
+    after = free0 - torch.cuda.mem_get_info(dev)[0]
+    copy_bytes = (nx - 1) * ny * 2 * C * 8
+    assert held - after >= copy_bytes // 2, (held, after, copy_bytes)       # the copy (7.7 MB here) is gone
+    with forced(capfd) as f:
+        got = it.interp_array(qxd, qyd).cpu().numpy()
+    assert " slopes2d L=4 " in f.plans[0], f.plans
+    check_equal(got.reshape(Q, C), ref, "after trim")

@@ -299,8 +299,9 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False, ra
     sx, sy = (123, 96) if rank == 0 else ([123, rank], [96, rank])   # (every rank its own block of the scattered queries)
     qx = torch.as_tensor(np.random.default_rng(sx).uniform(x[0], x[-1], nq).astype(np.float32), device=dev)
     qy = torch.as_tensor(np.random.default_rng(sy).uniform(y[0], y[-1], nq).astype(np.float32), device=dev)
-    out = torch.empty((nq, C), dtype=torch.float32, device=dev)
-    step = lambda: interp.strategy.interp_array_into(interp, qx, qy, out, async_launch=True)
+    out0 = torch.empty((nq, C), dtype=torch.float32, device=dev)
+    cur = {"out": out0}
+    step = lambda: interp.strategy.interp_array_into(interp, qx, qy, cur["out"], async_launch=True)
     alg = nq * C * 20 + nq * 8                                   # 5 x 4 B per point + the query pair
 
     import ctypes
@@ -326,7 +327,9 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False, ra
             txt = tf.read().decode(errors="replace")
         return "eval_fused2d_kernel" if "[ndi plan] fused2d" in txt else "eval_bilinear_kernel"
 
-    def measure(path):
+    def measure(path, out=None):
+        out = out0 if out is None else out
+        cur["out"] = out
         interp.strategy.path = path
         for _ in range(warmup):
             step()
@@ -402,14 +405,25 @@ def bilinear_leg(pkg, torch, dev, nx, C, nq, steps=20, warmup=3, probe=False, ra
     res.update(measure(pkg.PATH_AUTO))
     if res["path"] != "gather":
         res["gather_order"] = measure(pkg.PATH_GATHER)
+    if nq * C * 4 >= pkg.OUTPUT_OWNED_MIN_BYTES:
+        # Interp2D::interp_array allocates its own output (interp2d/mod.rs:175-196); the mirror takes it from ndi_output_alloc
+        # (placement look-and-retry).  The caller-buffer figures above stay the leg's primary ones -- the first
+        # torch.empty buffer, whatever it is; this is the same batch into a library-owned buffer, as interp_array runs it.
+        lib_out = pkg.output_empty((nq, C), np.float32, dev.index or 0)
+        r = measure(pkg.PATH_AUTO, lib_out)
+        res["library_owned_output"] = {k: r[k] for k in ("kernel_ms", "locate_ms", "group_ms", "ms_per_step", "Mpoints_s", "frac") if k in r}
+        res["library_owned_output"]["alloc"] = lib_out.ndi_output_info
+        del lib_out
+        pkg.output_trim()
     if probe:      # context only (round 5): a stripped-down kernel with the same four-corner access mix -- random cells, no
         # searches, token arithmetic.  It is NOT an upper bound (its lane mapping and in-flight depth are not tuned, and the
         # product kernel has beaten it): no ratio is derived from it.  The guide's figure for this kind of access
         # (MI355X_MICROARCH.md, random rows fetched once from a table far beyond the Infinity Cache) is 5.5-5.8 TB/s.
-        res["access_mix_probe_ms"] = round(interp.strategy.probe_ceiling(out, reps=7), 4)
+        res["access_mix_probe_ms"] = round(interp.strategy.probe_ceiling(out0, reps=7), 4)
         res["access_mix_probe_note"] = "context, not a ceiling; guide: random rows fetched once 5.5-5.8 TB/s"
     interp.strategy.release()
-    del interp, qx, qy, out
+    cur.clear()
+    del interp, qx, qy, out0
     torch.cuda.empty_cache()
     return res
 
@@ -841,6 +855,9 @@ def secondary_summary(sec):
     for k in ("c3", "c5_share"):
         if k in sec:
             out[k] = pick(sec[k], "ms_per_step", "kernel_ms", "locate_ms", "group_ms", "frac", "Mpoints_s", "path", "step_minus_kernels_ms")
+            lo = sec[k].get("library_owned_output")
+            if lo:      # the same batch into a buffer from ndi_output_alloc (what interp_array writes into)
+                out[k]["library_owned_output"] = pick(lo, "ms_per_step", "kernel_ms", "frac")
     for k in ("c2", "c2_linear", "c2_f32"):
         if k in sec:
             out[k] = pick(sec[k], "ms_per_step", "kernel_ms", "frac", "kernel_ms_per_output_buffer", "kernel_ms_library_owned_outputs",

@@ -12,7 +12,7 @@ The directory name carries a hyphen (fixed by the project layout); it is importe
 `ndarray_interp_amd` (see tests/conftest.py, bench.py, __graft_entry__.py).
 """
 from . import _capi
-from ._arrays import output_empty, output_trim, striped_ring
+from ._arrays import OUTPUT_OWNED_MIN_BYTES, output_empty, output_trim, striped_ring
 from .errors import BuilderError, DeviceError, InterpolateError, Panic
 from .interp1d import (BoundaryCondition, CubicSpline, CubicSplineStrategy, Interp1D, Interp1DBuilder,
                        Interp1DStrategy, Interp1DStrategyBuilder, Linear, RowBoundary, SingleBoundary)

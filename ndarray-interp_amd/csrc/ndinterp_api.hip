@@ -2896,10 +2896,9 @@ struct Interp2DImpl final : Interp2DBase {
         if (!P.compact) sc.recq2.reserve(nq * 2 * sizeof(T));
         sc.cursor2.reserve(((size_t)nb + 4) * sizeof(uint32_t));
         const size_t shm_c = ((size_t)3 * ntx + (size_t)2 * gthreads) * 4;
-        constexpr int fr_env = 4;
         static const int ft_env = [] { const char* e = std::getenv("NDI_GROUP_FINE_THREADS"); return e ? std::atoi(e) : 0; }();
         constexpr int fg_env = 0;
-        const int FR = (fr_env == 2 || fr_env == 8) ? fr_env : 4;   // records per thread and round of the fine pass
+        constexpr int FR = 4;   // records per thread and round of the fine pass (2 / 8 measured level: r05_c3_fine_round_variants.txt)
         const unsigned fthreads = (ft_env == 256 || ft_env == 512 || ft_env == 1024) ? (unsigned)ft_env : 1024u;
         // parts per tile row: one round per workgroup on evenly spread queries (measured at C3, profiles/r05_tuning.md:
         // 2560 one-round workgroups 78 us; 512 workgroups walking five rounds each with the next round's records in
@@ -2955,8 +2954,8 @@ struct Interp2DImpl final : Interp2DBase {
           if (fsort_env == 2) NDI_FSORT(8, 512); else if (fsort_env == 3) NDI_FSORT(4, 1024); else if (fsort_env == 4) NDI_FSORT(2, 512);
           else if (fsort_env == 5) NDI_FSORT(4, 256); else NDI_FSORT(4, 512);
 #undef NDI_FSORT
-        } else if (P.compact) { if (FR == 2) NDI_FINE(true, 2); else if (FR == 8) NDI_FINE(true, 8); else NDI_FINE(true, 4); }
-        else { if (FR == 2) NDI_FINE(false, 2); else if (FR == 8) NDI_FINE(false, 8); else NDI_FINE(false, 4); }
+        } else if (P.compact) NDI_FINE(true, FR);
+        else NDI_FINE(false, FR);
 #undef NDI_COARSE
 #undef NDI_FINE
       } else if (P.compact)

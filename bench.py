@@ -574,6 +574,22 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
                 owned.append(time_into(o))
                 del o
                 pkg.output_trim()                 # (a kept buffer would be handed out again: every candidate is a fresh allocation here)
+        # Interp1D::interp_array itself, call after call (interp1d/mod.rs:197-211): its allocation -- after the first call a
+        # buffer ndi_output_free kept, handed out again without a refill (NDI_OUTPUT_UNINITIALIZED) -- plus the evaluation with
+        # the kernel's own range test; the result is dropped before the next call, as a consumer that is done with it would
+        ia_ms = ia_info = None
+        if hasattr(pkg, "output_empty"):
+            r = interp.interp_array(qd)
+            torch.cuda.synchronize()
+            ia_info = getattr(r, "ndi_output_info", None)
+            del r
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = interp.interp_array(qd)
+                del r
+            torch.cuda.synchronize()
+            ia_ms = (time.perf_counter() - t0) / steps * 1e3
+            pkg.output_trim()
         kms, wall, prof = runs[0]                  # the FIRST allocation, no selection
         ntab = x.size + (2 * (x.size - 1) if strat_name == "cubic" else 0)
         comp = nq * lanes * el + ntab * lanes * el + nq * 16
@@ -593,6 +609,10 @@ def long_rows_leg(pkg, torch, dev, traffic_store, steps=3):
                     "frac_library_owned_outputs": [frac_of(r[0]) for r in owned],
                     "library_owned_info": owned_info,
                     "Mpoints_s": round(nq * lanes / wall / 1e6, 1),
+                    "interp_array_ms_per_call": round(ia_ms, 4) if ia_ms else None,
+                    "interp_array_Mpoints_s": round(nq * lanes / (ia_ms * 1e-3) / 1e6, 1) if ia_ms else None,
+                    "interp_array_note": "Interp1D::interp_array call after call, allocation included (a kept library-owned buffer, "
+                                         "no refill), result dropped before the next call; first call's allocation: " + json.dumps(ia_info),
                     "compulsory_bytes_per_launch": int(comp), "frac": frac_of(kms),
                     "bytes_basis": "compulsory bytes per launch (output + tables + query records, once)",
                     "survey_8d_model_bytes": int(model),
@@ -861,7 +881,7 @@ def secondary_summary(sec):
     for k in ("c2", "c2_linear", "c2_f32"):
         if k in sec:
             out[k] = pick(sec[k], "ms_per_step", "kernel_ms", "frac", "kernel_ms_per_output_buffer", "kernel_ms_library_owned_outputs",
-                          "frac_library_owned_outputs")
+                          "frac_library_owned_outputs", "interp_array_ms_per_call")
     if "host_path" in sec:
         out["host_path_GBps"] = sec["host_path"].get("output_GBps")
     if "c1" in sec:

@@ -398,7 +398,15 @@ ndi_status ndi_validate2d(int32_t dtype, const void* host_x, uint64_t x_len, con
  * ndi_output_free keeps up to two freed buffers of >= 1 GiB (together at most a third of the device's memory) for the next
  * request of the same size on the same device -- a fresh 32.8 GB allocation costs the allocator 0.7-1.4 s, a caller that
  * evaluates batch after batch would pay it on every call -- and ndi_output_alloc hands such a buffer out again, zeroed
- * (info->tries == 0).  ndi_output_trim releases the kept buffers. */
+ * (info->tries == 0).  ndi_output_trim releases the kept buffers.
+ * `flags` = NDI_OUTPUT_UNINITIALIZED: the contents are unspecified -- for a caller that overwrites every row it will read, as
+ * interp_array does (the buffer is dropped on Err, src/interp1d/mod.rs:210): a kept buffer then goes out without the refill
+ * (zeroing 32.8 GB costs what evaluating into it costs); new candidates are still filled, the fill being the measurement.
+ * ndi_output_free waits for the device before it keeps a buffer, as hipFree does before it releases one. */
+typedef enum ndi_output_flags {
+  NDI_OUTPUT_ZEROED = 0,
+  NDI_OUTPUT_UNINITIALIZED = 1
+} ndi_output_flags;
 typedef struct ndi_output_info {
   uint32_t tries;          /* candidates allocated and filled (0: a buffer kept by ndi_output_free was reused) */
   uint32_t reserved;
@@ -406,7 +414,8 @@ typedef struct ndi_output_info {
   double worst_fill_tbps;  /* ... of the slowest candidate seen */
   double alloc_ms;         /* wall time of the whole call */
 } ndi_output_info;
-ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max_tries, void** out, ndi_output_info* info);
+ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max_tries, uint32_t flags, void** out,
+                            ndi_output_info* info);
 ndi_status ndi_output_free(void* p);
 ndi_status ndi_output_trim(void);
 

@@ -12,7 +12,7 @@ The directory name carries a hyphen (fixed by the project layout); it is importe
 `ndarray_interp_amd` (see tests/conftest.py, bench.py, __graft_entry__.py).
 """
 from . import _capi
-from ._arrays import OUTPUT_OWNED_MIN_BYTES, output_empty, output_trim, striped_ring
+from ._arrays import OUTPUT_OWNED_MIN_BYTES, output_empty, output_trim, output_zeros, striped_ring
 from .errors import BuilderError, DeviceError, InterpolateError, Panic
 from .interp1d import (BoundaryCondition, CubicSpline, CubicSplineStrategy, Interp1D, Interp1DBuilder,
                        Interp1DStrategy, Interp1DStrategyBuilder, Linear, RowBoundary, SingleBoundary)
@@ -47,6 +47,6 @@ __all__ = [
     "Interp1D", "Interp1DBuilder", "Interp1DStrategy", "Interp1DStrategyBuilder", "Linear", "CubicSpline",
     "CubicSplineStrategy", "BoundaryCondition", "RowBoundary", "SingleBoundary",
     "Interp2D", "Interp2DBuilder", "Interp2DStrategy", "Interp2DStrategyBuilder", "Bilinear",
-    "Monotonic", "monotonic_prop", "get_lower_index", "Locator", "sharding", "device_count", "striped_ring", "output_empty", "output_trim",
+    "Monotonic", "monotonic_prop", "get_lower_index", "Locator", "sharding", "device_count", "striped_ring", "output_empty", "output_zeros", "output_trim",
     "profile_enable", "profile_read", "PATH_AUTO", "PATH_GATHER", "PATH_BUCKETED",
 ]

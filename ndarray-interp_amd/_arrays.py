@@ -85,7 +85,7 @@ class _OwnedOutput:
     """A buffer from ndi_output_alloc exposed through __cuda_array_interface__: torch.as_tensor() wraps it without a copy
     and keeps this object alive; the buffer goes back with ndi_output_free when the last tensor over it is gone."""
 
-    def __init__(self, shape, dtype, device, max_tries=0):
+    def __init__(self, shape, dtype, device, max_tries=0, zeroed=True):
         import ctypes
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
@@ -93,7 +93,9 @@ class _OwnedOutput:
         nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
         ptr = ctypes.c_void_p()
         self.info = _capi.OutputInfo()
-        st = _capi.lib().ndi_output_alloc(self.device, nbytes, int(max_tries), ctypes.byref(ptr), ctypes.byref(self.info))
+        st = _capi.lib().ndi_output_alloc(self.device, nbytes, int(max_tries),
+                                          _capi.OUTPUT_ZEROED if zeroed else _capi.OUTPUT_UNINITIALIZED,
+                                          ctypes.byref(ptr), ctypes.byref(self.info))
         if st != _capi.OK:
             from .errors import DeviceError
             raise DeviceError(_capi.last_error())
@@ -118,13 +120,20 @@ def output_trim() -> None:
     _capi.lib().ndi_output_trim()
 
 
-def output_empty(shape, dtype=np.float64, device: int = 0, max_tries: int = 0):
-    """A library-owned device output buffer (ndi_output_alloc: the reference's Array::zeros, interp1d/mod.rs:209, with the
+def output_empty(shape, dtype=np.float64, device: int = 0, max_tries: int = 0, zeroed: bool = False):
+    """A library-owned device output buffer (ndi_output_alloc: the allocation of interp_array, interp1d/mod.rs:209, with the
     placement check of include/ndinterp.h) as a torch tensor of `shape`.  `tensor.ndi_output_info` tells how many candidates
-    were tried and the fill rate of the one kept."""
-    own = _OwnedOutput(shape, dtype, device, max_tries)
+    were tried and the fill rate of the one kept.  Contents unspecified (NDI_OUTPUT_UNINITIALIZED: a buffer kept by
+    ndi_output_free comes back without a refill -- interp_array overwrites every row or drops the buffer); `output_zeros`
+    is the reference's Array::zeros."""
+    own = _OwnedOutput(shape, dtype, device, max_tries, zeroed)
     with torch.cuda.device(device):
         t = torch.as_tensor(own, device=f"cuda:{device}")
     t.ndi_output_info = {"tries": own.info.tries, "fill_TBps": round(own.info.fill_tbps, 3),
                          "worst_fill_TBps": round(own.info.worst_fill_tbps, 3), "alloc_ms": round(own.info.alloc_ms, 2)}
     return t
+
+
+def output_zeros(shape, dtype=np.float64, device: int = 0, max_tries: int = 0):
+    """`output_empty` filled with zeros: Array::zeros (interp1d/mod.rs:209)."""
+    return output_empty(shape, dtype, device, max_tries, zeroed=True)

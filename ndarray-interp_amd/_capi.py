@@ -25,6 +25,7 @@ LINEAR, CUBIC_SPLINE = 0, 1
 BC_NOT_A_KNOT, BC_NATURAL, BC_CLAMPED, BC_FIRST_DERIV, BC_SECOND_DERIV = range(5)
 BUILD_DEFAULT, BUILD_REFERENCE_ORDER = 0, 1
 EVAL_DEFAULT, EVAL_FRESH_OUTPUT, EVAL_ROWS_AFTER_ERROR_UNSPECIFIED = 0, 1, 2
+OUTPUT_ZEROED, OUTPUT_UNINITIALIZED = 0, 1   # ndi_output_flags
 PATH_AUTO, PATH_GATHER, PATH_BUCKETED = 0, 1, 2
 PATH_NAMES = {0: "auto", 1: "gather", 2: "bucketed"}
 
@@ -130,7 +131,7 @@ SYMBOLS = {
     "ndi_monotonic_prop": (C.c_int32, [C.c_int32, _P, C.c_uint64]),
     "ndi_validate1d": (C.c_int, [C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_int32]),
     "ndi_validate2d": (C.c_int, [C.c_int32, _P, C.c_uint64, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
-    "ndi_output_alloc": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(_P), C.POINTER(OutputInfo)]),
+    "ndi_output_alloc": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(OutputInfo)]),
     "ndi_output_free": (C.c_int, [_P]),
     "ndi_output_trim": (C.c_int, []),
     "ndi_device_count": (C.c_int32, []),

@@ -4767,8 +4767,10 @@ static double timed_zero_fill(void* p, size_t bytes, hipEvent_t a, hipEvent_t b)
 }
 }  // namespace ndi
 
-NDI_API ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max_tries, void** out, ndi_output_info* info) {
+NDI_API ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max_tries, uint32_t flags, void** out,
+                                    ndi_output_info* info) {
   if (!out) return ndi::fail(NDI_BAD_ARG, "null argument");
+  if (flags & ~(uint32_t)NDI_OUTPUT_UNINITIALIZED) return ndi::fail(NDI_BAD_ARG, "unknown ndi_output_flags bit");
   *out = nullptr;
   if (info) *info = ndi_output_info{};
   if (bytes == 0) return ndi::fail(NDI_BAD_ARG, "zero-sized output");
@@ -4806,7 +4808,9 @@ NDI_API ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max
         }
     }
     if (hit) {
-      const double ms = ndi::timed_zero_fill(hit, bytes, ea, eb);
+      // NDI_OUTPUT_UNINITIALIZED: the caller overwrites every row it reads (interp_array: the buffer is dropped on Err), so a
+      // kept buffer -- whose placement is known -- goes out as it is; the zero fill of 32.8 GB costs what evaluating into it costs
+      const double ms = (flags & NDI_OUTPUT_UNINITIALIZED) ? 0.0 : ndi::timed_zero_fill(hit, bytes, ea, eb);
       {
         std::lock_guard<std::mutex> g(R.mu);
         R.live[hit] = {device, (size_t)bytes};
@@ -4814,7 +4818,7 @@ NDI_API ndi_status ndi_output_alloc(int32_t device, uint64_t bytes, uint32_t max
       R.rates_set(hit, rate);
       if (info) {
         info->tries = 0;                                         // 0: a kept buffer, no candidate was allocated
-        info->fill_tbps = (double)bytes / (ms * 1e-3) / 1e12;
+        info->fill_tbps = ms > 0.0 ? (double)bytes / (ms * 1e-3) / 1e12 : rate;   // (not refilled: the rate it was kept with)
         info->worst_fill_tbps = info->fill_tbps;
         info->alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
       }
@@ -4914,6 +4918,9 @@ NDI_API ndi_status ndi_output_free(void* p) {
       kept = true;
     }
   }
+  // hipFree waits for the device; a kept buffer gives the same guarantee -- whoever gets it next (possibly without a refill,
+  // NDI_OUTPUT_UNINITIALIZED) must not meet the previous owner's kernels still writing into it from a non-blocking stream
+  if (kept) NDI_HIP(hipDeviceSynchronize());
   if (evict) {
     ndi::DeviceGuard de(evict_dev);
     NDI_HIP(hipFree(evict));

@@ -48,6 +48,9 @@ pub const NDI_BUILD_REFERENCE_ORDER: i32 = 1;
 pub const NDI_EVAL_DEFAULT: i32 = 0;
 pub const NDI_EVAL_FRESH_OUTPUT: i32 = 1;
 pub const NDI_EVAL_ROWS_AFTER_ERROR_UNSPECIFIED: i32 = 2;
+/// `ndi_output_flags` (`ndi_output_alloc`)
+pub const NDI_OUTPUT_ZEROED: i32 = 0;
+pub const NDI_OUTPUT_UNINITIALIZED: i32 = 1;
 /// `ndi_path`
 pub const NDI_PATH_AUTO: i32 = 0;
 pub const NDI_PATH_GATHER: i32 = 1;
@@ -346,6 +349,7 @@ extern "C" {
         device: i32,
         bytes: u64,
         max_tries: u32,
+        flags: u32,
         out: *mut *mut c_void,
         info: *mut ndi_output_info,
     ) -> i32;

@@ -23,7 +23,7 @@ def test_output_alloc_zeroed_and_freed(pkg):
     for nbytes in (4096 + 8, 3 << 20, (1 << 30) + 4096):
         p = ctypes.c_void_p()
         info = cap.OutputInfo()
-        assert lib.ndi_output_alloc(0, nbytes, 0, ctypes.byref(p), ctypes.byref(info)) == cap.OK, cap.last_error()
+        assert lib.ndi_output_alloc(0, nbytes, 0, cap.OUTPUT_ZEROED, ctypes.byref(p), ctypes.byref(info)) == cap.OK, cap.last_error()
         assert p.value and info.tries >= 1 and info.fill_tbps > 0 and info.worst_fill_tbps <= info.fill_tbps
         if nbytes < (1 << 30):
             assert info.tries == 1
@@ -33,7 +33,7 @@ def test_output_alloc_zeroed_and_freed(pkg):
     big = (1 << 30) + 4096
     p1 = ctypes.c_void_p(); info = cap.OutputInfo()
     assert lib.ndi_output_trim() == cap.OK
-    assert lib.ndi_output_alloc(0, big, 1, ctypes.byref(p1), ctypes.byref(info)) == cap.OK and info.tries == 1
+    assert lib.ndi_output_alloc(0, big, 1, cap.OUTPUT_ZEROED, ctypes.byref(p1), ctypes.byref(info)) == cap.OK and info.tries == 1
     import torch
     view = torch.as_tensor(type("V", (), {"__cuda_array_interface__": {"shape": (1024,), "typestr": "<f8", "data": (p1.value, False),
                                                                        "version": 2, "strides": None}})(), device="cuda:0")
@@ -42,24 +42,43 @@ def test_output_alloc_zeroed_and_freed(pkg):
     del view
     assert lib.ndi_output_free(p1) == cap.OK
     p2 = ctypes.c_void_p()
-    assert lib.ndi_output_alloc(0, big, 1, ctypes.byref(p2), ctypes.byref(info)) == cap.OK
+    assert lib.ndi_output_alloc(0, big, 1, cap.OUTPUT_ZEROED, ctypes.byref(p2), ctypes.byref(info)) == cap.OK
     assert info.tries == 0 and p2.value == p1.value
     view = torch.as_tensor(type("V", (), {"__cuda_array_interface__": {"shape": (1024,), "typestr": "<f8", "data": (p2.value, False),
                                                                        "version": 2, "strides": None}})(), device="cuda:0")
     assert bool((view == 0).all())
     del view
-    assert lib.ndi_output_free(p2) == cap.OK and lib.ndi_output_trim() == cap.OK
+    # NDI_OUTPUT_UNINITIALIZED: the kept buffer comes back as it was left (no refill), with the fill rate it was kept with
+    view = torch.as_tensor(type("V", (), {"__cuda_array_interface__": {"shape": (1024,), "typestr": "<f8", "data": (p2.value, False),
+                                                                       "version": 2, "strides": None}})(), device="cuda:0")
+    view.fill_(5.0)
+    torch.cuda.synchronize()
+    del view
+    kept_rate = info.fill_tbps
+    assert lib.ndi_output_free(p2) == cap.OK
+    p2b = ctypes.c_void_p()
+    assert lib.ndi_output_alloc(0, big, 1, cap.OUTPUT_UNINITIALIZED, ctypes.byref(p2b), ctypes.byref(info)) == cap.OK
+    assert info.tries == 0 and p2b.value == p1.value and info.fill_tbps > 0 and info.alloc_ms < 5.0, (info.tries, info.alloc_ms, kept_rate)
+    view = torch.as_tensor(type("V", (), {"__cuda_array_interface__": {"shape": (1024,), "typestr": "<f8", "data": (p2b.value, False),
+                                                                       "version": 2, "strides": None}})(), device="cuda:0")
+    assert bool((view == 5.0).all())
+    del view
+    assert lib.ndi_output_alloc(0, big, 1, 2, ctypes.byref(p2), ctypes.byref(info)) == cap.BAD_ARG      # unknown flag bit
+    assert lib.ndi_output_free(p2b) == cap.OK and lib.ndi_output_trim() == cap.OK
     p3 = ctypes.c_void_p()
-    assert lib.ndi_output_alloc(0, big, 1, ctypes.byref(p3), ctypes.byref(info)) == cap.OK and info.tries == 1
+    assert lib.ndi_output_alloc(0, big, 1, cap.OUTPUT_ZEROED, ctypes.byref(p3), ctypes.byref(info)) == cap.OK and info.tries == 1
     assert lib.ndi_output_free(p3) == cap.OK and lib.ndi_output_trim() == cap.OK
     assert lib.ndi_output_free(ctypes.c_void_p(0x1000)) == cap.BAD_ARG
     assert lib.ndi_output_free(None) == cap.OK
     p = ctypes.c_void_p()
-    assert lib.ndi_output_alloc(0, 0, 0, ctypes.byref(p), None) == cap.BAD_ARG
-    t = pkg.output_empty((1000, 37), np.float32, 0)
+    assert lib.ndi_output_alloc(0, 0, 0, 0, ctypes.byref(p), None) == cap.BAD_ARG
+    t = pkg.output_zeros((1000, 37), np.float32, 0)
     assert t.shape == (1000, 37) and t.dtype == torch.float32 and t.is_cuda and bool((t == 0).all())
     assert t.ndi_output_info["tries"] == 1
-    t2 = pkg.output_empty((3, 5, 7), np.float64, 0)
+    te = pkg.output_empty((1000, 37), np.float32, 0)           # (contents unspecified)
+    assert te.shape == (1000, 37) and te.ndi_output_info["tries"] == 1
+    del te
+    t2 = pkg.output_zeros((3, 5, 7), np.float64, 0)
     t2[1, 2, 3] = 4.0
     assert float(t2.sum()) == 4.0
     del t, t2

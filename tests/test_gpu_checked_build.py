@@ -47,12 +47,14 @@ def test_parity_suite_runs_clean_under_the_checked_library():
 @pytest.mark.gpu
 def test_round6_kernels_run_clean_under_the_checked_library():
     """Round 6's kernels under the checked build: the slope-record 2-D kernel (cell indices, strip slots), the wide spline
-    build, the sliced-output store paths and the library-owned outputs -- no violation, unchanged results."""
+    build, the sliced-output store paths, the library-owned outputs and the large-batch AUTO fuzz (every plan that opens at
+    1e5 .. 1e6 queries, random shapes) -- no violation, unchanged results."""
     _ensure_debug_library()
     env = dict(os.environ, NDI_LIB="libndinterp_hip_dbg.so")
-    files = [os.path.join(ROOT, "tests", f) for f in ("test_gpu_slopes2d.py", "test_gpu_spline_wide.py", "test_gpu_output_alloc.py")]
+    files = [os.path.join(ROOT, "tests", f) for f in ("test_gpu_slopes2d.py", "test_gpu_spline_wide.py", "test_gpu_output_alloc.py",
+                                                      "test_gpu_auto_fuzz.py")]
     r = subprocess.run([sys.executable, "-m", "pytest"] + files + [os.path.join(ROOT, "tests", "test_gpu_lanes.py"), "-m", "gpu", "-x", "-q",
-                        "-k", "slopes or wide_build or output or sliced_output or rows_after_error"],
+                        "-k", "slopes or wide_build or output or sliced_output or rows_after_error or auto_large_batches"],
                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1]
